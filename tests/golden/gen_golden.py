@@ -1,0 +1,495 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE's own Python (CPU, torch).
+
+Runs ONLY in the build container (needs /root/reference).  The reference's torch code for the
+kinematic / observation / reward / termination / TD(lambda) half of the tracker imports on CPU once
+empty stub modules are registered for the third-party packages it names but never calls on this
+path (isaacgym, gym, trimesh, wandb, tensorboardX ...).  This script calls those functions on seeded
+inputs and stores inputs + outputs as small .npz files.  Nothing from the reference is copied: the
+fixtures are data.
+
+The two motion clips that ship with the reference (data/terrains/*.pkl) are read with the
+non-executing reader parc_amd.util.safe_pickle (they are never unpickled); temporary motion files that
+the reference's MotionLib then loads are written by this script itself.
+
+usage:  python tests/golden/gen_golden.py
+"""
+import os
+import pickle
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("PARC_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+
+
+def _stub(name):
+    m = types.ModuleType(name)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+for _n in ["trimesh", "gym", "gym.spaces", "isaacgym", "isaacgym.gymapi", "isaacgym.gymtorch",
+           "isaacgym.gymutil", "wandb", "tensorboardX", "polyscope", "cv2", "embreex"]:
+    _stub(_n)
+sys.modules["gym"].spaces = sys.modules["gym.spaces"]
+sys.path.insert(0, REF)
+os.chdir(REF)  # the reference opens data/assets/humanoid.xml relative to its root
+
+import torch  # noqa: E402
+
+torch.set_num_threads(4)
+
+import util.torch_util as torch_util  # noqa: E402
+import anim.kin_char_model as kin_char_model  # noqa: E402
+import anim.motion_lib as motion_lib  # noqa: E402
+import util.terrain_util as terrain_util  # noqa: E402
+import util.geom_util as geom_util  # noqa: E402
+import learning.rl_util as rl_util  # noqa: E402
+import envs.ig_parkour.mgdm_dm_util as dmu  # noqa: E402
+import envs.ig_char_env as ig_char_env  # noqa: E402
+
+from parc_amd.util.safe_pickle import load_motion_file_safe  # noqa: E402
+
+OUT = HERE
+CHAR_FILE = "data/assets/humanoid.xml"
+
+
+def t(x, dtype=torch.float32):
+    return torch.tensor(np.asarray(x), dtype=dtype)
+
+
+def npy(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def rand_quat(rng, n):
+    q = rng.standard_normal((n, 4)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    return q
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrs.items()})
+    print("wrote", path, {k: npy(v).shape for k, v in arrs.items()})
+
+
+# --------------------------------------------------------------------------------------------
+def gen_quat(rng):
+    n = 192
+    a = rand_quat(rng, n)
+    b = rand_quat(rng, n)
+    # edge cases: identity, w<0, antipodal pairs, nearly equal, tiny angle
+    a[0] = [0, 0, 0, 1]
+    b[0] = [0, 0, 0, 1]
+    a[1] = [0, 0, 0, -1]
+    b[2] = -a[2]
+    b[3] = a[3]
+    b[4] = a[4] + 1e-4 * rng.standard_normal(4).astype(np.float32)
+    b[4] /= np.linalg.norm(b[4])
+    a[5] = [1e-7, 0, 0, 1]
+    a[5] /= np.linalg.norm(a[5])
+    a[6] = [0, 0, 1, 0]  # 180 deg about z
+    v = rng.standard_normal((n, 3)).astype(np.float32)
+    em = (rng.standard_normal((n, 3)) * 1.5).astype(np.float32)
+    em[0] = 0.0
+    em[1] = [1e-6, 0, 0]
+    em[2] = [0, 0, 3.5]       # |theta| > pi  -> normalize_angle wraps
+    em[3] = [4.0, 4.0, 0.0]
+    ang = (rng.standard_normal(n) * 2.0).astype(np.float32)
+    axis = rng.standard_normal((n, 3)).astype(np.float32)
+    tt = rng.random(n).astype(np.float32)
+    tt[0:3] = [0.0, 1.0, 0.5]
+    A, B, V, EM = t(a), t(b), t(v), t(em)
+    save("g1_quat",
+         a=a, b=b, v=v, exp_map=em, angle=ang, axis=axis, blend=tt,
+         quat_mul=torch_util.quat_mul(A, B),
+         quat_rotate=torch_util.quat_rotate(A, V),
+         exp_map_to_quat=torch_util.exp_map_to_quat(EM),
+         quat_to_exp_map=torch_util.quat_to_exp_map(A),
+         axis_angle_to_quat=torch_util.axis_angle_to_quat(t(axis), t(ang)),
+         quat_to_tan_norm=torch_util.quat_to_tan_norm(A),
+         slerp=torch_util.slerp(A, B, t(tt)),
+         calc_heading=torch_util.calc_heading(A),
+         calc_heading_quat_inv=torch_util.calc_heading_quat_inv(A),
+         quat_diff_angle=torch_util.quat_diff_angle(A, B),
+         )
+
+
+def load_char():
+    km = kin_char_model.KinCharModel("cpu")
+    km.load_char_file(CHAR_FILE)
+    return km
+
+
+def gen_char(km):
+    """Character description the build's own MJCF parser must reproduce (a3)."""
+    joint_type = []
+    axes = []
+    dof_idx = []
+    for j in range(km.get_num_joints()):
+        jt = km._joints[j]
+        joint_type.append(jt.joint_type.value)
+        axes.append(npy(jt.axis) if jt.axis is not None else np.zeros(3, np.float32))
+        dof_idx.append(jt.dof_idx)
+    save("g2_char",
+         parent=npy(km._parent_indices), local_translation=km._local_translation,
+         local_rotation=km._local_rotation, joint_type=np.array(joint_type, np.int32),
+         joint_axis=np.stack(axes).astype(np.float32), dof_idx=np.array(dof_idx, np.int32),
+         lower=km._lower_dof_limits, upper=km._upper_dof_limits,
+         body_names=np.array(km.get_body_names()))
+
+
+def gen_kin(rng, km, clip_frames):
+    n = 96
+    dof = (rng.standard_normal((n, 28)) * 0.8).astype(np.float32)
+    dof[0] = 0.0
+    dof[1] = clip_frames[10, 6:]
+    dof[2] = clip_frames[100, 6:]
+    dof[3, 0:3] = [0.0, 0.0, 3.3]   # spherical exp-map beyond pi
+    root_pos = (rng.standard_normal((n, 3)) * 2.0).astype(np.float32)
+    root_rot = rand_quat(rng, n)
+    D = t(dof)
+    jr = km.dof_to_rot(D)
+    back = km.rot_to_dof(jr)
+    bp, br = km.forward_kinematics(t(root_pos), t(root_rot), jr)
+    # arbitrary unit quats through rot_to_dof (hinge sign branch, w<0)
+    q = rand_quat(rng, n * 14).reshape(n, 14, 4)
+    dof_from_q = km.rot_to_dof(t(q))
+    save("g2_kin", dof=dof, root_pos=root_pos, root_rot=root_rot, joint_rot=jr, dof_back=back,
+         body_pos=bp, body_rot=br, rand_joint_rot=q, dof_from_rand=dof_from_q)
+
+
+def make_synth_clip(rng, km, num_frames, fps, seed_frames):
+    """Smooth random clip: low-frequency sinusoids around a seed pose."""
+    tt = np.arange(num_frames, dtype=np.float32) / fps
+    base = seed_frames[rng.integers(0, seed_frames.shape[0])].copy()
+    frames = np.tile(base[None], (num_frames, 1)).astype(np.float32)
+    for d in range(34):
+        amp = 0.3 if d >= 3 else 0.5
+        frames[:, d] += amp * np.sin(2 * np.pi * (0.2 + rng.random()) * tt + rng.random() * 6.28).astype(np.float32)
+    frames[:, 0] += 1.2 * tt  # walk along +x
+    frames[:, 2] = np.abs(frames[:, 2]) + 0.8
+    contacts = (rng.random((num_frames, 15)) > 0.7).astype(np.float32)
+    return frames, contacts
+
+
+def write_motion_file(path, frames, contacts, fps, loop_mode, terrain):
+    data = {"fps": fps, "loop_mode": loop_mode, "frames": frames, "contacts": contacts, "terrain": terrain}
+    with open(path, "wb") as f:
+        pickle.dump(data, f)
+
+
+def ref_terrain_from_dict(d):
+    hf = d["hf"]
+    ter = terrain_util.SubTerrain("terrain", hf.shape[0], hf.shape[1], float(d["dxdy"][0]), float(d["dxdy"][1]),
+                                  float(d["min_point"][0]), float(d["min_point"][1]), device="cpu")
+    ter.hf[:] = t(hf)
+    ter.hf_mask[:] = torch.tensor(d["hf_mask"])
+    ter.hf_maxmin[:] = t(d["hf_maxmin"])
+    return ter
+
+
+def gen_motion(rng, km, civ, teaser):
+    tmp = tempfile.mkdtemp(prefix="parc_golden_")
+    clips = []
+    # clip 0: the real shipped clip (CLAMP, 30 fps); clip 1: the other real clip
+    clips.append(("civ", civ["frames"], civ["contacts"], 30, "CLAMP"))
+    clips.append(("teaser", teaser["frames"], teaser["contacts"], 30, "CLAMP"))
+    f2, c2 = make_synth_clip(rng, km, 45, 30, civ["frames"])
+    clips.append(("synth_wrap", f2, c2, 30, "WRAP"))
+    f3, c3 = make_synth_clip(rng, km, 5, 20, civ["frames"])
+    clips.append(("synth_short", f3, c3, 20, "CLAMP"))
+    ter = ref_terrain_from_dict(civ["terrain"]).numpy_copy()
+    entries = []
+    for name, fr, co, fps, lm in clips:
+        p = os.path.join(tmp, name + ".pkl")
+        write_motion_file(p, fr.astype(np.float32), co.astype(np.float32), fps, lm, ter)
+        entries.append({"file": p, "weight": float(1.0 + len(entries))})
+    import yaml
+    ypath = os.path.join(tmp, "motions.yaml")
+    with open(ypath, "w") as f:
+        yaml.safe_dump({"motions": entries}, f)
+    mlib = motion_lib.MotionLib(ypath, km, "cpu", contact_info=True)
+
+    nq = 400
+    ids = rng.integers(0, len(clips), nq).astype(np.int64)
+    lens = npy(mlib._motion_lengths)[ids]
+    times = (rng.random(nq).astype(np.float32) * 1.4 - 0.15) * lens   # incl. <0 and > len
+    # exact frame times and the clip end
+    times[0:4] = [0.0, lens[1], 1.0 / 30.0, 2.0 / 30.0]
+    ids[0:4] = [0, 1, 0, 0]
+    times[4] = npy(mlib._motion_lengths)[2] * 2.5
+    ids[4] = 2  # wrap clip, several loops
+    out = mlib.calc_motion_frame(t(ids, torch.int64), t(times))
+    root_pos, root_rot, root_vel, root_ang_vel, joint_rot, dof_vel, contacts = out
+    dof_pos = mlib.joint_rot_to_dof(joint_rot)
+    save("g3_motion",
+         clip_names=np.array([c[0] for c in clips]),
+         clip_fps=np.array([c[3] for c in clips], np.float32),
+         clip_loop=np.array([motion_lib.LoopMode[c[4]].value for c in clips], np.int32),
+         clip_weights_in=np.array([e["weight"] for e in entries], np.float32),
+         frames_0=clips[0][1], frames_1=clips[1][1], frames_2=clips[2][1], frames_3=clips[3][1],
+         contacts_0=clips[0][2], contacts_1=clips[1][2], contacts_2=clips[2][2], contacts_3=clips[3][2],
+         motion_weights=mlib._motion_weights, motion_num_frames=mlib._motion_num_frames,
+         motion_lengths=mlib._motion_lengths, motion_start_idx=mlib._motion_start_idx,
+         motion_root_pos_delta=mlib._motion_root_pos_delta,
+         frame_root_pos=mlib._frame_root_pos, frame_root_rot=mlib._frame_root_rot,
+         frame_root_vel=mlib._frame_root_vel, frame_root_ang_vel=mlib._frame_root_ang_vel,
+         frame_joint_rot=mlib._frame_joint_rot, frame_dof_vel=mlib._frame_dof_vel,
+         frame_contacts=mlib._frame_contacts,
+         q_ids=ids, q_times=times,
+         q_root_pos=root_pos, q_root_rot=root_rot, q_root_vel=root_vel, q_root_ang_vel=root_ang_vel,
+         q_joint_rot=joint_rot, q_dof_vel=dof_vel, q_contacts=contacts, q_dof_pos=dof_pos)
+    return mlib, clips
+
+
+def gen_rays():
+    pts = geom_util.get_xy_points_cone(center=torch.zeros(2), dx=0.05, num_neg=2, num_pos=60,
+                                       num_rays_neg=3, num_rays_pos=3, angle_between_rays=0.26179938779)
+    save("g4_rays", ray_xy_points=pts, params=np.array([0.05, 2, 60, 3, 3, 0.26179938779], np.float64))
+    return pts
+
+
+def gen_heightmap(rng, civ, teaser, rays):
+    for name, d in (("civ", civ), ("teaser", teaser)):
+        ter = ref_terrain_from_dict(d["terrain"])
+        n = 128
+        lo = npy(ter.min_point)
+        hi = lo + npy(ter.dims).astype(np.float32) * npy(ter.dxdy)
+        xy = (lo + (hi - lo) * rng.random((n, 2))).astype(np.float32)
+        # some roots outside the grid -> index clamping; some high/low -> +-3 clamp
+        xy[0] = lo - 2.5
+        xy[1] = hi + 1.0
+        z = (rng.random(n) * 4.0 - 0.5).astype(np.float32)
+        z[2] = 9.0
+        z[3] = -7.0
+        heading = ((rng.random(n) * 2 - 1) * np.pi).astype(np.float32)
+        heading[4] = 0.0
+        root = np.concatenate([xy, z[:, None]], -1)
+        # what RefCharEnv._refresh_ray_obs_hfs does (mgdm_dm_util.py:158-179)
+        R = t(rays).unsqueeze(0).expand(n, -1, -1)
+        H = t(heading).unsqueeze(-1).expand(-1, R.shape[1])
+        pts = torch_util.rotate_2d_vec(R, H) + t(xy).unsqueeze(1)
+        pts_flat = pts.reshape(-1, 2)
+        hf = terrain_util.get_local_hf_from_terrain(pts_flat, ter).view(n, -1)
+        out = torch.clamp(hf - t(z).unsqueeze(-1), min=-3.0, max=3.0)
+        # distance of every query to the nearest rounding boundary (for tolerance-aware tests)
+        u = (pts_flat - ter.min_point) / ter.dxdy
+        frac = torch.abs(u - torch.floor(u) - 0.5).min(dim=-1)[0].view(n, -1)
+        save("g5_hf_" + name, hf=ter.hf, min_point=ter.min_point, dxdy=ter.dxdy, dims=npy(ter.dims),
+             root_pos=root, heading=heading, ray_hfs=out, raw_hf=hf, boundary_dist=frac,
+             grid_index=ter.get_grid_index(pts_flat).view(n, -1, 2))
+
+
+def gen_obs_reward_done(rng, km, mlib, civ, rays):
+    """One full post-physics pass of the tracker on a made-up simulator state (K3,K2,K4,K5..K10)."""
+    n = 64
+    device = "cpu"
+    M = mlib.num_motions()
+    ter = ref_terrain_from_dict(civ["terrain"])
+    motion_ids = t(rng.integers(0, M, n), torch.int64)
+    time_buf = t(rng.integers(0, 200, n).astype(np.float32) / 30.0)
+    time_buf[0] = 0.0       # first step -> no fail
+    time_buf[1] = 10.0      # timeout
+    motion_time_offsets = t(rng.random(n).astype(np.float32)) * mlib._motion_lengths[motion_ids]
+    motion_offsets = t((rng.standard_normal((M, 1, 2)) * 3.0).astype(np.float32))
+    env_offsets = torch.zeros(n, 3)
+    num_env_per_row = int(np.sqrt(n))
+    for i in range(n):
+        env_offsets[i, 0] = 2.0 * 2 * (i % num_env_per_row)
+        env_offsets[i, 1] = 2.0 * 2 * (i // num_env_per_row)
+    terrain_ids = torch.zeros(n, dtype=torch.int64)
+    key_body_ids = t([km.get_body_id(b) for b in ["right_hand", "left_hand", "right_foot", "left_foot"]], torch.int64)
+    tar_obs_steps = t([1, 2, 3, 10, 20, 30], torch.int)
+    timestep = 1.0 / 30.0
+
+    def move_to_terrain(pos, ids=None):
+        off = motion_offsets[motion_ids, terrain_ids] - env_offsets[:, 0:2]
+        while len(off.shape) < len(pos.shape):
+            off = off.unsqueeze(1)
+        return pos + off
+
+    # ---- reference state (DeepMimicEnv._update_ref_motion, dm_env.py:570-595)
+    motion_times = time_buf + motion_time_offsets
+    rp, rr, rv, rav, jr, dv, cont = mlib.calc_motion_frame(motion_ids, motion_times)
+    rp[..., 0:2] = move_to_terrain(rp[..., 0:2])
+    ref_body_pos, _ = km.forward_kinematics(rp, rr, jr)
+    ref_dof_pos = mlib.joint_rot_to_dof(jr)
+
+    # ---- simulated character = reference + perturbation
+    char_root_pos = rp + t(rng.standard_normal((n, 3)).astype(np.float32)) * 0.15
+    char_root_pos[2] = rp[2] + t([1.0, 0.0, 0.0])          # root pos fail
+    dq = torch_util.exp_map_to_quat(t(rng.standard_normal((n, 3)).astype(np.float32)) * 0.3)
+    dq[3] = torch_util.exp_map_to_quat(t([[0.0, 0.0, 1.5]]))[0]  # root rot fail
+    char_root_rot = torch_util.quat_mul(dq, rr)
+    char_root_vel = rv + t(rng.standard_normal((n, 3)).astype(np.float32)) * 0.5
+    char_root_ang_vel = rav + t(rng.standard_normal((n, 3)).astype(np.float32)) * 0.5
+    char_dof_pos = ref_dof_pos + t(rng.standard_normal((n, 28)).astype(np.float32)) * 0.2
+    char_dof_pos[4, 17:20] += 2.5                           # big pose error (right hip) -> pose fail
+    char_dof_vel = dv + t(rng.standard_normal((n, 28)).astype(np.float32)) * 1.0
+    char_joint_rot = km.dof_to_rot(char_dof_pos)
+    sim_body_pos, sim_body_rot = km.forward_kinematics(char_root_pos, char_root_rot, char_joint_rot)
+    # the simulator's rigid-body positions differ slightly from kinematic FK in general
+    char_rigid_body_pos = sim_body_pos + t(rng.standard_normal((n, 15, 3)).astype(np.float32)) * 0.01
+    char_rigid_body_pos[:, 0] = char_root_pos
+    contact_forces = t(rng.standard_normal((n, 15, 3)).astype(np.float32)) * 0.6
+    contact_forces[rng.random((n, 15)) > 0.4] = 0.0
+    contact_forces[5, 14] = t([0.0, 0.0, 250.0])
+
+    # ---- heightmap (IGParkourEnv._refresh_obs_hfs, ig_parkour_env.py:636-656)
+    glob = char_root_pos + env_offsets
+    heading = torch_util.calc_heading(char_root_rot)
+    R = rays.unsqueeze(0).expand(n, -1, -1)
+    H = heading.unsqueeze(-1).expand(-1, R.shape[1])
+    pts = (torch_util.rotate_2d_vec(R, H) + glob[:, 0:2].unsqueeze(1)).reshape(-1, 2)
+    ray_hfs = terrain_util.get_local_hf_from_terrain(pts, ter).view(n, -1) - glob[:, 2].unsqueeze(-1)
+    ray_hfs = torch.clamp(ray_hfs, min=-3.0, max=3.0)
+    u = (pts - ter.min_point) / ter.dxdy
+    hf_boundary = torch.abs(u - torch.floor(u) - 0.5).min(dim=-1)[0].view(n, -1)
+
+    # ---- target obs (DeepMimicEnv.compute_tar_obs, dm_env.py:686-718)
+    tp, tr, tj, tc = dmu.fetch_tar_obs_data(motion_ids, motion_times, mlib, timestep, tar_obs_steps)
+    tp[..., 0:2] = move_to_terrain(tp[..., 0:2])
+    tbp, _ = km.forward_kinematics(tp.reshape(-1, 3), tr.reshape(-1, 4), tj.reshape(-1, 14, 4))
+    tbp = tbp.reshape(n, 6, 15, 3)
+    tar_key_pos = tbp[..., key_body_ids, :]
+
+    # ---- obs (IGParkourEnv._compute_obs, ig_parkour_env.py:1054-1244)
+    key_pos = sim_body_pos[..., key_body_ids, :]
+    obs_dict = dmu.compute_deepmimic_obs(root_pos=char_root_pos, root_rot=char_root_rot, root_vel=char_root_vel,
+                                         root_ang_vel=char_root_ang_vel, joint_rot=char_joint_rot,
+                                         dof_vel=char_dof_vel, key_pos=key_pos, global_obs=False,
+                                         root_height_obs=False, enable_tar_obs=True, tar_root_pos=tp,
+                                         tar_root_rot=tr, tar_joint_rot=tj, tar_key_pos=tar_key_pos)
+    char_obs = obs_dict["char_obs"]
+    tar_obs = obs_dict["tar_obs"].reshape(n, -1)
+    char_contacts = (torch.norm(contact_forces, dim=-1) > 1e-5).float()
+    obs = torch.cat([char_obs, tar_obs, tc.reshape(n, -1), char_contacts, ray_hfs], dim=-1)
+    assert obs.shape[1] == 1312, obs.shape
+
+    # ---- reward (IGParkourEnv._update_reward, ig_parkour_env.py:1275-1339,1399-1404)
+    joint_err_w = t([1.0, 0.6, 0.6, 0.4, 0.0, 0.6, 0.4, 0.0, 1.0, 0.6, 0.4, 1.0, 0.6, 0.4])
+    dof_err_w = torch.zeros(28)
+    for j in range(1, 15):
+        dd = km.get_joint_dof_dim(j)
+        if dd > 0:
+            di = km.get_joint_dof_idx(j)
+            dof_err_w[di:di + dd] = joint_err_w[j - 1]
+    comp = dmu.compute_deepmimic_reward(
+        root_pos=char_root_pos, root_rot=char_root_rot, root_vel=char_root_vel, root_ang_vel=char_root_ang_vel,
+        joint_rot=char_joint_rot, dof_vel=char_dof_vel, key_pos=char_rigid_body_pos[..., key_body_ids, :],
+        tar_root_pos=rp, tar_root_rot=rr, tar_root_vel=rv, tar_root_ang_vel=rav, tar_joint_rot=jr,
+        tar_dof_vel=dv, tar_key_pos=ref_body_pos[..., key_body_ids, :],
+        joint_rot_err_w=joint_err_w, dof_err_w=dof_err_w, track_root_h=True, track_root=True)
+    w = np.array([0.5, 0.1, 0.15, 0.1, 0.15])
+    w = w / w.sum()
+    contact_w = torch.full((15,), 5.0)
+    contact_pen = torch.mean(dmu.compute_contact_reward(cont, contact_forces, contact_w), dim=-1)
+    reward = (float(w[0]) * comp[:, 0] + float(w[1]) * comp[:, 1] + float(w[2]) * comp[:, 2]
+              + float(w[3]) * comp[:, 3] + float(w[4]) * comp[:, 4]) + contact_pen
+    reward = 1.0 * reward
+
+    # ---- done (RefCharEnv.update_done + DeepMimicEnv.update_done, mgdm_dm_util.py:205-230, dm_env.py:720-783)
+    pose_term = t([0.7, 1.0, 0.7, 0.7, 0.7, 0.7, 0.7, 0.7, 1.0, 1.2, 10.0, 1.0, 1.2, 10.0])
+    global_body_pos = char_rigid_body_pos[..., 0:2] + env_offsets[:, 0:2].unsqueeze(1)
+    bgi = ter.get_grid_index(global_body_pos)
+    term_h = ter.hf[bgi[..., 0], bgi[..., 1]] + 0.15
+    done_buf = torch.zeros(n, dtype=torch.int)
+    outs = {}
+    for tag, cb in (("nocontact", torch.zeros(0, dtype=torch.int64)),
+                    ("feet", t([km.get_body_id("right_foot"), km.get_body_id("left_foot")], torch.int64))):
+        d = dmu.compute_done(done_buf=done_buf, time=time_buf, ep_len=10.0, root_rot=char_root_rot,
+                             body_pos=char_rigid_body_pos, char_root_pos=char_root_pos, tar_root_rot=rr,
+                             tar_body_pos=ref_body_pos, contact_force=contact_forces, contact_body_ids=cb,
+                             termination_heights=term_h, pose_termination=True, pose_termination_dist=pose_term,
+                             global_obs=False, enable_early_termination=True, track_root=True,
+                             root_pos_termination_dist=0.6, root_rot_termination_angle=1.309)
+        outs[tag] = d.clone()
+    motion_len = mlib.get_motion_length(motion_ids)
+    motion_end = torch.logical_and(motion_times >= motion_len,
+                                   mlib.get_motion_loop_mode(motion_ids) != motion_lib.LoopMode.WRAP.value)
+    done_final = outs["nocontact"].clone()
+    # fail-rate EMA (sequential over done envs, dm_env.py:758-772)
+    fail_rates = torch.ones(M)
+    done_any = torch.logical_or(done_final != 0, motion_end)
+    for e in torch.nonzero(done_any).flatten().tolist():
+        m = motion_ids[e]
+        if done_final[e] == 1:
+            fail_rates[m] = fail_rates[m] * (1.0 - 0.01) + 0.01
+        else:
+            fail_rates[m] = fail_rates[m] * (1.0 - 0.01)
+    done_final[motion_end] = 1
+
+    # tracking error (mgdm_dm_util.py:578-611)
+    rb_pos, rb_rot = km.forward_kinematics(rp, rr, jr)
+    terr = dmu.compute_tracking_error(char_root_pos, char_root_rot, sim_body_rot, sim_body_pos, rp, rr, rb_rot,
+                                      rb_pos, char_root_vel, char_root_ang_vel, char_dof_vel, rv, rav, dv)
+
+    save("g6_step",
+         motion_ids=motion_ids, time_buf=time_buf, motion_time_offsets=motion_time_offsets,
+         motion_offsets=motion_offsets, env_offsets=env_offsets, key_body_ids=key_body_ids,
+         tar_obs_steps=tar_obs_steps, hf=ter.hf, min_point=ter.min_point, dxdy=ter.dxdy,
+         rays=rays,
+         ref_root_pos=rp, ref_root_rot=rr, ref_root_vel=rv, ref_root_ang_vel=rav, ref_joint_rot=jr,
+         ref_dof_vel=dv, ref_contacts=cont, ref_body_pos=ref_body_pos, ref_dof_pos=ref_dof_pos,
+         char_root_pos=char_root_pos, char_root_rot=char_root_rot, char_root_vel=char_root_vel,
+         char_root_ang_vel=char_root_ang_vel, char_dof_pos=char_dof_pos, char_dof_vel=char_dof_vel,
+         char_rigid_body_pos=char_rigid_body_pos, contact_forces=contact_forces,
+         ray_hfs=ray_hfs, hf_boundary=hf_boundary,
+         tar_root_pos=tp, tar_root_rot=tr, tar_joint_rot=tj, tar_contacts=tc, tar_key_pos=tar_key_pos,
+         char_obs=char_obs, tar_obs=tar_obs, obs=obs,
+         joint_err_w=joint_err_w, dof_err_w=dof_err_w, reward_terms=comp, contact_penalty=contact_pen,
+         reward=reward, reward_w=w.astype(np.float32),
+         pose_termination_dist=pose_term, termination_heights=term_h,
+         done_nocontact=outs["nocontact"], done_feet=outs["feet"], motion_end=motion_end,
+         done_final=done_final, fail_rates=fail_rates, tracking_error=terr)
+
+
+def gen_td_lambda(rng):
+    T, n = 32, 96
+    r = rng.random((T, n)).astype(np.float32)
+    v = (rng.random((T, n)) * 100.0).astype(np.float32)
+    done = rng.choice([0, 0, 0, 0, 0, 0, 0, 1, 2, 3], size=(T, n)).astype(np.int32)
+    ret = rl_util.compute_td_lambda_return(t(r), t(v), t(done, torch.int), 0.99, 0.95)
+    # advantage normalisation (dm_ppo_agent.py:393-403)
+    vals = (rng.random((T, n)) * 100.0).astype(np.float32)
+    mask = (rng.random((T, n)) > 0.1).astype(np.float32)
+    adv = ret - t(vals)
+    ra = adv.flatten()[(t(mask) == 1.0).flatten()]
+    std, mean = torch.std_mean(ra)
+    norm_adv = torch.clamp((adv - mean) / torch.clamp_min(std, 1e-5), -4.0, 4.0)
+    # T=1 edge case
+    ret1 = rl_util.compute_td_lambda_return(t(r[:1]), t(v[:1]), t(done[:1], torch.int), 0.99, 0.95)
+    save("g9_td_lambda", r=r, next_vals=v, done=done, ret=ret, vals=vals, rand_action_mask=mask,
+         adv_mean=mean, adv_std=std, norm_adv=norm_adv, ret_T1=ret1,
+         params=np.array([0.99, 0.95, 4.0], np.float64))
+
+
+def main():
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    civ = load_motion_file_safe(os.path.join(REF, "data/terrains/civilization.pkl"))
+    teaser = load_motion_file_safe(os.path.join(REF, "data/terrains/TEASER_TERRAIN.pkl"))
+    km = load_char()
+    gen_quat(rng)
+    gen_char(km)
+    gen_kin(rng, km, civ["frames"])
+    mlib, _ = gen_motion(rng, km, civ, teaser)
+    rays = gen_rays()
+    gen_heightmap(rng, civ, teaser, rays)
+    gen_obs_reward_done(rng, km, mlib, civ, rays)
+    gen_td_lambda(rng)
+
+
+if __name__ == "__main__":
+    main()
