@@ -1,0 +1,202 @@
+/*
+ * parc_hip.h -- C-ABI of libparc_hip.so: the MI355X (gfx950) hot path of the PARC motion tracker.
+ *
+ * The reference (ZhengmaoHe/PARC) has no FFI of its own: its hot path sits behind Python classes
+ * (envs/ig_parkour/ig_parkour_env.py IGParkourEnv, learning/dm_ppo_agent.py DMPPOAgent) that call
+ * Isaac Gym binaries and chains of torch ops.  This library replaces exactly those call sites; each
+ * entry point names the reference function(s) it stands in for (paths relative to the reference
+ * root).  parc_amd/ binds it with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions:
+ *   - plain pointers and sizes only; every data pointer is a DEVICE pointer unless the name says host;
+ *   - all arithmetic fp32, indices int64 where the reference uses LongTensor, flags int32;
+ *   - `stream` is a hipStream_t passed as void*; functions enqueue work and return, they never
+ *     synchronise, allocate or free;  return 0 on success, a negative PARC_E* code on bad arguments,
+ *     a positive hipError_t if a launch failed;
+ *   - quaternions are xyzw.
+ */
+#ifndef PARC_HIP_H
+#define PARC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PARC_MAX_BODIES 16
+#define PARC_MAX_DOFS 64
+#define PARC_MAX_TAR_STEPS 6
+#define PARC_MAX_KEY_BODIES 8
+
+#define PARC_OK 0
+#define PARC_EINVAL (-1)
+#define PARC_EUNSUPPORTED (-2)
+
+/* anim/kin_char_model.py:11-15 JointType */
+#define PARC_JOINT_ROOT 0
+#define PARC_JOINT_HINGE 1
+#define PARC_JOINT_SPHERICAL 2
+#define PARC_JOINT_FIXED 3
+
+/* envs/base_env.py:12-16 DoneFlags */
+#define PARC_DONE_NULL 0
+#define PARC_DONE_FAIL 1
+#define PARC_DONE_SUCC 2
+#define PARC_DONE_TIME 3
+
+/* Kinematic tree, host struct passed by value.  anim/kin_char_model.py:142-178 (KinCharModel.init). */
+typedef struct {
+    int32_t num_bodies;                         /* 15 for data/assets/humanoid.xml */
+    int32_t dof_size;                           /* 28 */
+    int32_t max_depth;
+    int32_t parent[PARC_MAX_BODIES];            /* -1 for the root */
+    int32_t joint_type[PARC_MAX_BODIES];
+    int32_t dof_idx[PARC_MAX_BODIES];
+    int32_t depth[PARC_MAX_BODIES];
+    float local_translation[PARC_MAX_BODIES][3];
+    float local_rotation[PARC_MAX_BODIES][4];
+    float joint_axis[PARC_MAX_BODIES][3];
+} parc_char_model_t;
+
+/*
+ * Clip database in HBM.  anim/motion_lib.py:204-380 (MotionLib._load_motions) keeps seven flat frame
+ * arrays; here one frame is ONE 16-byte-aligned row so a query gathers two contiguous rows:
+ *   [0, 4B)               quaternions: root_rot, joint_rot[0..J)      (B = num_bodies quats)
+ *   [off_pos, +3)         root_pos
+ *   [off_contacts, +B)    contacts
+ *   [off_root_vel, +3) [off_root_ang_vel, +3) [off_dof_vel, +D)   (taken from frame idx0 only)
+ */
+typedef struct {
+    int32_t num_motions, num_bodies, dof_size, row_stride; /* row_stride in floats, multiple of 4 */
+    int32_t off_pos, off_contacts, off_root_vel, off_root_ang_vel, off_dof_vel;
+    const int32_t *num_frames;   /* [M] */
+    const int32_t *start_idx;    /* [M] */
+    const float *length;         /* [M] seconds */
+    const int32_t *loop_mode;    /* [M] 0 CLAMP, 1 WRAP  (anim/motion_lib.py:11-13) */
+    const float *pos_delta;      /* [M,3] */
+    const float *frames;         /* [total_frames, row_stride] */
+} parc_motion_lib_t;
+
+/* util/terrain_util.py:21-40 SubTerrain: hf[X,Y] row-major, cell centre = min_point + ij*dxdy */
+typedef struct {
+    const float *hf;
+    int32_t dim_x, dim_y;
+    float min_x, min_y, dx, dy;
+} parc_terrain_t;
+
+/* Scalars of the tracker env config (PARC/tracker_config/dm_env_default.yaml), host struct by value. */
+typedef struct {
+    int32_t num_tar_steps;                       /* tar_obs_steps: 6 */
+    float tar_dt[PARC_MAX_TAR_STEPS];            /* timestep * tar_obs_steps, seconds */
+    int32_t num_key_bodies;
+    int32_t key_body_ids[PARC_MAX_KEY_BODIES];
+    float joint_err_w[PARC_MAX_BODIES];          /* [J] */
+    float dof_err_w[PARC_MAX_DOFS];              /* [D] */
+    float contact_w[PARC_MAX_BODIES];            /* [B] */
+    float reward_w[5];                           /* pose, vel, root_pos, root_vel, key_pos (normalised) */
+    float rel_deepmimic_w;
+    float pose_termination_dist[PARC_MAX_BODIES];/* [J] */
+    int32_t pose_termination, enable_early_termination, track_root;
+    float root_pos_termination_dist, root_rot_termination_angle, termination_height;
+    int32_t num_contact_bodies;
+    int32_t contact_body_mask[PARC_MAX_BODIES];  /* 1 = body may touch the ground */
+    float episode_length, contact_eps, min_obs_h, max_obs_h;
+    int32_t num_ray_points;                      /* 441 */
+    int32_t obs_dim;                             /* 1312 */
+} parc_track_cfg_t;
+
+/*
+ * Per-env device buffers.  The first four are the Isaac Gym state tensors the reference wraps at
+ * envs/ig_env.py:764-780 (same row layout: pos3 quat4 linvel3 angvel3).
+ */
+typedef struct {
+    int32_t num_envs;
+    const float *root_state;        /* [N,13] */
+    const float *dof_state;         /* [N,D,2] pos,vel interleaved */
+    const float *rigid_body_state;  /* [N,B,13] */
+    const float *contact_forces;    /* [N,B,3] */
+    const float *env_offsets;       /* [N,3]   ig_parkour_env.py:496-501 */
+    const int64_t *motion_ids;      /* [N]     dm_env.py:98 */
+    const float *motion_time_offsets; /* [N]   dm_env.py:100 */
+    const float *motion_xy_offset;  /* [N,2] = motion_offsets[motion_id, terrain_id]  (dm_env.py:604-615) */
+    const float *time_buf;          /* [N] */
+    /* outputs */
+    float *ref_root_pos, *ref_root_rot, *ref_root_vel, *ref_root_ang_vel; /* [N,3] [N,4] [N,3] [N,3] */
+    float *ref_joint_rot, *ref_dof_vel, *ref_dof_pos;                     /* [N,J,4] [N,D] [N,D] */
+    float *ref_contacts, *ref_body_pos;                                   /* [N,B] [N,B,3] */
+    float *obs;                     /* [N,obs_dim]; columns [obs_dim-P, obs_dim) belong to parc_refresh_obs_hfs */
+    float *reward;                  /* [N] */
+    float *reward_terms;            /* [6,N]: pose_r vel_r root_pos_r root_vel_r key_pos_r contact_penalty */
+    int32_t *done;                  /* [N]  DoneFlags after the motion-end override (dm_env.py:782) */
+    int32_t *done_kind;             /* [N]  0 none, 1 failed, 2 ended without failing (feeds parc_update_fail_rates) */
+} parc_env_buffers_t;
+
+/* ---- K5: local heightmap ---------------------------------------------------------------------
+ * RefCharEnv._refresh_ray_obs_hfs  envs/ig_parkour/mgdm_dm_util.py:158-179
+ * + terrain_util.get_local_hf_from_terrain util/terrain_util.py:1329-1346, SubTerrain.get_grid_index :113-126.
+ * root_pos_xyz [N,3] is the GLOBAL position (env offset added), heading [N] = calc_heading(root_rot).
+ * out row e starts at out + e*out_stride (floats); P values per row: clamp(hf - z, min_h, max_h). */
+int parc_refresh_ray_obs_hfs(void *stream, int n_envs, const float *ray_xy, int n_points,
+                             const float *root_pos_xyz, const float *heading, parc_terrain_t terrain,
+                             float min_h, float max_h, float *out, int64_t out_stride);
+
+/* IGParkourEnv._refresh_obs_hfs  envs/ig_parkour/ig_parkour_env.py:636-656: same, but straight from the
+ * simulator's root_state [N,13] and env_offsets [N,3] (heading computed in-kernel, no temporaries). */
+int parc_refresh_obs_hfs(void *stream, int n_envs, const float *ray_xy, int n_points, const float *root_state,
+                         const float *env_offsets, parc_terrain_t terrain, float min_h, float max_h, float *out,
+                         int64_t out_stride);
+
+/* ---- K1/K4/K2: KinCharModel.dof_to_rot / rot_to_dof / forward_kinematics  anim/kin_char_model.py:478-541 */
+int parc_dof_to_rot(void *stream, parc_char_model_t model, int n, const float *dof, float *joint_rot);
+int parc_rot_to_dof(void *stream, parc_char_model_t model, int n, const float *joint_rot, float *dof);
+int parc_forward_kinematics(void *stream, parc_char_model_t model, int n, const float *root_pos, const float *root_rot,
+                            const float *joint_rot, float *body_pos, float *body_rot);
+
+/* ---- K3: MotionLib.calc_motion_frame  anim/motion_lib.py:80-112 (contact_info=True)
+ * outputs AoS: root_pos[Q,3] root_rot[Q,4] root_vel[Q,3] root_ang_vel[Q,3] joint_rot[Q,J,4] dof_vel[Q,D] contacts[Q,B] */
+int parc_calc_motion_frame(void *stream, parc_motion_lib_t mlib, int n_queries, const int64_t *motion_ids,
+                           const float *motion_times, float *root_pos, float *root_rot, float *root_vel,
+                           float *root_ang_vel, float *joint_rot, float *dof_vel, float *contacts);
+
+/* ---- clip database build: MotionLib._load_motions  anim/motion_lib.py:264-290,405-423 and
+ * KinCharModel.compute_frame_dof_vel  anim/kin_char_model.py:543-581 for all clips at once.
+ * frames [F,6+D] (root pos, root exp map, dofs), contacts [F,B] or NULL, frame_clip [F] clip index of
+ * each frame, clip_fps [M]; mlib carries num_frames/start_idx and the row layout; rows [F,row_stride] out. */
+int parc_motion_lib_build(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, int total_frames,
+                          const float *frames, const float *contacts, const int32_t *frame_clip, const float *clip_fps,
+                          float *rows);
+
+/* ---- fused post-physics pass: one launch per env step ------------------------------------------
+ * IGEnv._post_physics_step  envs/ig_env.py:839-848 for the tracker:
+ *   DeepMimicEnv._update_ref_motion        dm_env.py:570-595          (K3 + tile shift + K2 + K4)
+ *   IGParkourEnv._compute_obs              ig_parkour_env.py:1054-1244 (K1 K2 K6 K7 K8, columns [0, obs_dim-P))
+ *   IGParkourEnv._update_reward            ig_parkour_env.py:1275-1339,1399-1404 (K9)
+ *   RefCharEnv.update_done / DeepMimicEnv.update_done  mgdm_dm_util.py:205-230,392-460, dm_env.py:746-783 (K10)
+ * env_ids (int64, device) selects a subset (reset path: ig_parkour_env.py:1033-1036); NULL = all envs.
+ * what: bit0 ref-state update, bit1 observations, bit2 reward+done. */
+#define PARC_POST_REF 1
+#define PARC_POST_OBS 2
+#define PARC_POST_REWARD_DONE 4
+int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
+                         parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what);
+
+/* DeepMimicEnv.update_done's per-done-env Python loop (dm_env.py:758-772): EMA of per-clip failure rates,
+ * applied in increasing env order exactly as the reference's loop does. */
+int parc_update_fail_rates(void *stream, int n_envs, int n_motions, const int64_t *motion_ids, const int32_t *done_kind,
+                           float ema_w, float *fail_rates);
+
+/* ---- K16/K17: rl_util.compute_td_lambda_return  learning/rl_util.py:6-29  (time-major [T,N]) and the
+ * advantage normalisation of DMPPOAgent._build_train_data  learning/dm_ppo_agent.py:393-403.
+ * workspace: >= 3*1024 doubles (device), zeroing not required. */
+int parc_td_lambda_return(void *stream, int T, int N, const float *reward, const float *next_vals, const int32_t *done,
+                          float discount, float td_lambda, float *ret);
+int parc_adv_normalize(void *stream, int n, const float *ret, const float *vals, const float *rand_action_mask,
+                       float clip, float *norm_adv, float *mean_std_out /* [2] */, double *workspace);
+
+int parc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARC_HIP_H */

@@ -1,0 +1,157 @@
+"""ctypes binding of libparc_hip.so (include/parc_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this module raises.
+Tensors are handed over as raw device pointers (``tensor.data_ptr()``) together with the current
+HIP stream of torch; nothing here allocates or synchronises.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libparc_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["parc_kin.hip", "parc_sim.hip"]
+
+MAX_BODIES = 16
+MAX_DOFS = 64
+MAX_TAR_STEPS = 6
+MAX_KEY_BODIES = 8
+
+POST_REF = 1
+POST_OBS = 2
+POST_REWARD_DONE = 4
+
+c_int = ctypes.c_int
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_f = ctypes.c_float
+c_vp = ctypes.c_void_p
+
+
+class CharModelS(ctypes.Structure):
+    _fields_ = [("num_bodies", c_i32), ("dof_size", c_i32), ("max_depth", c_i32),
+                ("parent", c_i32 * MAX_BODIES), ("joint_type", c_i32 * MAX_BODIES), ("dof_idx", c_i32 * MAX_BODIES),
+                ("depth", c_i32 * MAX_BODIES),
+                ("local_translation", (c_f * 3) * MAX_BODIES), ("local_rotation", (c_f * 4) * MAX_BODIES),
+                ("joint_axis", (c_f * 3) * MAX_BODIES)]
+
+
+class MotionLibS(ctypes.Structure):
+    _fields_ = [("num_motions", c_i32), ("num_bodies", c_i32), ("dof_size", c_i32), ("row_stride", c_i32),
+                ("off_pos", c_i32), ("off_contacts", c_i32), ("off_root_vel", c_i32), ("off_root_ang_vel", c_i32),
+                ("off_dof_vel", c_i32),
+                ("num_frames", c_vp), ("start_idx", c_vp), ("length", c_vp), ("loop_mode", c_vp), ("pos_delta", c_vp),
+                ("frames", c_vp)]
+
+
+class TerrainS(ctypes.Structure):
+    _fields_ = [("hf", c_vp), ("dim_x", c_i32), ("dim_y", c_i32), ("min_x", c_f), ("min_y", c_f), ("dx", c_f), ("dy", c_f)]
+
+
+class TrackCfgS(ctypes.Structure):
+    _fields_ = [("num_tar_steps", c_i32), ("tar_dt", c_f * MAX_TAR_STEPS),
+                ("num_key_bodies", c_i32), ("key_body_ids", c_i32 * MAX_KEY_BODIES),
+                ("joint_err_w", c_f * MAX_BODIES), ("dof_err_w", c_f * MAX_DOFS), ("contact_w", c_f * MAX_BODIES),
+                ("reward_w", c_f * 5), ("rel_deepmimic_w", c_f),
+                ("pose_termination_dist", c_f * MAX_BODIES),
+                ("pose_termination", c_i32), ("enable_early_termination", c_i32), ("track_root", c_i32),
+                ("root_pos_termination_dist", c_f), ("root_rot_termination_angle", c_f), ("termination_height", c_f),
+                ("num_contact_bodies", c_i32), ("contact_body_mask", c_i32 * MAX_BODIES),
+                ("episode_length", c_f), ("contact_eps", c_f), ("min_obs_h", c_f), ("max_obs_h", c_f),
+                ("num_ray_points", c_i32), ("obs_dim", c_i32)]
+
+
+class EnvBuffersS(ctypes.Structure):
+    _fields_ = [("num_envs", c_i32),
+                ("root_state", c_vp), ("dof_state", c_vp), ("rigid_body_state", c_vp), ("contact_forces", c_vp),
+                ("env_offsets", c_vp), ("motion_ids", c_vp), ("motion_time_offsets", c_vp), ("motion_xy_offset", c_vp),
+                ("time_buf", c_vp),
+                ("ref_root_pos", c_vp), ("ref_root_rot", c_vp), ("ref_root_vel", c_vp), ("ref_root_ang_vel", c_vp),
+                ("ref_joint_rot", c_vp), ("ref_dof_vel", c_vp), ("ref_dof_pos", c_vp),
+                ("ref_contacts", c_vp), ("ref_body_pos", c_vp),
+                ("obs", c_vp), ("reward", c_vp), ("reward_terms", c_vp), ("done", c_vp), ("done_kind", c_vp)]
+
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP sources for gfx950 into parc_amd/lib/libparc_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(os.path.dirname(_HERE), "include", "parc_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libparc_hip.so is not built ({}); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "-- there is no CPU fallback".format(LIB_PATH))
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    L.parc_abi_version.restype = c_int
+    L.parc_refresh_ray_obs_hfs.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, TerrainS, c_f, c_f, c_vp, c_i64]
+    L.parc_refresh_obs_hfs.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, TerrainS, c_f, c_f, c_vp, c_i64]
+    L.parc_dof_to_rot.argtypes = [c_vp, CharModelS, c_int, c_vp, c_vp]
+    L.parc_rot_to_dof.argtypes = [c_vp, CharModelS, c_int, c_vp, c_vp]
+    L.parc_forward_kinematics.argtypes = [c_vp, CharModelS, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
+    L.parc_calc_motion_frame.argtypes = [c_vp, MotionLibS, c_int, c_vp, c_vp] + [c_vp] * 7
+    L.parc_motion_lib_build.argtypes = [c_vp, CharModelS, MotionLibS, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
+    L.parc_track_post_step.argtypes = [c_vp, CharModelS, MotionLibS, TerrainS, TrackCfgS, EnvBuffersS, c_vp, c_int, c_int]
+    L.parc_update_fail_rates.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_vp]
+    L.parc_td_lambda_return.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_f, c_f, c_vp]
+    L.parc_adv_normalize.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp]
+    for name in ("parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
+                 "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step",
+                 "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize"):
+        getattr(L, name).restype = c_int
+    if hasattr(L, "parc_sim_abi"):
+        from . import _hip_sim
+        _hip_sim.declare(L)
+
+
+EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
+            "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step",
+            "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize"]
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("{} failed with code {} ({})".format(what, rc, "bad argument" if rc == -1 else "unsupported" if rc == -2 else "hipError"))
+
+
+def stream():
+    return c_vp(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA/HIP tensor (None -> NULL)."""
+    if t is None:
+        return c_vp(0)
+    assert t.is_cuda, "HIP kernels need device tensors (no CPU fallback)"
+    assert t.is_contiguous(), "tensor must be contiguous"
+    return c_vp(t.data_ptr())
+
+
+def terrain_struct(hf, min_point, dxdy):
+    assert hf.dtype == torch.float32 and hf.is_contiguous() and hf.dim() == 2
+    return TerrainS(ptr(hf), int(hf.shape[0]), int(hf.shape[1]), float(min_point[0]), float(min_point[1]),
+                    float(dxdy[0]), float(dxdy[1]))

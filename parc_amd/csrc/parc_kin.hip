@@ -1,0 +1,872 @@
+// Kinematic / observation / reward / termination / TD(lambda) kernels of the PARC tracker hot path,
+// written for gfx950 (MI355X): 64-lane wavefronts, 16-lane body groups, LDS-staged observation rows.
+// C-ABI in include/parc_hip.h.  Reference citations are relative to the reference root.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/parc_hip.h"
+#include "parc_math.h"
+
+#define PARC_CHECK_LAUNCH()                         \
+    do {                                            \
+        hipError_t _e = hipGetLastError();          \
+        if (_e != hipSuccess) return (int)_e;       \
+    } while (0)
+
+// =============================================================================================
+// K5  local heightmap gather
+// =============================================================================================
+// One workgroup = HF_EPB consecutive envs.  Per-env scalars (global x,y,z, cos/sin heading) are computed
+// once and staged in LDS; every thread owns one 16-byte output slot (4 ray points) whose template
+// coordinates it keeps in registers across the HF_EPB envs.  Stores are whole float4s (the row's
+// misaligned head/tail elements go to the first/last slot), so a wave writes 1 KiB contiguous per
+// instruction; the heightfield itself stays in L1/L2 (a 441-point fan touches ~100 cells).
+#ifndef HF_EPB
+#define HF_EPB 4
+#endif
+#define HF_THREADS 128
+
+// util/terrain_util.py:107-126: torch.round (half to even) then clamp to the grid
+PARC_DEV float hf_lookup(const parc_terrain_t &t, float px, float py) {
+    float fi = rintf((px - t.min_x) / t.dx);
+    float fj = rintf((py - t.min_y) / t.dy);
+    fi = fminf(fmaxf(fi, 0.f), (float)(t.dim_x - 1));
+    fj = fminf(fmaxf(fj, 0.f), (float)(t.dim_y - 1));
+    return t.hf[(int)fi * t.dim_y + (int)fj];
+}
+
+template <bool FROM_STATE>
+__global__ __launch_bounds__(HF_THREADS) void hf_gather_kernel(int n_envs, const float *__restrict__ ray_xy, int n_points,
+                                                               const float *__restrict__ root, const float *__restrict__ aux,
+                                                               parc_terrain_t ter, float min_h, float max_h,
+                                                               float *__restrict__ out, int64_t out_stride, int head) {
+    __shared__ float prm[HF_EPB][5];
+    const int tid = threadIdx.x;
+    const int e0 = blockIdx.x * HF_EPB;
+    if (tid < HF_EPB) {
+        int e = e0 + tid;
+        if (e < n_envs) {
+            float gx, gy, gz, hd;
+            if (FROM_STATE) {
+                // ig_parkour_env.py:640-641: global xyz = root pos + env offset, heading from root rot
+                const float *rs = root + (size_t)e * 13;
+                gx = rs[0] + aux[3 * e + 0];
+                gy = rs[1] + aux[3 * e + 1];
+                gz = rs[2] + aux[3 * e + 2];
+                hd = calc_heading(ld4(rs + 3));
+            } else {
+                gx = root[3 * e + 0];
+                gy = root[3 * e + 1];
+                gz = root[3 * e + 2];
+                hd = aux[e];
+            }
+            prm[tid][0] = gx;
+            prm[tid][1] = gy;
+            prm[tid][2] = gz;
+            prm[tid][3] = cosf(hd);
+            prm[tid][4] = sinf(hd);
+        }
+    }
+    __syncthreads();
+    // slot 0: the `head` leading scalars; slots 1..nbody: aligned float4s; last slot: trailing scalars
+    const int nbody = (n_points - head) >> 2;
+    const int tail = n_points - head - 4 * nbody;
+    const int nslots = nbody + 2;
+    for (int q = tid; q < nslots; q += HF_THREADS) {
+        int p0, cnt;
+        if (q == 0) {
+            p0 = 0;
+            cnt = head;
+        } else if (q <= nbody) {
+            p0 = head + 4 * (q - 1);
+            cnt = 4;
+        } else {
+            p0 = head + 4 * nbody;
+            cnt = tail;
+        }
+        if (cnt == 0) continue;
+        float rx[4], ry[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int p = min(p0 + i, n_points - 1);
+            rx[i] = ray_xy[2 * p];
+            ry[i] = ray_xy[2 * p + 1];
+        }
+#pragma unroll
+        for (int ee = 0; ee < HF_EPB; ++ee) {
+            int e = e0 + ee;
+            if (e >= n_envs) break;
+            float gx = prm[ee][0], gy = prm[ee][1], gz = prm[ee][2], c = prm[ee][3], s = prm[ee][4];
+            float h[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // torch_util.rotate_2d_vec (util/torch_util.py:619-631) then + root xy
+                float px = (rx[i] * c - ry[i] * s) + gx;
+                float py = (rx[i] * s + ry[i] * c) + gy;
+                float v = hf_lookup(ter, px, py) - gz;
+                h[i] = fminf(fmaxf(v, min_h), max_h);
+            }
+            float *o = out + (size_t)e * out_stride + p0;
+            if (cnt == 4) {
+                *reinterpret_cast<float4 *>(o) = make_float4(h[0], h[1], h[2], h[3]);
+            } else {
+                for (int i = 0; i < cnt; ++i) o[i] = h[i];
+            }
+        }
+    }
+}
+
+// generic fallback (arbitrary row alignment): one thread per output value
+template <bool FROM_STATE>
+__global__ __launch_bounds__(256) void hf_gather_scalar_kernel(int n_envs, const float *__restrict__ ray_xy, int n_points,
+                                                               const float *__restrict__ root, const float *__restrict__ aux,
+                                                               parc_terrain_t ter, float min_h, float max_h,
+                                                               float *__restrict__ out, int64_t out_stride) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n_envs * n_points) return;
+    int e = (int)(idx / n_points), p = (int)(idx % n_points);
+    float gx, gy, gz, hd;
+    if (FROM_STATE) {
+        const float *rs = root + (size_t)e * 13;
+        gx = rs[0] + aux[3 * e + 0];
+        gy = rs[1] + aux[3 * e + 1];
+        gz = rs[2] + aux[3 * e + 2];
+        hd = calc_heading(ld4(rs + 3));
+    } else {
+        gx = root[3 * e + 0];
+        gy = root[3 * e + 1];
+        gz = root[3 * e + 2];
+        hd = aux[e];
+    }
+    float c = cosf(hd), s = sinf(hd);
+    float x = ray_xy[2 * p], y = ray_xy[2 * p + 1];
+    float v = hf_lookup(ter, (x * c - y * s) + gx, (x * s + y * c) + gy) - gz;
+    out[(size_t)e * out_stride + p] = fminf(fmaxf(v, min_h), max_h);
+}
+
+static int launch_hf(bool from_state, void *stream, int n_envs, const float *ray_xy, int n_points, const float *root,
+                     const float *aux, parc_terrain_t ter, float min_h, float max_h, float *out, int64_t out_stride) {
+    if (n_envs < 0 || n_points <= 0 || !ray_xy || !root || !aux || !out || !ter.hf || out_stride < n_points) return PARC_EINVAL;
+    if (n_envs == 0) return PARC_OK;
+    int head;
+    if ((out_stride & 3) == 0) {
+        head = (int)(((16 - ((uintptr_t)out & 15)) & 15) >> 2);  // same misalignment on every row
+        if (head > n_points) head = n_points;
+    } else {
+        head = n_points;  // rows are differently aligned: all-scalar path through slot 0 (not vectorised)
+    }
+    dim3 grid((n_envs + HF_EPB - 1) / HF_EPB), block(HF_THREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (head == n_points && n_points > 3) {
+        // rows are not uniformly 16-byte aligned: one thread per point, dword stores
+        long total = (long)n_envs * n_points;
+        dim3 g2((unsigned)((total + 255) / 256)), b2(256);
+        if (from_state)
+            hipLaunchKernelGGL(hf_gather_scalar_kernel<true>, g2, b2, 0, st, n_envs, ray_xy, n_points, root, aux, ter, min_h, max_h, out, out_stride);
+        else
+            hipLaunchKernelGGL(hf_gather_scalar_kernel<false>, g2, b2, 0, st, n_envs, ray_xy, n_points, root, aux, ter, min_h, max_h, out, out_stride);
+        PARC_CHECK_LAUNCH();
+        return PARC_OK;
+    }
+    if (from_state)
+        hipLaunchKernelGGL(hf_gather_kernel<true>, grid, block, 0, st, n_envs, ray_xy, n_points, root, aux, ter, min_h, max_h, out, out_stride, head);
+    else
+        hipLaunchKernelGGL(hf_gather_kernel<false>, grid, block, 0, st, n_envs, ray_xy, n_points, root, aux, ter, min_h, max_h, out, out_stride, head);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+extern "C" int parc_refresh_ray_obs_hfs(void *stream, int n_envs, const float *ray_xy, int n_points, const float *root_pos_xyz,
+                                        const float *heading, parc_terrain_t terrain, float min_h, float max_h, float *out,
+                                        int64_t out_stride) {
+    return launch_hf(false, stream, n_envs, ray_xy, n_points, root_pos_xyz, heading, terrain, min_h, max_h, out, out_stride);
+}
+
+extern "C" int parc_refresh_obs_hfs(void *stream, int n_envs, const float *ray_xy, int n_points, const float *root_state,
+                                    const float *env_offsets, parc_terrain_t terrain, float min_h, float max_h, float *out,
+                                    int64_t out_stride) {
+    return launch_hf(true, stream, n_envs, ray_xy, n_points, root_state, env_offsets, terrain, min_h, max_h, out, out_stride);
+}
+
+// =============================================================================================
+// Body-per-lane helpers: a pose is handled by a 16-lane group, lane b = body b (b = 0 root).
+// =============================================================================================
+#define GRP 16
+
+static bool model_ok(const parc_char_model_t &m) { return m.num_bodies >= 1 && m.num_bodies <= PARC_MAX_BODIES && m.dof_size <= PARC_MAX_DOFS; }
+
+PARC_DEV float shfl16(float v, int src) { return __shfl(v, src, GRP); }
+PARC_DEV q4 shfl16(q4 q, int src) { return q4{shfl16(q.x, src), shfl16(q.y, src), shfl16(q.z, src), shfl16(q.w, src)}; }
+PARC_DEV v3 shfl16(v3 v, int src) { return v3{shfl16(v.x, src), shfl16(v.y, src), shfl16(v.z, src)}; }
+PARC_DEV float sum16(float v) {
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, GRP);
+    return v;
+}
+PARC_DEV int any16(int v) {
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) v |= __shfl_xor(v, m, GRP);
+    return v;
+}
+
+// anim/kin_char_model.py:57-77: one joint's dofs -> quaternion (lane b >= 1)
+PARC_DEV q4 joint_dof_to_rot(const parc_char_model_t &m, int b, const float *dof, int stride) {
+    int jt = m.joint_type[b];
+    if (jt == PARC_JOINT_HINGE) {
+        return axis_angle_to_quat(mk3(m.joint_axis[b][0], m.joint_axis[b][1], m.joint_axis[b][2]), dof[m.dof_idx[b] * stride]);
+    } else if (jt == PARC_JOINT_SPHERICAL) {
+        int d = m.dof_idx[b];
+        return exp_map_to_quat(mk3(dof[d * stride], dof[(d + 1) * stride], dof[(d + 2) * stride]));
+    }
+    return mk4(0.f, 0.f, 0.f, 1.f);
+}
+
+// anim/kin_char_model.py:79-100: one joint's quaternion -> dofs
+PARC_DEV void joint_rot_to_dof(const parc_char_model_t &m, int b, q4 q, float *dof) {
+    int jt = m.joint_type[b];
+    if (jt == PARC_JOINT_HINGE) {
+        v3 ax;
+        float an;
+        quat_to_axis_angle(q, ax, an);
+        float d = m.joint_axis[b][0] * ax.x + m.joint_axis[b][1] * ax.y + m.joint_axis[b][2] * ax.z;
+        if (d < 0.f) an *= -1.f;
+        dof[m.dof_idx[b]] = an;
+    } else if (jt == PARC_JOINT_SPHERICAL) {
+        v3 e = quat_to_exp_map(q);
+        int d = m.dof_idx[b];
+        dof[d] = e.x;
+        dof[d + 1] = e.y;
+        dof[d + 2] = e.z;
+    }
+}
+
+// anim/kin_char_model.py:509-541, level-synchronous over the tree: lane b ends with body b's world
+// position/rotation.  jq = joint rotation of lane's body (ignored for the root lane).
+PARC_DEV void group_fk(const parc_char_model_t &m, int b, v3 root_pos, q4 root_rot, q4 jq, v3 &pos, q4 &rot) {
+    const bool valid = b < m.num_bodies;
+    const int par = (valid && b > 0) ? m.parent[b] : 0;
+    const int dep = valid ? m.depth[b] : -1;
+    q4 lq = mk4(0.f, 0.f, 0.f, 1.f);
+    v3 lt = mk3(0.f, 0.f, 0.f);
+    if (valid && b > 0) {
+        lq = quat_mul(ld4(m.local_rotation[b]), jq);
+        lt = ld3(m.local_translation[b]);
+    }
+    pos = root_pos;
+    rot = root_rot;
+    for (int lev = 1; lev <= m.max_depth; ++lev) {
+        v3 pp = shfl16(pos, par);
+        q4 pr = shfl16(rot, par);
+        if (dep == lev) {
+            pos = pp + quat_rotate(pr, lt);
+            rot = quat_mul(pr, lq);
+        }
+    }
+}
+
+struct frame_query {
+    const float *row0, *row1;
+    float blend, loop_phase;
+    int wrap;
+};
+
+// anim/motion_lib.py:443-456,527-538 (+ :458-475 loop offset)
+PARC_DEV frame_query make_query(const parc_motion_lib_t &ml, int64_t id, float time) {
+    frame_query fq;
+    float len = ml.length[id];
+    fq.wrap = ml.loop_mode[id] == 1;
+    float phase = time / len;
+    fq.loop_phase = floorf(phase);
+    if (fq.wrap) phase = phase - floorf(phase);
+    phase = fminf(fmaxf(phase, 0.f), 1.f);
+    int nf = ml.num_frames[id];
+    float fp = phase * (float)(nf - 1);
+    int i0 = (int)fp;
+    int i1 = min(i0 + 1, nf - 1);
+    fq.blend = fp - (float)i0;
+    int st = ml.start_idx[id];
+    fq.row0 = ml.frames + (size_t)(st + i0) * ml.row_stride;
+    fq.row1 = ml.frames + (size_t)(st + i1) * ml.row_stride;
+    return fq;
+}
+
+// lane b: slerped quaternion b of the frame pair (b = 0 root rotation, b >= 1 joint b-1)
+PARC_DEV q4 query_quat(const frame_query &fq, int b) {
+    float4 a = *reinterpret_cast<const float4 *>(fq.row0 + 4 * b);
+    float4 c = *reinterpret_cast<const float4 *>(fq.row1 + 4 * b);
+    return slerp(mk4(a.x, a.y, a.z, a.w), mk4(c.x, c.y, c.z, c.w), fq.blend);
+}
+
+PARC_DEV float lerp_ref(float a, float b, float t) { return (1.0f - t) * a + t * b; }
+
+PARC_DEV v3 query_root_pos(const parc_motion_lib_t &ml, const frame_query &fq, int64_t id) {
+    const float *p0 = fq.row0 + ml.off_pos, *p1 = fq.row1 + ml.off_pos;
+    v3 p = mk3(lerp_ref(p0[0], p1[0], fq.blend), lerp_ref(p0[1], p1[1], fq.blend), lerp_ref(p0[2], p1[2], fq.blend));
+    if (fq.wrap) {
+        const float *d = ml.pos_delta + 3 * id;
+        p = p + mk3(fq.loop_phase * d[0], fq.loop_phase * d[1], fq.loop_phase * d[2]);
+    }
+    return p;
+}
+
+// =============================================================================================
+// K3 standalone (16 lanes per query, 4 queries per wave)
+// =============================================================================================
+__global__ __launch_bounds__(256) void motion_frame_kernel(parc_motion_lib_t ml, int nq, const int64_t *__restrict__ ids,
+                                                           const float *__restrict__ times, float *root_pos, float *root_rot,
+                                                           float *root_vel, float *root_ang_vel, float *joint_rot,
+                                                           float *dof_vel, float *contacts) {
+    int q = (blockIdx.x * blockDim.x + threadIdx.x) / GRP;
+    int b = threadIdx.x % GRP;
+    if (q >= nq) return;
+    const int B = ml.num_bodies, J = B - 1, D = ml.dof_size;
+    int64_t id = ids[q];
+    frame_query fq = make_query(ml, id, times[q]);
+    if (b < B) {
+        q4 r = query_quat(fq, b);
+        if (b == 0) st4(root_rot + 4 * (size_t)q, r);
+        else st4(joint_rot + ((size_t)q * J + (b - 1)) * 4, r);
+        contacts[(size_t)q * B + b] = lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend);
+    }
+    if (b == 0) {
+        st3(root_pos + 3 * (size_t)q, query_root_pos(ml, fq, id));
+        st3(root_vel + 3 * (size_t)q, ld3(fq.row0 + ml.off_root_vel));
+        st3(root_ang_vel + 3 * (size_t)q, ld3(fq.row0 + ml.off_root_ang_vel));
+    }
+    for (int d = b; d < D; d += GRP) dof_vel[(size_t)q * D + d] = fq.row0[ml.off_dof_vel + d];
+}
+
+extern "C" int parc_calc_motion_frame(void *stream, parc_motion_lib_t mlib, int nq, const int64_t *ids, const float *times,
+                                      float *root_pos, float *root_rot, float *root_vel, float *root_ang_vel, float *joint_rot,
+                                      float *dof_vel, float *contacts) {
+    if (nq < 0 || mlib.num_bodies > PARC_MAX_BODIES || (mlib.row_stride & 3)) return PARC_EINVAL;
+    if (nq == 0) return PARC_OK;
+    int threads = 256, per = threads / GRP;
+    hipLaunchKernelGGL(motion_frame_kernel, dim3((nq + per - 1) / per), dim3(threads), 0, (hipStream_t)stream, mlib, nq, ids, times,
+                       root_pos, root_rot, root_vel, root_ang_vel, joint_rot, dof_vel, contacts);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+
+// =============================================================================================
+// Clip database build: MotionLib._load_motions  anim/motion_lib.py:264-290,405-423 and
+// KinCharModel.compute_frame_dof_vel  anim/kin_char_model.py:543-581, for ALL clips in one launch.
+// pass 1: pose rows (quaternions, root position, contacts); pass 2: finite-difference velocities.
+// =============================================================================================
+__global__ __launch_bounds__(256) void motion_rows_kernel(parc_char_model_t m, parc_motion_lib_t ml, int total_frames,
+                                                          const float *__restrict__ frames, const float *__restrict__ contacts,
+                                                          float *rows) {
+    int f = (blockIdx.x * blockDim.x + threadIdx.x) / GRP, b = threadIdx.x % GRP;
+    if (f >= total_frames || b >= m.num_bodies) return;
+    const float *fr = frames + (size_t)f * (6 + m.dof_size);
+    float *row = rows + (size_t)f * ml.row_stride;
+    q4 q;
+    if (b == 0) {
+        q = exp_map_to_quat(mk3(fr[3], fr[4], fr[5]));            // motion_lib.py:418
+        st3(row + ml.off_pos, ld3(fr));
+    } else {
+        q = quat_pos(joint_dof_to_rot(m, b, fr + 6, 1));           // motion_lib.py:420-421
+    }
+    st4(row + 4 * b, q);
+    row[ml.off_contacts + b] = contacts ? contacts[(size_t)f * m.num_bodies + b] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void motion_vel_kernel(parc_char_model_t m, parc_motion_lib_t ml, int total_frames,
+                                                         const int32_t *__restrict__ frame_clip, const float *__restrict__ clip_fps,
+                                                         float *rows) {
+    int f = (blockIdx.x * blockDim.x + threadIdx.x) / GRP, b = threadIdx.x % GRP;
+    if (f >= total_frames || b >= m.num_bodies) return;
+    int c = frame_clip[f];
+    int nf = ml.num_frames[c], st = ml.start_idx[c];
+    float *row = rows + (size_t)f * ml.row_stride;
+    if (nf < 2) {
+        if (b == 0) {
+            st3(row + ml.off_root_vel, mk3(0.f, 0.f, 0.f));
+            st3(row + ml.off_root_ang_vel, mk3(0.f, 0.f, 0.f));
+        }
+        for (int d = b; d < m.dof_size; d += GRP) row[ml.off_dof_vel + d] = 0.f;
+        return;
+    }
+    int f0 = min(f - st, nf - 2) + st;  // the last frame repeats the previous difference (motion_lib.py:283,288)
+    const float *r0 = rows + (size_t)f0 * ml.row_stride, *r1 = r0 + ml.row_stride;
+    float fps = clip_fps[c];
+    float dt = 1.0f / fps;
+    if (b == 0) {
+        v3 p0 = ld3(r0 + ml.off_pos), p1 = ld3(r1 + ml.off_pos);
+        st3(row + ml.off_root_vel, fps * (p1 - p0));                                        // :281-283
+        v3 em = quat_to_exp_map(quat_mul(ld4(r1), quat_conj(ld4(r0))));                     // quat_diff :286-287
+        st3(row + ml.off_root_ang_vel, fps * em);
+    } else {
+        q4 dr = quat_unit(quat_pos(quat_mul(quat_conj(ld4(r0 + 4 * b)), ld4(r1 + 4 * b))));  // kin_char_model.py:558-559
+        int jt = m.joint_type[b];
+        if (jt == PARC_JOINT_HINGE) {
+            v3 e = quat_to_exp_map(dr);
+            row[ml.off_dof_vel + m.dof_idx[b]] = m.joint_axis[b][0] * (e.x / dt) + m.joint_axis[b][1] * (e.y / dt) + m.joint_axis[b][2] * (e.z / dt);
+        } else if (jt == PARC_JOINT_SPHERICAL) {
+            v3 e = quat_to_exp_map(dr);
+            float *o = row + ml.off_dof_vel + m.dof_idx[b];
+            o[0] = e.x / dt;
+            o[1] = e.y / dt;
+            o[2] = e.z / dt;
+        }
+    }
+}
+
+extern "C" int parc_motion_lib_build(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, int total_frames,
+                                     const float *frames, const float *contacts, const int32_t *frame_clip, const float *clip_fps,
+                                     float *rows) {
+    if (!model_ok(model) || total_frames < 0 || mlib.num_bodies != model.num_bodies || (mlib.row_stride & 3)) return PARC_EINVAL;
+    if (total_frames == 0) return PARC_OK;
+    dim3 grid((total_frames + 15) / 16), block(256);
+    (void)hipMemsetAsync(rows, 0, sizeof(float) * (size_t)total_frames * mlib.row_stride, (hipStream_t)stream);
+    hipLaunchKernelGGL(motion_rows_kernel, grid, block, 0, (hipStream_t)stream, model, mlib, total_frames, frames, contacts, rows);
+    hipLaunchKernelGGL(motion_vel_kernel, grid, block, 0, (hipStream_t)stream, model, mlib, total_frames, frame_clip, clip_fps, rows);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+// =============================================================================================
+// K1 / K4 / K2 standalone (16 lanes per pose)
+// =============================================================================================
+__global__ __launch_bounds__(256) void dof_to_rot_kernel(parc_char_model_t m, int n, const float *__restrict__ dof, float *jrot) {
+    int i = (blockIdx.x * blockDim.x + threadIdx.x) / GRP, b = threadIdx.x % GRP;
+    if (i >= n || b == 0 || b >= m.num_bodies) return;
+    st4(jrot + ((size_t)i * (m.num_bodies - 1) + (b - 1)) * 4, joint_dof_to_rot(m, b, dof + (size_t)i * m.dof_size, 1));
+}
+
+__global__ __launch_bounds__(256) void rot_to_dof_kernel(parc_char_model_t m, int n, const float *__restrict__ jrot, float *dof) {
+    int i = (blockIdx.x * blockDim.x + threadIdx.x) / GRP, b = threadIdx.x % GRP;
+    if (i >= n || b == 0 || b >= m.num_bodies) return;
+    joint_rot_to_dof(m, b, ld4(jrot + ((size_t)i * (m.num_bodies - 1) + (b - 1)) * 4), dof + (size_t)i * m.dof_size);
+}
+
+__global__ __launch_bounds__(256) void fk_kernel(parc_char_model_t m, int n, const float *__restrict__ root_pos,
+                                                 const float *__restrict__ root_rot, const float *__restrict__ jrot,
+                                                 float *body_pos, float *body_rot) {
+    int i = (blockIdx.x * blockDim.x + threadIdx.x) / GRP, b = threadIdx.x % GRP;
+    bool live = i < n;
+    int ii = live ? i : 0;
+    q4 jq = mk4(0.f, 0.f, 0.f, 1.f);
+    if (b >= 1 && b < m.num_bodies) jq = ld4(jrot + ((size_t)ii * (m.num_bodies - 1) + (b - 1)) * 4);
+    v3 pos;
+    q4 rot;
+    group_fk(m, b, ld3(root_pos + 3 * (size_t)ii), ld4(root_rot + 4 * (size_t)ii), jq, pos, rot);
+    if (live && b < m.num_bodies) {
+        st3(body_pos + ((size_t)i * m.num_bodies + b) * 3, pos);
+        st4(body_rot + ((size_t)i * m.num_bodies + b) * 4, rot);
+    }
+}
+
+extern "C" int parc_dof_to_rot(void *stream, parc_char_model_t model, int n, const float *dof, float *joint_rot) {
+    if (n < 0 || !model_ok(model)) return PARC_EINVAL;
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(dof_to_rot_kernel, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, model, n, dof, joint_rot);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+extern "C" int parc_rot_to_dof(void *stream, parc_char_model_t model, int n, const float *joint_rot, float *dof) {
+    if (n < 0 || !model_ok(model)) return PARC_EINVAL;
+    if (n == 0) return PARC_OK;
+    (void)hipMemsetAsync(dof, 0, sizeof(float) * (size_t)n * model.dof_size, (hipStream_t)stream);
+    hipLaunchKernelGGL(rot_to_dof_kernel, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, model, n, joint_rot, dof);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+extern "C" int parc_forward_kinematics(void *stream, parc_char_model_t model, int n, const float *root_pos, const float *root_rot,
+                                       const float *joint_rot, float *body_pos, float *body_rot) {
+    if (n < 0 || !model_ok(model)) return PARC_EINVAL;
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(fk_kernel, dim3((n + 15) / 16), dim3(256), 0, (hipStream_t)stream, model, n, root_pos, root_rot, joint_rot,
+                       body_pos, body_rot);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+// =============================================================================================
+// Fused post-physics pass: one 128-thread workgroup per env = 8 pose groups of 16 body lanes
+//   group 0      simulated character  -> char_obs, char_contacts
+//   group 1      reference pose at t  -> ref_* state, reward, done
+//   group 2..7   target poses t+dt_s  -> tar_obs, tar_contacts
+// The observation row (columns [0, obs_dim - P)) is assembled in LDS and written with float4 stores.
+// =============================================================================================
+#define POST_THREADS 128
+#define POST_MAX_ROW 1024
+
+__global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_model_t m, parc_motion_lib_t ml, parc_terrain_t ter,
+                                                                 parc_track_cfg_t cfg, parc_env_buffers_t buf,
+                                                                 const int64_t *__restrict__ env_ids, int what) {
+    __shared__ __attribute__((aligned(16))) float row[POST_MAX_ROW];
+    const int tid = threadIdx.x;
+    const int g = tid / GRP, b = tid % GRP;
+    const int e = env_ids ? (int)env_ids[blockIdx.x] : (int)blockIdx.x;
+    const int B = m.num_bodies, J = B - 1, D = m.dof_size, K = cfg.num_key_bodies, S = cfg.num_tar_steps;
+    const int Wc = 12 + 6 * J + D + 3 * K;   // char_obs width (136)
+    const int Wt = 9 + 6 * J + 3 * K;        // one target step (105)
+    const int row_len = cfg.obs_dim - cfg.num_ray_points;  // 871
+    const bool valid = b < B;
+
+    const float *rs = buf.root_state + (size_t)e * 13;
+    const v3 c_pos = ld3(rs);
+    const q4 c_rot = ld4(rs + 3);
+    const q4 hinv = calc_heading_quat_inv(c_rot);
+    const int64_t mid = buf.motion_ids[e];
+    const float mtime = buf.time_buf[e] + buf.motion_time_offsets[e];   // dm_env.py:597-602
+    const float offx = buf.motion_xy_offset[2 * e] - buf.env_offsets[3 * e];          // dm_env.py:604-615
+    const float offy = buf.motion_xy_offset[2 * e + 1] - buf.env_offsets[3 * e + 1];
+    const float *dofs = buf.dof_state + (size_t)e * D * 2;  // interleaved pos,vel
+
+    int key_slot = -1;
+    for (int k = 0; k < K; ++k)
+        if (cfg.key_body_ids[k] == b) key_slot = k;
+
+    // ---- phase A: every group gets its pose (root transform + one joint rotation per lane)
+    const bool is_char = g == 0, is_ref = g == 1, is_tar = g >= 2 && g - 2 < S;
+    frame_query fq;
+    q4 jq = mk4(0.f, 0.f, 0.f, 1.f);
+    v3 p_root = c_pos;
+    q4 r_root = c_rot;
+    if (is_char) {
+        if (valid && b > 0) jq = joint_dof_to_rot(m, b, dofs, 2);      // K1 (kin_char_model.py:478-491)
+    } else {
+        // K3: MotionLib.calc_motion_frame at t (ref) or t + dt_s (targets); dm_env.py:570-582, mgdm_dm_util.py:279-302
+        const float t = mtime + (is_tar ? cfg.tar_dt[g - 2] : 0.f);
+        fq = make_query(ml, mid, t);
+        if (valid) jq = query_quat(fq, b);
+        p_root = query_root_pos(ml, fq, mid);
+        p_root.x += offx;                                              // _move_to_motion_terrain dm_env.py:604-615
+        p_root.y += offy;
+        r_root = shfl16(jq, 0);
+    }
+    // ---- phase B: K2 forward kinematics, level-synchronous inside the 16-lane group
+    v3 pos;
+    q4 rot;
+    group_fk(m, b, p_root, r_root, jq, pos, rot);
+
+    // ---- phase C: per-group epilogues
+    if (is_char) {
+        if (what & PARC_POST_OBS) {
+            // compute_char_obs  envs/ig_char_env.py:582-626 (global_obs False, no root height)
+            if (b == 0) {
+                quat_to_tan_norm(quat_mul(hinv, c_rot), row);
+                st3(row + 6, quat_rotate(hinv, ld3(rs + 7)));
+                st3(row + 9, quat_rotate(hinv, ld3(rs + 10)));
+            } else if (valid) {
+                quat_to_tan_norm(jq, row + 12 + 6 * (b - 1));
+            }
+            for (int d = b; d < D; d += GRP) row[12 + 6 * J + d] = dofs[2 * d + 1];
+            if (key_slot >= 0) st3(row + 12 + 6 * J + D + 3 * key_slot, quat_rotate(hinv, pos - c_pos));
+            // char contacts  ig_parkour_env.py:841-848
+            if (valid) {
+                v3 f = ld3(buf.contact_forces + ((size_t)e * B + b) * 3);
+                row[Wc + S * Wt + S * B + b] = sqrtf(dot3(f, f)) > cfg.contact_eps ? 1.f : 0.f;
+            }
+        }
+    } else if (is_ref) {
+        if (what & (PARC_POST_REF | PARC_POST_REWARD_DONE)) {
+            // DeepMimicEnv._update_ref_motion  dm_env.py:570-595
+            const v3 r_pos = p_root;
+            const q4 r_rot = r_root;
+            const q4 rq = jq;
+            float r_contact = valid ? lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend) : 0.f;
+            v3 r_vel = ld3(fq.row0 + ml.off_root_vel), r_avel = ld3(fq.row0 + ml.off_root_ang_vel);
+            if (what & PARC_POST_REF) {
+                if (b == 0) {
+                    st3(buf.ref_root_pos + 3 * (size_t)e, r_pos);
+                    st4(buf.ref_root_rot + 4 * (size_t)e, r_rot);
+                    st3(buf.ref_root_vel + 3 * (size_t)e, r_vel);
+                    st3(buf.ref_root_ang_vel + 3 * (size_t)e, r_avel);
+                } else if (valid) {
+                    st4(buf.ref_joint_rot + ((size_t)e * J + (b - 1)) * 4, rq);
+                    joint_rot_to_dof(m, b, rq, buf.ref_dof_pos + (size_t)e * D);      // K4
+                }
+                if (valid) {
+                    buf.ref_contacts[(size_t)e * B + b] = r_contact;
+                    st3(buf.ref_body_pos + ((size_t)e * B + b) * 3, pos);
+                }
+                for (int d = b; d < D; d += GRP) buf.ref_dof_vel[(size_t)e * D + d] = fq.row0[ml.off_dof_vel + d];
+            }
+            if (what & PARC_POST_REWARD_DONE) {
+                // compute_deepmimic_reward  mgdm_dm_util.py:327-390 (track_root, track_root_h)
+                float pose_e = 0.f, vel_e = 0.f, key_e = 0.f, cpen = 0.f;
+                int pose_fail = 0, fall_contact = 0, fall_height = 0;
+                const float *bs = buf.rigid_body_state + ((size_t)e * B + (valid ? b : 0)) * 13;
+                const v3 sim_pos = ld3(bs);
+                const v3 sim_root = ld3(buf.rigid_body_state + (size_t)e * B * 13);
+                if (valid && b > 0) {
+                    q4 cj = joint_dof_to_rot(m, b, dofs, 2);
+                    float da = quat_diff_angle(cj, rq);
+                    pose_e = cfg.joint_err_w[b - 1] * da * da;
+                }
+                for (int d = b; d < D; d += GRP) {
+                    float dv = fq.row0[ml.off_dof_vel + d] - dofs[2 * d + 1];
+                    vel_e += cfg.dof_err_w[d] * dv * dv;
+                }
+                if (key_slot >= 0) {
+                    v3 df = (pos - r_pos) - (sim_pos - c_pos);
+                    key_e = dot3(df, df);
+                }
+                if (valid) {
+                    // compute_contact_reward  mgdm_dm_util.py:555-576
+                    v3 f = ld3(buf.contact_forces + ((size_t)e * B + b) * 3);
+                    float fn = fminf(sqrtf(dot3(f, f)), 1.0f);
+                    float cr = -(1.0f - r_contact) * fn;
+                    cr += r_contact * fn;
+                    cpen = cfg.contact_w[b] * cr;
+                    // compute_done  mgdm_dm_util.py:392-460
+                    if (b > 0) {
+                        v3 df = (pos - r_pos) - (sim_pos - sim_root);
+                        float lim = cfg.pose_termination_dist[b - 1];
+                        pose_fail = dot3(df, df) > lim * lim;
+                    }
+                    if (cfg.num_contact_bodies > 0 && !cfg.contact_body_mask[b]) {
+                        fall_contact = fabsf(f.x) > 0.1f || fabsf(f.y) > 0.1f || fabsf(f.z) > 0.1f;
+                        float th = hf_lookup(ter, sim_pos.x + buf.env_offsets[3 * e], sim_pos.y + buf.env_offsets[3 * e + 1]) + cfg.termination_height;
+                        fall_height = sim_pos.z < th;
+                    }
+                }
+                pose_e = sum16(pose_e);
+                vel_e = sum16(vel_e);
+                key_e = sum16(key_e);
+                cpen = sum16(cpen);
+                pose_fail = any16(pose_fail);
+                fall_contact = any16(fall_contact);
+                fall_height = any16(fall_height);
+                if (b == 0) {
+                    v3 dp = r_pos - c_pos;
+                    float root_pos_err = dot3(dp, dp);
+                    float rre = quat_diff_angle(c_rot, r_rot);
+                    float rre2 = rre * rre;
+                    v3 dv = r_vel - ld3(rs + 7), dw = r_avel - ld3(rs + 10);
+                    float pose_r = expf(-0.25f * pose_e);
+                    float vel_r = expf(-0.01f * vel_e);
+                    float root_pose_r = expf(-5.0f * (root_pos_err + 0.1f * rre2));
+                    float root_vel_r = expf(-1.0f * (dot3(dv, dv) + 0.1f * dot3(dw, dw)));
+                    float key_r = expf(-10.0f * key_e);
+                    float cp = cpen / (float)B;
+                    // ig_parkour_env.py:1317-1339,1404
+                    float dm = cfg.reward_w[0] * pose_r + cfg.reward_w[1] * vel_r + cfg.reward_w[2] * root_pose_r +
+                               cfg.reward_w[3] * root_vel_r + cfg.reward_w[4] * key_r;
+                    dm += cp;
+                    buf.reward[e] = cfg.rel_deepmimic_w * dm;
+                    const int N = buf.num_envs;
+                    buf.reward_terms[0 * (size_t)N + e] = pose_r;
+                    buf.reward_terms[1 * (size_t)N + e] = vel_r;
+                    buf.reward_terms[2 * (size_t)N + e] = root_pose_r;
+                    buf.reward_terms[3 * (size_t)N + e] = root_vel_r;
+                    buf.reward_terms[4 * (size_t)N + e] = key_r;
+                    buf.reward_terms[5 * (size_t)N + e] = cp;
+                    // done
+                    const float tm = buf.time_buf[e];
+                    int done = PARC_DONE_NULL;
+                    if (tm >= cfg.episode_length) done = PARC_DONE_TIME;
+                    if (cfg.enable_early_termination) {
+                        int failed = 0;
+                        if (cfg.num_contact_bodies > 0) failed = fall_contact && fall_height;
+                        if (cfg.pose_termination) {
+                            int pf = pose_fail;
+                            if (cfg.track_root) {
+                                v3 dr = sim_root - r_pos;
+                                pf |= dot3(dr, dr) > cfg.root_pos_termination_dist * cfg.root_pos_termination_dist;
+                                pf |= fabsf(rre) > cfg.root_rot_termination_angle;
+                            }
+                            failed |= pf;
+                        }
+                        if (!(tm > 1e-5f)) failed = 0;
+                        if (failed) done = PARC_DONE_FAIL;
+                    }
+                    // DeepMimicEnv.update_done  dm_env.py:746-783
+                    int motion_end = (mtime >= ml.length[mid]) && (ml.loop_mode[mid] != 1);
+                    int kind = 0;
+                    if (done != PARC_DONE_NULL || motion_end) kind = (done == PARC_DONE_FAIL) ? 1 : 2;
+                    if (motion_end) done = PARC_DONE_FAIL;
+                    buf.done[e] = done;
+                    buf.done_kind[e] = kind;
+                }
+            }
+        }
+    } else if (is_tar) {
+        if (what & PARC_POST_OBS) {
+            // DeepMimicEnv.compute_tar_obs + compute_tar_obs  dm_env.py:686-718, mgdm_dm_util.py:462-519
+            const int s = g - 2;
+            float *o = row + Wc + s * Wt;
+            v3 rpo = quat_rotate(hinv, p_root - c_pos);
+            if (b == 0) {
+                st3(o, rpo);
+                quat_to_tan_norm(quat_mul(hinv, r_root), o + 3);
+            } else if (valid) {
+                quat_to_tan_norm(jq, o + 9 + 6 * (b - 1));
+            }
+            if (key_slot >= 0) st3(o + 9 + 6 * J + 3 * key_slot, quat_rotate(hinv, pos - p_root) + rpo);
+            if (valid)
+                row[Wc + S * Wt + s * B + b] = lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend);
+        }
+    }
+    if (what & PARC_POST_OBS) {
+        __syncthreads();
+        float *dst = buf.obs + (size_t)e * cfg.obs_dim;
+        const int n4 = row_len >> 2;
+        for (int i = tid; i < n4; i += POST_THREADS) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(row)[i];
+        for (int i = 4 * n4 + tid; i < row_len; i += POST_THREADS) dst[i] = row[i];
+    }
+}
+
+extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
+                                    parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what) {
+    if (!model_ok(model) || mlib.num_bodies != model.num_bodies || mlib.dof_size != model.dof_size) return PARC_EINVAL;
+    if (cfg.num_tar_steps < 0 || cfg.num_tar_steps > PARC_MAX_TAR_STEPS || cfg.num_key_bodies > PARC_MAX_KEY_BODIES) return PARC_EUNSUPPORTED;
+    const int B = model.num_bodies, J = B - 1, D = model.dof_size, K = cfg.num_key_bodies, S = cfg.num_tar_steps;
+    const int row_len = (12 + 6 * J + D + 3 * K) + S * (9 + 6 * J + 3 * K) + S * B + B;
+    if (row_len + cfg.num_ray_points != cfg.obs_dim || row_len > POST_MAX_ROW || (cfg.obs_dim & 3)) return PARC_EINVAL;
+    if (((uintptr_t)buf.obs & 15) || ((uintptr_t)mlib.frames & 15) || (mlib.row_stride & 3)) return PARC_EINVAL;
+    int n = env_ids ? n_sel : buf.num_envs;
+    if (n < 0) return PARC_EINVAL;
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(track_post_kernel, dim3(n), dim3(POST_THREADS), 0, (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, what);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+// =============================================================================================
+// Fail-rate EMA: one thread per clip walks the envs in order (dm_env.py:758-772)
+// =============================================================================================
+__global__ void fail_rate_kernel(int n_envs, int n_motions, const int64_t *__restrict__ motion_ids,
+                                 const int32_t *__restrict__ done_kind, float ema_w, float *fail_rates) {
+    int mi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mi >= n_motions) return;
+    float fr = fail_rates[mi];
+    bool touched = false;
+    for (int e = 0; e < n_envs; ++e) {
+        int k = done_kind[e];
+        if (k != 0 && motion_ids[e] == mi) {
+            fr = (k == 1) ? fr * (1.0f - ema_w) + ema_w : fr * (1.0f - ema_w);
+            touched = true;
+        }
+    }
+    if (touched) fail_rates[mi] = fr;
+}
+
+extern "C" int parc_update_fail_rates(void *stream, int n_envs, int n_motions, const int64_t *motion_ids, const int32_t *done_kind,
+                                      float ema_w, float *fail_rates) {
+    if (n_envs < 0 || n_motions <= 0) return PARC_EINVAL;
+    hipLaunchKernelGGL(fail_rate_kernel, dim3((n_motions + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_envs, n_motions, motion_ids,
+                       done_kind, ema_w, fail_rates);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+// =============================================================================================
+// K16 TD(lambda): one env per lane, backward recurrence in a register; [T,N] loads coalesce over envs
+// =============================================================================================
+__global__ __launch_bounds__(256) void td_lambda_kernel(int T, int N, const float *__restrict__ r, const float *__restrict__ nv,
+                                                        const int32_t *__restrict__ done, float discount, float lam, float *ret) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    size_t i = (size_t)(T - 1) * N + e;
+    float next_ret = r[i] + discount * nv[i];
+    ret[i] = next_ret;
+    for (int t = T - 2; t >= 0; --t) {
+        i = (size_t)t * N + e;
+        float reset = done[i] != PARC_DONE_NULL ? 1.f : 0.f;
+        float cl = lam * (1.0f - reset);
+        float cur = r[i] + discount * ((1.0f - cl) * nv[i] + cl * next_ret);
+        ret[i] = cur;
+        next_ret = cur;
+    }
+}
+
+extern "C" int parc_td_lambda_return(void *stream, int T, int N, const float *reward, const float *next_vals, const int32_t *done,
+                                     float discount, float td_lambda, float *ret) {
+    if (T <= 0 || N < 0) return PARC_EINVAL;
+    if (N == 0) return PARC_OK;
+    hipLaunchKernelGGL(td_lambda_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, T, N, reward, next_vals, done,
+                       discount, td_lambda, ret);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+// =============================================================================================
+// K17 advantage normalisation: deterministic two-stage (sum, sumsq, count) in fp64, then normalise
+// =============================================================================================
+#define ADV_BLOCKS 1024
+__global__ __launch_bounds__(256) void adv_partial_kernel(int n, const float *__restrict__ ret, const float *__restrict__ vals,
+                                                          const float *__restrict__ mask, double *ws) {
+    __shared__ double sh[3][256];
+    double s = 0.0, ss = 0.0, c = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (mask[i] == 1.0f) {
+            double a = (double)(ret[i] - vals[i]);
+            s += a;
+            ss += a * a;
+            c += 1.0;
+        }
+    }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = ss;
+    sh[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + st];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + st];
+            sh[2][threadIdx.x] += sh[2][threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        ws[blockIdx.x] = sh[0][0];
+        ws[ADV_BLOCKS + blockIdx.x] = sh[1][0];
+        ws[2 * ADV_BLOCKS + blockIdx.x] = sh[2][0];
+    }
+}
+
+__global__ __launch_bounds__(256) void adv_apply_kernel(int n, int nblocks, const float *__restrict__ ret, const float *__restrict__ vals,
+                                                        float clip, const double *__restrict__ ws, float *out, float *mean_std) {
+    __shared__ double sh[3][256];
+    double s = 0.0, ss = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        s += ws[i];
+        ss += ws[ADV_BLOCKS + i];
+        c += ws[2 * ADV_BLOCKS + i];
+    }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = ss;
+    sh[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + st];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + st];
+            sh[2][threadIdx.x] += sh[2][threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    double cnt = sh[2][0];
+    double mean = cnt > 0.0 ? sh[0][0] / cnt : 0.0;
+    double var = cnt > 1.0 ? fmax((sh[1][0] - cnt * mean * mean) / (cnt - 1.0), 0.0) : 0.0;  // torch.std_mean: unbiased
+    float meanf = (float)mean, stdf = (float)sqrt(var);
+    float den = fmaxf(stdf, 1e-5f);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        mean_std[0] = meanf;
+        mean_std[1] = stdf;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float a = ((ret[i] - vals[i]) - meanf) / den;
+        out[i] = fminf(fmaxf(a, -clip), clip);
+    }
+}
+
+extern "C" int parc_adv_normalize(void *stream, int n, const float *ret, const float *vals, const float *rand_action_mask, float clip,
+                                  float *norm_adv, float *mean_std_out, double *workspace) {
+    if (n <= 0 || !workspace) return PARC_EINVAL;
+    int nb = (n + 255) / 256;
+    if (nb > ADV_BLOCKS) nb = ADV_BLOCKS;
+    hipLaunchKernelGGL(adv_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, n, ret, vals, rand_action_mask, workspace);
+    hipLaunchKernelGGL(adv_apply_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, n, nb, ret, vals, clip, workspace, norm_adv, mean_std_out);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+extern "C" int parc_abi_version(void) { return 1; }

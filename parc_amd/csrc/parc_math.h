@@ -1,0 +1,153 @@
+// Device quaternion / rotation math for the tracker kernels (gfx950).
+// Quaternions are xyzw, fp32, as in the reference's util/torch_util.py; each helper follows the
+// reference's operation order so results agree with it to a few ulp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define PARC_DEV __device__ __forceinline__
+
+struct q4 {
+    float x, y, z, w;
+};
+struct v3 {
+    float x, y, z;
+};
+
+PARC_DEV v3 mk3(float x, float y, float z) { return v3{x, y, z}; }
+PARC_DEV q4 mk4(float x, float y, float z, float w) { return q4{x, y, z, w}; }
+PARC_DEV v3 operator+(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+PARC_DEV v3 operator-(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+PARC_DEV v3 operator*(float s, v3 a) { return v3{s * a.x, s * a.y, s * a.z}; }
+PARC_DEV float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PARC_DEV v3 cross3(v3 a, v3 b) { return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+// util/torch_util.py:4-7
+PARC_DEV float normalize_angle(float x) { return atan2f(sinf(x), cosf(x)); }
+
+// util/torch_util.py:40-58
+PARC_DEV q4 quat_mul(q4 a, q4 b) {
+    float ww = (a.z + a.x) * (b.x + b.y);
+    float yy = (a.w - a.y) * (b.w + b.z);
+    float zz = (a.w + a.y) * (b.w - b.z);
+    float xx = ww + yy + zz;
+    float qq = 0.5f * (xx + (a.z - a.x) * (b.x - b.y));
+    q4 o;
+    o.w = qq - ww + (a.z - a.y) * (b.y - b.z);
+    o.x = qq - xx + (a.x + a.w) * (b.x + b.w);
+    o.y = qq - yy + (a.w - a.x) * (b.y + b.z);
+    o.z = qq - zz + (a.z + a.y) * (b.w - b.x);
+    return o;
+}
+
+// util/torch_util.py:60-66
+PARC_DEV v3 quat_rotate(q4 q, v3 v) {
+    v3 qv = mk3(q.x, q.y, q.z);
+    v3 t = 2.f * cross3(qv, v);
+    v3 c = cross3(qv, t);
+    return v3{v.x + q.w * t.x + c.x, v.y + q.w * t.y + c.y, v.z + q.w * t.z + c.z};
+}
+
+PARC_DEV q4 quat_conj(q4 q) { return q4{-q.x, -q.y, -q.z, q.w}; }
+
+// util/torch_util.py:33-38
+PARC_DEV q4 quat_pos(q4 q) {
+    float s = q.w < 0.f ? -1.f : 1.f;
+    return q4{s * q.x, s * q.y, s * q.z, s * q.w};
+}
+
+// util/torch_util.py:9-12 (eps 1e-9) on a quaternion
+PARC_DEV q4 quat_unit(q4 q) {
+    float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    n = fmaxf(n, 1e-9f);
+    return q4{q.x / n, q.y / n, q.z / n, q.w / n};
+}
+
+// util/torch_util.py:311-317
+PARC_DEV q4 axis_angle_to_quat(v3 axis, float angle) {
+    float theta = angle / 2.f;
+    float n = fmaxf(sqrtf(dot3(axis, axis)), 1e-9f);
+    float s = sinf(theta);
+    q4 q = q4{axis.x / n * s, axis.y / n * s, axis.z / n * s, cosf(theta)};
+    return quat_unit(q);
+}
+
+// util/torch_util.py:394-419
+PARC_DEV q4 exp_map_to_quat(v3 em) {
+    float a = sqrtf(dot3(em, em));
+    v3 ax = v3{em.x / a, em.y / a, em.z / a};
+    a = normalize_angle(a);
+    bool ok = fabsf(a) > 1e-5f;
+    if (!ok) {
+        ax = mk3(0.f, 0.f, 1.f);
+        a = 0.f;
+    }
+    return axis_angle_to_quat(ax, a);
+}
+
+// util/torch_util.py:68-88
+PARC_DEV void quat_to_axis_angle(q4 qin, v3 &axis, float &angle) {
+    q4 q = quat_pos(qin);
+    float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
+    float a = 2.0f * atan2f(len, q.w);
+    if (len > 1e-5f) {
+        axis = v3{q.x / len, q.y / len, q.z / len};
+        angle = a;
+    } else {
+        axis = mk3(0.f, 0.f, 1.f);
+        angle = 0.f;
+    }
+}
+
+// util/torch_util.py:346-351
+PARC_DEV v3 quat_to_exp_map(q4 q) {
+    v3 ax;
+    float an;
+    quat_to_axis_angle(q, ax, an);
+    return an * ax;
+}
+
+// util/torch_util.py:427-431
+PARC_DEV float quat_diff_angle(q4 q0, q4 q1) {
+    v3 ax;
+    float an;
+    quat_to_axis_angle(quat_mul(q1, quat_conj(q0)), ax, an);
+    return an;
+}
+
+// util/torch_util.py:443-468
+PARC_DEV q4 slerp(q4 q0, q4 q1, float t) {
+    float c = q0.x * q1.x + q0.y * q1.y + q0.z * q1.z + q0.w * q1.w;
+    float sg = c < 0.f ? -1.f : 1.f;
+    q1 = q4{sg * q1.x, sg * q1.y, sg * q1.z, sg * q1.w};
+    c = fabsf(c);
+    float ht = acosf(c);
+    float s = sqrtf(1.0f - c * c);
+    float ra = sinf((1.f - t) * ht) / s;
+    float rb = sinf(t * ht) / s;
+    q4 o = q4{ra * q0.x + rb * q1.x, ra * q0.y + rb * q1.y, ra * q0.z + rb * q1.z, ra * q0.w + rb * q1.w};
+    if (fabsf(s) < 0.001f) o = q4{0.5f * q0.x + 0.5f * q1.x, 0.5f * q0.y + 0.5f * q1.y, 0.5f * q0.z + 0.5f * q1.z, 0.5f * q0.w + 0.5f * q1.w};
+    if (fabsf(c) >= 1.f) o = q0;
+    return o;
+}
+
+// util/torch_util.py:470-479
+PARC_DEV float calc_heading(q4 q) {
+    v3 d = quat_rotate(q, mk3(1.f, 0.f, 0.f));
+    return atan2f(d.y, d.x);
+}
+
+// util/torch_util.py:491-499
+PARC_DEV q4 calc_heading_quat_inv(q4 q) { return axis_angle_to_quat(mk3(0.f, 0.f, 1.f), -calc_heading(q)); }
+
+// util/torch_util.py:361-373: 6 floats = R(q) e_x | R(q) e_z
+PARC_DEV void quat_to_tan_norm(q4 q, float *o) {
+    v3 t = quat_rotate(q, mk3(1.f, 0.f, 0.f));
+    v3 n = quat_rotate(q, mk3(0.f, 0.f, 1.f));
+    o[0] = t.x; o[1] = t.y; o[2] = t.z;
+    o[3] = n.x; o[4] = n.y; o[5] = n.z;
+}
+
+PARC_DEV q4 ld4(const float *p) { return q4{p[0], p[1], p[2], p[3]}; }
+PARC_DEV v3 ld3(const float *p) { return v3{p[0], p[1], p[2]}; }
+PARC_DEV void st4(float *p, q4 q) { p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w; }
+PARC_DEV void st3(float *p, v3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }

@@ -1,0 +1,196 @@
+"""Device buffers + launch glue of the tracker's post-physics pass.
+
+Owns the tensors the reference's env classes own (IGEnv state tensors envs/ig_env.py:764-780,
+ref_* buffers ig_parkour_env.py:694-704, data buffers :771-811) and hands their raw pointers to the
+HIP kernels (include/parc_hip.h).  The env class (parc_amd/envs/ig_parkour/ig_parkour_env.py) exposes views of
+these tensors under the reference's attribute names.
+"""
+import numpy as np
+import torch
+
+from . import _hip
+
+
+class TrackerConfig:
+    """Scalars the kernels need, parsed from the env YAML (PARC/tracker_config/dm_env_default.yaml)."""
+
+    def __init__(self, env_config, kin_char_model, num_ray_points):
+        km = kin_char_model
+        B, D = km.get_num_joints(), km.get_dof_size()
+        J = B - 1
+        unsupported = []
+        if env_config.get("global_obs", False):
+            unsupported.append("global_obs=True")
+        if env_config.get("global_root_height_obs", False):
+            unsupported.append("global_root_height_obs=True")
+        if not env_config.get("enable_tar_obs", True):
+            unsupported.append("enable_tar_obs=False")
+        if not env_config.get("use_contact_info", True):
+            unsupported.append("use_contact_info=False")
+        if env_config.get("has_target_xy_obs", False):
+            unsupported.append("has_target_xy_obs=True")
+        if not env_config.get("track_root_h", True):
+            unsupported.append("track_root_h=False")
+        if not env_config.get("track_root", True):
+            unsupported.append("track_root=False")
+        if env_config.get("rel_task_w", 0.0) > 0:
+            unsupported.append("rel_task_w>0")
+        if unsupported:
+            raise NotImplementedError("tracker kernels cover the default tracker configuration; unsupported: " + ", ".join(unsupported))
+
+        self.timestep = 1.0 / env_config["control_freq"]
+        steps = list(env_config.get("tar_obs_steps", [1]))
+        keys = [km.get_body_id(n) for n in env_config.get("key_bodies", [])]
+        assert len(steps) <= _hip.MAX_TAR_STEPS and len(keys) <= _hip.MAX_KEY_BODIES
+        s = _hip.TrackCfgS()
+        s.num_tar_steps = len(steps)
+        ts = torch.tensor(steps, dtype=torch.int) * self.timestep   # mgdm_dm_util.py:289: timestep * tar_obs_steps (fp32)
+        for i, v in enumerate(ts.to(torch.float32).tolist()):
+            s.tar_dt[i] = v
+        s.num_key_bodies = len(keys)
+        for i, k in enumerate(keys):
+            s.key_body_ids[i] = k
+        jw = env_config.get("joint_err_w", None)
+        jw = [1.0] * J if jw is None else list(jw)
+        assert len(jw) == J
+        dw = np.zeros(D, dtype=np.float32)
+        for j in range(1, B):       # ig_parkour_env.py:1573-1592
+            dd = km.get_joint_dof_dim(j)
+            if dd > 0:
+                di = km.get_joint_dof_idx(j)
+                dw[di:di + dd] = jw[j - 1]
+        for i in range(J):
+            s.joint_err_w[i] = jw[i]
+        for i in range(D):
+            s.dof_err_w[i] = float(dw[i])
+        cw = env_config["contact_weights"]
+        for i in range(B):
+            s.contact_w[i] = float(cw[i])
+        w = np.array([env_config["pose_w"], env_config["vel_w"], env_config["root_pos_w"], env_config["root_vel_w"],
+                      env_config["key_pos_w"]], dtype=np.float64)
+        w = w / w.sum()             # ig_parkour_env.py:122-132
+        for i in range(5):
+            s.reward_w[i] = float(w[i])
+        s.rel_deepmimic_w = float(env_config["rel_deepmimic_w"])
+        ptd = env_config["pose_termination_dist"]
+        for i in range(J):
+            s.pose_termination_dist[i] = float(ptd[i])
+        s.pose_termination = int(bool(env_config.get("pose_termination", False)))
+        s.enable_early_termination = int(bool(env_config["enable_early_termination"]))
+        s.track_root = int(bool(env_config["track_root"]))
+        s.root_pos_termination_dist = float(env_config["root_pos_termination_dist"])
+        s.root_rot_termination_angle = float(env_config["root_rot_termination_angle"])
+        s.termination_height = float(env_config["termination_height"])
+        cb = [km.get_body_id(n) for n in env_config.get("contact_bodies", [])]
+        s.num_contact_bodies = len(cb)
+        for b in cb:
+            s.contact_body_mask[b] = 1
+        s.episode_length = float(env_config["episode_length"])
+        s.contact_eps = 1e-5        # IGParkourEnv._get_char_contact_state default eps (ig_parkour_env.py:841)
+        s.min_obs_h = float(env_config["min_obs_h"])
+        s.max_obs_h = float(env_config["max_obs_h"])
+        s.num_ray_points = int(num_ray_points)
+        K, S = len(keys), len(steps)
+        self.char_obs_dim = 12 + 6 * J + D + 3 * K
+        self.tar_obs_dim = 9 + 6 * J + 3 * K
+        self.obs_dim = self.char_obs_dim + S * self.tar_obs_dim + S * B + B + num_ray_points
+        s.obs_dim = self.obs_dim
+        self.struct = s
+        self.key_body_ids = keys
+        self.contact_body_ids = cb
+        self.tar_obs_steps = steps
+        self.num_bodies, self.dof_size = B, D
+
+
+class TrackerCore:
+    def __init__(self, num_envs, device, kin_char_model, motion_lib, cfg, ray_xy_points):
+        self.N = N = num_envs
+        self.device = device
+        self.km = kin_char_model
+        self.mlib = motion_lib
+        self.cfg = cfg
+        B, D = cfg.num_bodies, cfg.dof_size
+        f32 = dict(dtype=torch.float32, device=device)
+        z = torch.zeros
+        # Isaac Gym state tensor layouts (envs/ig_env.py:764-780)
+        self.root_state = z((N, 13), **f32)
+        self.root_state[:, 6] = 1.0
+        self.dof_state = z((N * D, 2), **f32)
+        self.rigid_body_state = z((N * B, 13), **f32)
+        self.rigid_body_state[:, 6] = 1.0
+        self.contact_forces = z((N * B, 3), **f32)
+        self.env_offsets = z((N, 3), **f32)
+        self.motion_ids = z((N,), dtype=torch.int64, device=device)
+        self.motion_terrain_ids = z((N,), dtype=torch.int64, device=device)
+        self.motion_time_offsets = z((N,), **f32)
+        self.motion_xy_offset = z((N, 2), **f32)
+        self.time_buf = z((N,), **f32)
+        self.timestep_buf = z((N,), dtype=torch.int, device=device)
+        self.ref_root_pos = z((N, 3), **f32)
+        self.ref_root_rot = z((N, 4), **f32)
+        self.ref_root_rot[:, 3] = 1.0
+        self.ref_root_vel = z((N, 3), **f32)
+        self.ref_root_ang_vel = z((N, 3), **f32)
+        self.ref_joint_rot = z((N, B - 1, 4), **f32)
+        self.ref_joint_rot[..., 3] = 1.0
+        self.ref_dof_vel = z((N, D), **f32)
+        self.ref_dof_pos = z((N, D), **f32)
+        self.ref_contacts = z((N, B), **f32)
+        self.ref_body_pos = z((N, B, 3), **f32)
+        self.obs = z((N, cfg.obs_dim), **f32)
+        self.reward = z((N,), **f32)
+        self.reward_terms = z((6, N), **f32)
+        self.done = z((N,), dtype=torch.int, device=device)
+        self.done_kind = z((N,), dtype=torch.int, device=device)
+        self.ray_xy_points = ray_xy_points.to(device=device, dtype=torch.float32).contiguous()
+        P = self.ray_xy_points.shape[0]
+        assert P == cfg.struct.num_ray_points
+        # the heightmap columns of the observation row ARE the _ray_hfs buffer (no copy)
+        self.ray_hfs = self.obs[:, cfg.obs_dim - P:]
+        self.terrain = None
+        self._terrain_struct = None
+        self._buf_struct = None
+
+    def set_terrain(self, terrain):
+        self.terrain = terrain
+        hf = terrain.hf.to(device=self.device, dtype=torch.float32).contiguous()
+        self._hf = hf
+        self._terrain_struct = _hip.terrain_struct(hf, terrain.min_point.tolist(), terrain.dxdy.tolist())
+
+    def buffers(self):
+        if self._buf_struct is None:
+            p = _hip.ptr
+            self._buf_struct = _hip.EnvBuffersS(
+                self.N, p(self.root_state), p(self.dof_state), p(self.rigid_body_state), p(self.contact_forces),
+                p(self.env_offsets), p(self.motion_ids), p(self.motion_time_offsets), p(self.motion_xy_offset), p(self.time_buf),
+                p(self.ref_root_pos), p(self.ref_root_rot), p(self.ref_root_vel), p(self.ref_root_ang_vel),
+                p(self.ref_joint_rot), p(self.ref_dof_vel), p(self.ref_dof_pos), p(self.ref_contacts), p(self.ref_body_pos),
+                p(self.obs), p(self.reward), p(self.reward_terms), p(self.done), p(self.done_kind))
+        return self._buf_struct
+
+    # ---- K5 (IGParkourEnv._refresh_obs_hfs)
+    def refresh_obs_hfs(self):
+        c = self.cfg.struct
+        P = c.num_ray_points
+        out = _hip.c_vp(self.obs.data_ptr() + 4 * (self.cfg.obs_dim - P))
+        _hip.check(_hip.lib().parc_refresh_obs_hfs(_hip.stream(), self.N, _hip.ptr(self.ray_xy_points), P, _hip.ptr(self.root_state),
+                                                  _hip.ptr(self.env_offsets), self._terrain_struct, c.min_obs_h, c.max_obs_h, out,
+                                                  self.cfg.obs_dim), "parc_refresh_obs_hfs")
+
+    # ---- fused K3/K2/K4/K6-K10
+    def post_step(self, what, env_ids=None):
+        if env_ids is not None:
+            env_ids = env_ids.to(torch.int64).contiguous()
+            n = int(env_ids.shape[0])
+            if n == 0:
+                return
+            ids = _hip.ptr(env_ids)
+        else:
+            n, ids = 0, _hip.c_vp(0)
+        _hip.check(_hip.lib().parc_track_post_step(_hip.stream(), self.km.c_struct(), self.mlib.c_struct(), self._terrain_struct,
+                                                   self.cfg.struct, self.buffers(), ids, n, what), "parc_track_post_step")
+
+    def update_fail_rates(self, fail_rates, ema_w):
+        _hip.check(_hip.lib().parc_update_fail_rates(_hip.stream(), self.N, self.mlib.num_motions(), _hip.ptr(self.motion_ids),
+                                                     _hip.ptr(self.done_kind), float(ema_w), _hip.ptr(fail_rates)),
+                   "parc_update_fail_rates")

@@ -1,0 +1,116 @@
+"""Heightfield container of the tracker.
+
+Mirror of the hot-path part of the reference's ``util/terrain_util.py``: ``SubTerrain`` (:21-258) with the
+same field names -- motion pickles embed instances of it, so it must unpickle under the module path
+``util.terrain_util`` (parc_amd.install_reference_aliases) -- and ``get_local_hf_from_terrain``
+(:1329-1346).  Procedural generators and the voxel-mesh export are "next" rows.
+"""
+import copy
+
+import numpy as np
+import torch
+
+
+class SubTerrain:
+    def __init__(self, terrain_name="terrain", x_dim=256, y_dim=256, dx=1.0, dy=1.0, min_x=-1.0, min_y=-1.0, device="cuda:0"):
+        self.terrain_name = terrain_name
+        self.hf = torch.zeros((x_dim, y_dim), dtype=torch.float32, device=device)
+        self.dims = torch.tensor([x_dim, y_dim], dtype=torch.int64, device=device)
+        self.min_point = torch.tensor([min_x, min_y], dtype=torch.float32, device=device)
+        self.dxdy = torch.tensor([dx, dy], dtype=torch.float32, device=device)
+        self.hf_mask = torch.zeros((x_dim, y_dim), dtype=torch.bool, device=device)
+        self.hf_maxmin = torch.zeros((x_dim, y_dim, 2), dtype=torch.float32, device=device)
+        self.hf_maxmin[..., 0] = 1.0
+        self.hf_maxmin[..., 1] = -1.0
+
+    _FIELDS = (("hf", torch.float32), ("dims", torch.int64), ("min_point", torch.float32), ("dxdy", torch.float32),
+               ("hf_mask", torch.bool), ("hf_maxmin", torch.float32))
+
+    @classmethod
+    def from_arrays(cls, hf, min_point, dxdy, hf_mask=None, hf_maxmin=None, name="terrain", device="cpu"):
+        hf = np.asarray(hf, dtype=np.float32)
+        t = cls(name, hf.shape[0], hf.shape[1], float(dxdy[0]), float(dxdy[1]), float(min_point[0]), float(min_point[1]), device=device)
+        t.hf[:] = torch.as_tensor(hf, device=device)
+        if hf_mask is not None:
+            t.hf_mask[:] = torch.as_tensor(np.asarray(hf_mask, dtype=bool), device=device)
+        if hf_maxmin is not None:
+            t.hf_maxmin[:] = torch.as_tensor(np.asarray(hf_maxmin, dtype=np.float32), device=device)
+        return t
+
+    def update_old(self):
+        if not hasattr(self, "hf_maxmin"):
+            shape = (self.hf.shape[0], self.hf.shape[1], 2)
+            if isinstance(self.hf, torch.Tensor):
+                self.hf_maxmin = torch.zeros(shape, dtype=torch.float32, device=self.hf.device)
+            else:
+                self.hf_maxmin = np.zeros(shape, dtype=np.float32)
+            self.hf_maxmin[..., 0] = 1.0
+            self.hf_maxmin[..., 1] = -1.0
+
+    def to_torch(self, device):
+        for name, dtype in self._FIELDS:
+            v = getattr(self, name)
+            if isinstance(v, torch.Tensor):
+                setattr(self, name, v.to(device=device))
+            else:
+                setattr(self, name, torch.as_tensor(np.asarray(v), dtype=dtype, device=device))
+
+    def set_device(self, device):
+        self.to_torch(device)
+
+    def to_numpy(self):
+        for name, _ in self._FIELDS:
+            v = getattr(self, name)
+            if isinstance(v, torch.Tensor):
+                setattr(self, name, v.detach().cpu().numpy())
+
+    def numpy_copy(self):
+        t = copy.deepcopy(self)
+        t.to_numpy()
+        return t
+
+    def torch_copy(self):
+        return copy.deepcopy(self)
+
+    def get_real_size(self):
+        return self.dims * self.dxdy
+
+    def get_max_point(self):
+        return self.min_point + self.get_real_size() - self.dxdy
+
+    def get_inbounds_grid_index(self, grid_ind):
+        return torch.clamp(grid_ind, torch.zeros_like(self.dims), self.dims - 1)
+
+    def round_point_to_grid_index(self, point):
+        return torch.round((point - self.min_point) / self.dxdy).to(dtype=torch.int64)
+
+    def get_grid_index(self, point):
+        return self.get_inbounds_grid_index(self.round_point_to_grid_index(point))
+
+    def get_hf_val_from_points(self, xy_points):
+        g = self.get_grid_index(xy_points)
+        return self.hf[g[..., 0], g[..., 1]]
+
+    def get_point(self, ij):
+        return self.min_point + ij * self.dxdy
+
+    def pad(self, padding_size, height=0.0):
+        p = padding_size
+        self.hf = torch.nn.functional.pad(self.hf, [p, p, p, p], value=height)
+        mask = torch.zeros((self.hf_mask.shape[0] + 2 * p, self.hf_mask.shape[1] + 2 * p), dtype=torch.bool, device=self.hf.device)
+        mask[p:mask.shape[0] - p, p:mask.shape[1] - p] = self.hf_mask
+        self.hf_mask = mask
+        mx = torch.max(self.hf_maxmin[..., 0]).item()
+        mn = torch.min(self.hf_maxmin[..., 1]).item()
+        new_max = torch.nn.functional.pad(self.hf_maxmin[..., 0], [p, p, p, p], value=mx)
+        new_min = torch.nn.functional.pad(self.hf_maxmin[..., 1], [p, p, p, p], value=mn)
+        self.hf_maxmin = torch.stack([new_max, new_min], dim=-1)
+        self.min_point = self.min_point - self.dxdy * p
+        self.dims = self.dims + 2 * p
+
+
+def get_local_hf_from_terrain(xy_points, terrain):
+    """Nearest-cell height lookup for arbitrary query points (torch; the per-step 441-point fan goes through
+    the HIP kernel parc_refresh_obs_hfs instead)."""
+    g = terrain.get_grid_index(xy_points)
+    return terrain.hf[g[..., 0], g[..., 1]]

@@ -1,0 +1,285 @@
+"""GPU parity: the HIP path (through the C-ABI of libparc_hip.so) against the CPU oracle on the same seeded
+inputs and against the golden vectors the reference's Python produced.  fp32; tolerances as in
+test_oracle_golden.py (device libm vs glibc/torch differ by a few ulp in sin/cos/atan2/acos)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(a, b, atol=2e-5, rtol=1e-5):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+
+
+def T(x, dtype=torch.float32):
+    return torch.tensor(np.asarray(x), dtype=dtype, device=DEV)
+
+
+@pytest.fixture(scope="module")
+def km():
+    from parc_amd.anim.kin_char_model import KinCharModel
+    from parc_amd.assets import humanoid_spec
+    m = KinCharModel(DEV)
+    m.load_char_file(humanoid_spec.write_mjcf())
+    return m
+
+
+@pytest.fixture(scope="module")
+def mlib(km):
+    from parc_amd.anim.motion_lib import MotionLib, LoopMode
+    import pickle, tempfile, os, yaml
+    z = golden("g3_motion")
+    tmp = tempfile.mkdtemp(prefix="parc_test_")
+    entries = []
+    for i in range(4):
+        p = os.path.join(tmp, str(z["clip_names"][i]) + ".pkl")
+        with open(p, "wb") as f:
+            pickle.dump({"fps": float(z["clip_fps"][i]), "loop_mode": LoopMode(int(z["clip_loop"][i])).name,
+                         "frames": z["frames_%d" % i], "contacts": z["contacts_%d" % i]}, f)
+        entries.append({"file": p, "weight": float(z["clip_weights_in"][i])})
+    yp = os.path.join(tmp, "motions.yaml")
+    with open(yp, "w") as f:
+        yaml.safe_dump({"motions": entries}, f)
+    return MotionLib(yp, km, DEV, contact_info=True)
+
+
+def test_extension_loaded():
+    from parc_amd import _hip
+    assert _hip.lib().parc_abi_version() == 1
+
+
+def test_g2_dof_rot_fk(km, oracle, ref_char):
+    z = golden("g2_kin")
+    jr = km.dof_to_rot(T(z["dof"]))
+    close(jr, z["joint_rot"])
+    close(jr, oracle.dof_to_rot(ref_char, z["dof"]), atol=2e-6)
+    close(km.rot_to_dof(T(z["joint_rot"])), z["dof_back"])
+    close(km.rot_to_dof(T(z["rand_joint_rot"])), z["dof_from_rand"])
+    bp, br = km.forward_kinematics(T(z["root_pos"]), T(z["root_rot"]), T(z["joint_rot"]))
+    close(bp, z["body_pos"])
+    close(br, z["body_rot"])
+    # ragged / empty batch
+    e = km.dof_to_rot(torch.zeros((0, 28), device=DEV))
+    assert e.shape == (0, 14, 4)
+    one = km.dof_to_rot(T(z["dof"][:1]))
+    close(one, z["joint_rot"][:1])
+
+
+def test_g3_motion_lib_build_and_sample(mlib, ref_mlib):
+    z = golden("g3_motion")
+    close(mlib._motion_lengths, z["motion_lengths"], atol=1e-6)
+    close(mlib._motion_weights, z["motion_weights"], atol=1e-6)
+    close(mlib._motion_root_pos_delta, z["motion_root_pos_delta"], atol=1e-6)
+    close(mlib._frame_root_pos, z["frame_root_pos"], atol=1e-6)
+    close(mlib._frame_root_rot, z["frame_root_rot"], atol=2e-6)
+    close(mlib._frame_joint_rot, z["frame_joint_rot"], atol=2e-6)
+    close(mlib._frame_root_vel, z["frame_root_vel"], atol=1e-4)
+    close(mlib._frame_root_ang_vel, z["frame_root_ang_vel"], atol=2e-4)
+    close(mlib._frame_dof_vel, z["frame_dof_vel"], atol=2e-4)
+    close(mlib._frame_contacts, z["frame_contacts"], atol=0)
+    out = mlib.calc_motion_frame(T(z["q_ids"], torch.int64), T(z["q_times"]))
+    names = ["q_root_pos", "q_root_rot", "q_root_vel", "q_root_ang_vel", "q_joint_rot", "q_dof_vel", "q_contacts"]
+    tol = dict(q_root_vel=1e-4, q_root_ang_vel=2e-4, q_dof_vel=2e-4)
+    o = ref_mlib.calc_motion_frame(z["q_ids"], z["q_times"])
+    okeys = ["root_pos", "root_rot", "root_vel", "root_ang_vel", "joint_rot", "dof_vel", "contacts"]
+    for t, n, ok in zip(out, names, okeys):
+        close(t, z[n], atol=tol.get(n, 2e-5))
+        close(t, o[ok], atol=tol.get(n, 2e-5))
+    # empty query
+    e = mlib.calc_motion_frame(torch.zeros(0, dtype=torch.int64, device=DEV), torch.zeros(0, device=DEV))
+    assert e[0].shape == (0, 3)
+
+
+def _hf_check(out, ref, boundary):
+    out = out.detach().cpu().numpy()
+    bad = out != ref
+    assert not np.any(bad & ~(boundary < 1e-4)), "mismatch away from cell boundaries: %d" % int(np.sum(bad & ~(boundary < 1e-4)))
+    assert np.mean(bad) < 2e-3
+
+
+@pytest.mark.parametrize("name", ["g5_hf_civ", "g5_hf_teaser"])
+def test_g5_heightmap_gather(name, oracle):
+    from parc_amd import _hip
+    z = golden(name)
+    rays = T(golden("g4_rays")["ray_xy_points"])
+    hf = T(z["hf"])
+    ter = _hip.terrain_struct(hf, z["min_point"].tolist(), z["dxdy"].tolist())
+    root, heading = T(z["root_pos"]), T(z["heading"])
+    n, P = root.shape[0], rays.shape[0]
+    ref_o = oracle.refresh_ray_obs_hfs(z["ray_xy_points"] if "ray_xy_points" in z else golden("g4_rays")["ray_xy_points"],
+                                       z["root_pos"], z["heading"], z["hf"], z["min_point"], z["dxdy"])
+    # (a) dense [N,P] output: rows are not 16-byte aligned -> scalar kernel
+    out = torch.full((n, P), -99.0, device=DEV)
+    _hip.check(_hip.lib().parc_refresh_ray_obs_hfs(_hip.stream(), n, _hip.ptr(rays), P, _hip.ptr(root), _hip.ptr(heading), ter,
+                                                  -3.0, 3.0, _hip.ptr(out), P), "hf")
+    _hf_check(out, z["ray_hfs"], z["boundary_dist"])
+    _hf_check(out, ref_o, z["boundary_dist"])
+    # (b) written into the observation row layout [N,1312] at column 871 -> vectorised float4 kernel
+    obs = torch.full((n, 1312), -99.0, device=DEV)
+    dst = _hip.c_vp(obs.data_ptr() + 4 * 871)
+    _hip.check(_hip.lib().parc_refresh_ray_obs_hfs(_hip.stream(), n, _hip.ptr(rays), P, _hip.ptr(root), _hip.ptr(heading), ter,
+                                                  -3.0, 3.0, dst, 1312), "hf")
+    _hf_check(obs[:, 871:], z["ray_hfs"], z["boundary_dist"])
+    assert torch.all(obs[:, :871] == -99.0)          # nothing outside the heightmap columns is touched
+    assert torch.equal(obs[:, 871:], out) or np.mean((obs[:, 871:] != out).cpu().numpy()) < 1e-3
+    # (c) n = 0 and a ragged n (not a multiple of the envs-per-block)
+    assert _hip.lib().parc_refresh_ray_obs_hfs(_hip.stream(), 0, _hip.ptr(rays), P, _hip.ptr(root), _hip.ptr(heading), ter,
+                                               -3.0, 3.0, dst, 1312) == 0
+    obs2 = torch.full((n, 1312), -99.0, device=DEV)
+    dst2 = _hip.c_vp(obs2.data_ptr() + 4 * 871)
+    _hip.check(_hip.lib().parc_refresh_ray_obs_hfs(_hip.stream(), 7, _hip.ptr(rays), P, _hip.ptr(root), _hip.ptr(heading), ter,
+                                                  -3.0, 3.0, dst2, 1312), "hf")
+    assert torch.equal(obs2[:7, 871:], obs[:7, 871:]) and torch.all(obs2[7:] == -99.0)
+
+
+def _core_from_golden(km, mlib):
+    from parc_amd.tracker_core import TrackerConfig, TrackerCore
+    from parc_amd.util.terrain_util import SubTerrain
+    from parc_amd.envs.ig_parkour.default_config import default_env_config
+    z = golden("g6_step")
+    cfg = TrackerConfig(default_env_config()["env"], km, 441)
+    n = 64
+    core = TrackerCore(n, DEV, km, mlib, cfg, T(z["rays"]))
+    core.set_terrain(SubTerrain.from_arrays(z["hf"], z["min_point"], z["dxdy"], device=DEV))
+    core.root_state[:, 0:3] = T(z["char_root_pos"])
+    core.root_state[:, 3:7] = T(z["char_root_rot"])
+    core.root_state[:, 7:10] = T(z["char_root_vel"])
+    core.root_state[:, 10:13] = T(z["char_root_ang_vel"])
+    ds = core.dof_state.view(n, 28, 2)
+    ds[..., 0] = T(z["char_dof_pos"])
+    ds[..., 1] = T(z["char_dof_vel"])
+    core.rigid_body_state.view(n, 15, 13)[..., 0:3] = T(z["char_rigid_body_pos"])
+    core.contact_forces.view(n, 15, 3)[:] = T(z["contact_forces"])
+    core.env_offsets[:] = T(z["env_offsets"])
+    core.motion_ids[:] = T(z["motion_ids"], torch.int64)
+    core.motion_time_offsets[:] = T(z["motion_time_offsets"])
+    core.motion_xy_offset[:] = T(z["motion_offsets"][z["motion_ids"], 0])
+    core.time_buf[:] = T(z["time_buf"])
+    return core, z
+
+
+def test_g6_fused_post_step(km, mlib, oracle, ref_char, ref_mlib):
+    from parc_amd import _hip
+    core, z = _core_from_golden(km, mlib)
+    core.refresh_obs_hfs()
+    core.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE)
+    torch.cuda.synchronize()
+    _hf_check(core.ray_hfs, z["ray_hfs"], z["hf_boundary"])
+    for k in ("ref_root_pos", "ref_root_rot", "ref_joint_rot", "ref_contacts", "ref_body_pos", "ref_dof_pos"):
+        close(getattr(core, k), z[k])
+    for k in ("ref_root_vel", "ref_root_ang_vel", "ref_dof_vel"):
+        close(getattr(core, k), z[k], atol=2e-4)
+    obs = core.obs.cpu().numpy()
+    close(obs[:, 0:136], z["char_obs"])
+    close(obs[:, 136:766], z["tar_obs"], atol=3e-5)
+    close(obs[:, 766:856], z["tar_contacts"].reshape(64, -1))
+    close(obs[:, 856:871], (np.linalg.norm(z["contact_forces"], axis=-1) > 1e-5).astype(np.float32), atol=0)
+    close(core.reward, z["reward"])
+    close(core.reward_terms[0:5].t(), z["reward_terms"])
+    close(core.reward_terms[5], z["contact_penalty"])
+    np.testing.assert_array_equal(core.done.cpu().numpy(), z["done_final"])
+    # fail-rate EMA in env order
+    fr = torch.ones(4, device=DEV)
+    core.update_fail_rates(fr, 0.01)
+    close(fr, z["fail_rates"], atol=1e-6)
+    # oracle on the same inputs (full obs row incl. heightmap columns where they agree bit-exactly)
+    off = z["motion_offsets"][z["motion_ids"], 0] - z["env_offsets"][:, 0:2]
+    times = z["time_buf"] + z["motion_time_offsets"]
+    tar_dt = (z["tar_obs_steps"].astype(np.float32) * np.float32(1.0 / 30.0)).astype(np.float32)
+    o_obs = oracle.compute_obs(ref_char, ref_mlib, tar_dt, z["key_body_ids"], z["motion_ids"], times, off, z["char_root_pos"],
+                               z["char_root_rot"], z["char_root_vel"], z["char_root_ang_vel"], z["char_dof_pos"], z["char_dof_vel"],
+                               z["contact_forces"], z["ray_hfs"])
+    close(obs[:, :871], o_obs[:, :871], atol=3e-5)
+
+
+def test_g6_post_step_subset_and_contact_bodies(km, mlib):
+    """reset path: observations only, for a subset of env ids; and the fall-contact termination branch."""
+    from parc_amd import _hip
+    core, z = _core_from_golden(km, mlib)
+    core.obs[:] = -7.0
+    ids = torch.tensor([3, 9, 40], dtype=torch.int64, device=DEV)
+    core.post_step(_hip.POST_OBS, ids)
+    obs = core.obs.cpu().numpy()
+    close(obs[[3, 9, 40], :871], z["obs"][[3, 9, 40], :871], atol=3e-5)
+    mask = np.ones(64, bool)
+    mask[[3, 9, 40]] = False
+    assert np.all(obs[mask] == -7.0)
+    core.post_step(_hip.POST_OBS, torch.zeros(0, dtype=torch.int64, device=DEV))   # empty id list is a no-op
+    # contact bodies = feet -> done_feet golden (before the motion-end override; compare where no motion end)
+    core.cfg.struct.num_contact_bodies = 2
+    core.cfg.struct.contact_body_mask[11] = 1
+    core.cfg.struct.contact_body_mask[14] = 1
+    core.post_step(_hip.POST_REF | _hip.POST_REWARD_DONE)
+    done = core.done.cpu().numpy()
+    me = z["motion_end"]
+    np.testing.assert_array_equal(done[~me], z["done_feet"][~me])
+    assert np.all(done[me] == 1)
+    core.cfg.struct.num_contact_bodies = 0
+
+
+def test_g9_td_lambda_and_advantage(oracle):
+    from parc_amd.learning import rl_util
+    z = golden("g9_td_lambda")
+    g, lam, clip = [float(x) for x in z["params"]]
+    ret = rl_util.compute_td_lambda_return(T(z["r"]), T(z["next_vals"]), T(z["done"], torch.int32), g, lam)
+    close(ret, z["ret"], atol=1e-4, rtol=1e-6)
+    close(ret, oracle.td_lambda_return(z["r"], z["next_vals"], z["done"], g, lam), atol=1e-4, rtol=1e-6)
+    ret1 = rl_util.compute_td_lambda_return(T(z["r"][:1]), T(z["next_vals"][:1]), T(z["done"][:1], torch.int32), g, lam)
+    close(ret1, z["ret_T1"])
+    adv, ms = rl_util.normalize_advantage(T(z["ret"]), T(z["vals"]), T(z["rand_action_mask"]), clip)
+    assert abs(ms[0].item() - float(z["adv_mean"])) < 1e-3 and abs(ms[1].item() - float(z["adv_std"])) < 1e-3
+    close(adv, z["norm_adv"], atol=1e-4)
+
+
+def test_full_size_properties(km, mlib):
+    """BASELINE sizes (4096 envs): size-independent properties instead of an oracle run.
+    heightmap: translation by whole cells shifts the lookup; flat terrain gives -z; TD(lambda) with lambda=0 is
+    one-step TD; with no resets and constant r,v it is the closed form."""
+    from parc_amd import _hip
+    from parc_amd.learning import rl_util
+    n, P = 4096, 441
+    g = torch.Generator(device="cpu").manual_seed(1)
+    rays = T(golden("g4_rays")["ray_xy_points"])
+    hf = torch.rand((144, 144), generator=g).to(DEV) * 2.0
+    ter = _hip.terrain_struct(hf, [-28.8, -28.8], [0.4, 0.4])
+    root = torch.zeros((n, 3))
+    root[:, 0:2] = (torch.rand((n, 2), generator=g) - 0.5) * 40.0
+    root[:, 2] = torch.rand(n, generator=g)
+    heading = (torch.rand(n, generator=g) - 0.5) * 6.28
+    root, heading = root.to(DEV), heading.to(DEV)
+    obs = torch.zeros((n, 1312), device=DEV)
+    dst = _hip.c_vp(obs.data_ptr() + 4 * 871)
+    L = _hip.lib()
+    _hip.check(L.parc_refresh_ray_obs_hfs(_hip.stream(), n, _hip.ptr(rays), P, _hip.ptr(root), _hip.ptr(heading), ter, -3.0, 3.0, dst, 1312), "hf")
+    a = obs[:, 871:].clone()
+    assert a.min() >= -3.0 and a.max() <= 3.0
+    # shift terrain origin and roots by 3 cells in x: identical lookups
+    ter2 = _hip.terrain_struct(hf, [-28.8 + 1.2, -28.8], [0.4, 0.4])
+    root2 = root.clone()
+    root2[:, 0] += 1.2
+    _hip.check(L.parc_refresh_ray_obs_hfs(_hip.stream(), n, _hip.ptr(rays), P, _hip.ptr(root2), _hip.ptr(heading), ter2, -3.0, 3.0, dst, 1312), "hf")
+    assert (obs[:, 871:] != a).float().mean().item() < 2e-3     # only fp32 boundary flips
+    # flat terrain: exactly clamp(h0 - z)
+    flat = torch.full((144, 144), 0.25, device=DEV)
+    ter3 = _hip.terrain_struct(flat, [-28.8, -28.8], [0.4, 0.4])
+    _hip.check(L.parc_refresh_ray_obs_hfs(_hip.stream(), n, _hip.ptr(rays), P, _hip.ptr(root), _hip.ptr(heading), ter3, -3.0, 3.0, dst, 1312), "hf")
+    assert torch.equal(obs[:, 871:], (0.25 - root[:, 2:3]).clamp(-3, 3).expand(-1, P))
+    # TD(lambda)
+    Tn = 32
+    r = torch.rand((Tn, n), device=DEV)
+    v = torch.rand((Tn, n), device=DEV) * 50
+    done = torch.zeros((Tn, n), dtype=torch.int32, device=DEV)
+    ret0 = rl_util.compute_td_lambda_return(r, v, done, 0.99, 0.0)
+    assert torch.allclose(ret0, r + 0.99 * v, atol=1e-5)
+    rc = torch.full((Tn, n), 0.5, device=DEV)
+    vc = torch.full((Tn, n), 50.0, device=DEV)          # fixed point of v = r + g v
+    retc = rl_util.compute_td_lambda_return(rc, vc, done, 0.99, 0.95)
+    assert torch.allclose(retc, vc, atol=1e-3)
+    done_all = torch.ones((Tn, n), dtype=torch.int32, device=DEV)
+    ret1 = rl_util.compute_td_lambda_return(r, v, done_all, 0.99, 0.95)   # reset everywhere -> one-step TD
+    assert torch.allclose(ret1, r + 0.99 * v, atol=1e-5)
