@@ -104,7 +104,7 @@ class KinCharModel:
         for j in joints:
             if j.limits is None:
                 continue
-            lim = np.asarray(j.limits, dtype=np.float32).reshape(-1, 2)
+            lim = (j.limits.detach().cpu().numpy() if isinstance(j.limits, torch.Tensor) else np.asarray(j.limits)).astype(np.float32).reshape(-1, 2)
             lo.append(lim[:, 0])
             hi.append(lim[:, 1])
         self._lower_dof_limits = torch.as_tensor(np.concatenate(lo), device=self._device) if lo else []
