@@ -174,12 +174,16 @@ int parc_motion_lib_build(void *stream, parc_char_model_t model, parc_motion_lib
  *   IGParkourEnv._update_reward            ig_parkour_env.py:1275-1339,1399-1404 (K9)
  *   RefCharEnv.update_done / DeepMimicEnv.update_done  mgdm_dm_util.py:205-230,392-460, dm_env.py:746-783 (K10)
  * env_ids (int64, device) selects a subset (reset path: ig_parkour_env.py:1033-1036); NULL = all envs.
- * what: bit0 ref-state update, bit1 observations, bit2 reward+done. */
+ * what: bit0 ref-state update, bit1 observations, bit2 reward+done, bit3 fuse the local heightmap (K5,
+ * ig_parkour_env.py:636-656) into the same launch: the whole obs row is then written at once and
+ * parc_refresh_obs_hfs is not needed (requires bit1; ray_xy [P,2] device pointer, else may be NULL). */
 #define PARC_POST_REF 1
 #define PARC_POST_OBS 2
 #define PARC_POST_REWARD_DONE 4
+#define PARC_POST_HF 8
 int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
-                         parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what);
+                         parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
+                         const float *ray_xy);
 
 /* DeepMimicEnv.update_done's per-done-env Python loop (dm_env.py:758-772): EMA of per-clip failure rates,
  * applied in increasing env order exactly as the reference's loop does. */

@@ -24,6 +24,7 @@ MAX_KEY_BODIES = 8
 POST_REF = 1
 POST_OBS = 2
 POST_REWARD_DONE = 4
+POST_HF = 8
 
 c_int = ctypes.c_int
 c_i32 = ctypes.c_int32
@@ -115,7 +116,7 @@ def _declare(L):
     L.parc_forward_kinematics.argtypes = [c_vp, CharModelS, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
     L.parc_calc_motion_frame.argtypes = [c_vp, MotionLibS, c_int, c_vp, c_vp] + [c_vp] * 7
     L.parc_motion_lib_build.argtypes = [c_vp, CharModelS, MotionLibS, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
-    L.parc_track_post_step.argtypes = [c_vp, CharModelS, MotionLibS, TerrainS, TrackCfgS, EnvBuffersS, c_vp, c_int, c_int]
+    L.parc_track_post_step.argtypes = [c_vp, CharModelS, MotionLibS, TerrainS, TrackCfgS, EnvBuffersS, c_vp, c_int, c_int, c_vp]
     L.parc_update_fail_rates.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_vp]
     L.parc_td_lambda_return.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_f, c_f, c_vp]
     L.parc_adv_normalize.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp]

@@ -55,6 +55,17 @@ class MotionLib:
             clips = self._read_motion_files(motion_input)
         elif init_type == "motion_frames":
             clips = self._clips_from_frames(motion_input, loop_mode, fps, contacts)
+        elif init_type == "clips":
+            # in-memory clip dicts (parc_amd.synthetic.make_dataset): frames, contacts, fps, loop, weight[, name, hf...]
+            clips = list(motion_input)
+            self._motion_names = [c.get("name", "clip_%d" % i) for i, c in enumerate(clips)]
+            self._motion_files = list(self._motion_names)
+            self._terrains = []
+            for c in clips:
+                if "hf" in c:
+                    self._terrains.append(terrain_util.SubTerrain.from_arrays(c["hf"], c["min_point"], c["dxdy"], device=device))
+                else:
+                    self._terrains.append(None)
         else:
             raise NotImplementedError("init_type {!r} (the diffusion loader is outside the tracker hot path)".format(init_type))
         self._build(clips)

@@ -16,14 +16,16 @@
 // =============================================================================================
 // K5  local heightmap gather
 // =============================================================================================
-// One workgroup = HF_EPB consecutive envs.  Per-env scalars (global x,y,z, cos/sin heading) are computed
-// once and staged in LDS; every thread owns one 16-byte output slot (4 ray points) whose template
-// coordinates it keeps in registers across the HF_EPB envs.  Stores are whole float4s (the row's
-// misaligned head/tail elements go to the first/last slot), so a wave writes 1 KiB contiguous per
-// instruction; the heightfield itself stays in L1/L2 (a 441-point fan touches ~100 cells).
-#ifndef HF_EPB
-#define HF_EPB 4
-#endif
+// One workgroup = HF_EPB consecutive envs; every thread owns one 16-byte output slot (4 ray points) whose
+// template coordinates stay in registers across those envs, so a wave stores 1 KiB contiguous per
+// instruction (the row's misaligned head/tail elements are slot 0 / the last slot).  The heightfield is
+// L1/L2-resident (a 441-point fan touches ~100 cells), so the kernel is bound by instruction issue, not
+// HBM: per env the lookup is folded into two affine maps in CELL units,
+//     u_i = x*(c/dx) - y*(s/dx) + (gx-min_x)/dx ,   u_j = x*(s/dy) + y*(c/dy) + (gy-min_y)/dy
+// (c,s = cos/sin of the heading taken directly from the rotated x axis: cos(atan2(b,a)) = a/|(a,b)|),
+// then rndne + clamp + one load per point.  This reassociates the reference's fp32 expression
+// (rotate, add root, subtract min, divide): values agree except for queries within a few ulp of a cell
+// boundary (tests bound this), the returned heights themselves are exact copies.
 #define HF_THREADS 128
 
 // util/terrain_util.py:107-126: torch.round (half to even) then clamp to the grid
@@ -35,39 +37,58 @@ PARC_DEV float hf_lookup(const parc_terrain_t &t, float px, float py) {
     return t.hf[(int)fi * t.dim_y + (int)fj];
 }
 
+struct hf_env_prm {
+    float ax, bx, cx, ay, by, cy, gz;
+};
+
 template <bool FROM_STATE>
+PARC_DEV hf_env_prm hf_env_params(int e, const float *__restrict__ root, const float *__restrict__ aux, const parc_terrain_t &ter,
+                                  float inv_dx, float inv_dy) {
+    float gx, gy, gz, c, s;
+    if (FROM_STATE) {
+        // ig_parkour_env.py:640-641: global xyz = root pos + env offset; heading of R(q) e_x (torch_util.py:470-479)
+        const float *rs = root + (size_t)e * 13;
+        gx = rs[0] + aux[3 * e + 0];
+        gy = rs[1] + aux[3 * e + 1];
+        gz = rs[2] + aux[3 * e + 2];
+        float qx = rs[3], qy = rs[4], qz = rs[5], qw = rs[6];
+        float a = 1.0f - 2.0f * (qy * qy + qz * qz);
+        float b = 2.0f * (qw * qz + qx * qy);
+        float n2 = a * a + b * b;
+        float inv = rsqrtf(n2);
+        c = n2 > 0.f ? a * inv : 1.0f;   // atan2(0,0) = 0
+        s = n2 > 0.f ? b * inv : 0.0f;
+    } else {
+        gx = root[3 * e + 0];
+        gy = root[3 * e + 1];
+        gz = root[3 * e + 2];
+        sincosf(aux[e], &s, &c);
+    }
+    hf_env_prm p;
+    p.ax = c * inv_dx;
+    p.bx = -s * inv_dx;
+    p.cx = (gx - ter.min_x) * inv_dx;
+    p.ay = s * inv_dy;
+    p.by = c * inv_dy;
+    p.cy = (gy - ter.min_y) * inv_dy;
+    p.gz = gz;
+    return p;
+}
+
+template <bool FROM_STATE, int HF_EPB, int ABL = 0>
 __global__ __launch_bounds__(HF_THREADS) void hf_gather_kernel(int n_envs, const float *__restrict__ ray_xy, int n_points,
                                                                const float *__restrict__ root, const float *__restrict__ aux,
                                                                parc_terrain_t ter, float min_h, float max_h,
                                                                float *__restrict__ out, int64_t out_stride, int head) {
-    __shared__ float prm[HF_EPB][5];
     const int tid = threadIdx.x;
     const int e0 = blockIdx.x * HF_EPB;
-    if (tid < HF_EPB) {
-        int e = e0 + tid;
-        if (e < n_envs) {
-            float gx, gy, gz, hd;
-            if (FROM_STATE) {
-                // ig_parkour_env.py:640-641: global xyz = root pos + env offset, heading from root rot
-                const float *rs = root + (size_t)e * 13;
-                gx = rs[0] + aux[3 * e + 0];
-                gy = rs[1] + aux[3 * e + 1];
-                gz = rs[2] + aux[3 * e + 2];
-                hd = calc_heading(ld4(rs + 3));
-            } else {
-                gx = root[3 * e + 0];
-                gy = root[3 * e + 1];
-                gz = root[3 * e + 2];
-                hd = aux[e];
-            }
-            prm[tid][0] = gx;
-            prm[tid][1] = gy;
-            prm[tid][2] = gz;
-            prm[tid][3] = cosf(hd);
-            prm[tid][4] = sinf(hd);
-        }
-    }
-    __syncthreads();
+    const float inv_dx = 1.0f / ter.dx, inv_dy = 1.0f / ter.dy;
+    const float max_i = (float)(ter.dim_x - 1), max_j = (float)(ter.dim_y - 1);
+    hf_env_prm prm[HF_EPB];
+    const unsigned out_bytes = (unsigned)min((unsigned long long)n_envs * (unsigned long long)out_stride * 4ull, 0xFFFFFFFFull);
+    __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, out_bytes, 0x00020000);
+#pragma unroll
+    for (int ee = 0; ee < HF_EPB; ++ee) prm[ee] = hf_env_params<FROM_STATE>(min(e0 + ee, n_envs - 1), root, aux, ter, inv_dx, inv_dy);
     // slot 0: the `head` leading scalars; slots 1..nbody: aligned float4s; last slot: trailing scalars
     const int nbody = (n_points - head) >> 2;
     const int tail = n_points - head - 4 * nbody;
@@ -92,25 +113,39 @@ __global__ __launch_bounds__(HF_THREADS) void hf_gather_kernel(int n_envs, const
             rx[i] = ray_xy[2 * p];
             ry[i] = ray_xy[2 * p + 1];
         }
+        float h[HF_EPB][4];
+#pragma unroll
+        for (int ee = 0; ee < HF_EPB; ++ee) {
+            const hf_env_prm pr = prm[ee];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float ui = fmaf(rx[i], pr.ax, fmaf(ry[i], pr.bx, pr.cx));
+                float uj = fmaf(rx[i], pr.ay, fmaf(ry[i], pr.by, pr.cy));
+                ui = __builtin_amdgcn_fmed3f(rintf(ui), 0.f, max_i);
+                uj = __builtin_amdgcn_fmed3f(rintf(uj), 0.f, max_j);
+                float v = ((ABL == 1 || ABL == 5) ? (ui + uj) : ter.hf[(int)ui * ter.dim_y + (int)uj]) - pr.gz;
+                h[ee][i] = __builtin_amdgcn_fmed3f(v, min_h, max_h);
+            }
+        }
 #pragma unroll
         for (int ee = 0; ee < HF_EPB; ++ee) {
             int e = e0 + ee;
             if (e >= n_envs) break;
-            float gx = prm[ee][0], gy = prm[ee][1], gz = prm[ee][2], c = prm[ee][3], s = prm[ee][4];
-            float h[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // torch_util.rotate_2d_vec (util/torch_util.py:619-631) then + root xy
-                float px = (rx[i] * c - ry[i] * s) + gx;
-                float py = (rx[i] * s + ry[i] * c) + gy;
-                float v = hf_lookup(ter, px, py) - gz;
-                h[i] = fminf(fmaxf(v, min_h), max_h);
-            }
-            float *o = out + (size_t)e * out_stride + p0;
-            if (cnt == 4) {
-                *reinterpret_cast<float4 *>(o) = make_float4(h[0], h[1], h[2], h[3]);
+            const size_t off = (size_t)e * out_stride + p0;
+            float *o = out + off;
+            if (ABL == 2 || ABL == 5) {
+                if (h[ee][0] + h[ee][1] + h[ee][2] + h[ee][3] == 12345.678f) o[0] = 1.f;   // ablation: keep the math, drop the stores
+            } else if (cnt == 4) {
+                if (ABL == 3 || ABL == 4) {
+                    typedef float f32x4 __attribute__((ext_vector_type(4)));
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    f32x4 v = {h[ee][0], h[ee][1], h[ee][2], h[ee][3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), out_rsrc, (unsigned)(off * 4), 0, ABL == 3 ? 16 : 2);
+                } else {
+                    *reinterpret_cast<float4 *>(o) = make_float4(h[ee][0], h[ee][1], h[ee][2], h[ee][3]);
+                }
             } else {
-                for (int i = 0; i < cnt; ++i) o[i] = h[i];
+                for (int i = 0; i < cnt; ++i) o[i] = h[ee][i];
             }
         }
     }
@@ -144,6 +179,9 @@ __global__ __launch_bounds__(256) void hf_gather_scalar_kernel(int n_envs, const
     out[(size_t)e * out_stride + p] = fminf(fmaxf(v, min_h), max_h);
 }
 
+static int g_hf_epb = 2;
+static int g_hf_abl = 0;  // diagnostic ablations (timing only, outputs wrong): 1 no gather, 2 no stores
+
 static int launch_hf(bool from_state, void *stream, int n_envs, const float *ray_xy, int n_points, const float *root,
                      const float *aux, parc_terrain_t ter, float min_h, float max_h, float *out, int64_t out_stride) {
     if (n_envs < 0 || n_points <= 0 || !ray_xy || !root || !aux || !out || !ter.hf || out_stride < n_points) return PARC_EINVAL;
@@ -155,7 +193,6 @@ static int launch_hf(bool from_state, void *stream, int n_envs, const float *ray
     } else {
         head = n_points;  // rows are differently aligned: all-scalar path through slot 0 (not vectorised)
     }
-    dim3 grid((n_envs + HF_EPB - 1) / HF_EPB), block(HF_THREADS);
     hipStream_t st = (hipStream_t)stream;
     if (head == n_points && n_points > 3) {
         // rows are not uniformly 16-byte aligned: one thread per point, dword stores
@@ -168,11 +205,43 @@ static int launch_hf(bool from_state, void *stream, int n_envs, const float *ray
         PARC_CHECK_LAUNCH();
         return PARC_OK;
     }
-    if (from_state)
-        hipLaunchKernelGGL(hf_gather_kernel<true>, grid, block, 0, st, n_envs, ray_xy, n_points, root, aux, ter, min_h, max_h, out, out_stride, head);
-    else
-        hipLaunchKernelGGL(hf_gather_kernel<false>, grid, block, 0, st, n_envs, ray_xy, n_points, root, aux, ter, min_h, max_h, out, out_stride, head);
+#define HF_LAUNCH3(FS, EPB, AB)                                                                                          \
+    hipLaunchKernelGGL((hf_gather_kernel<FS, EPB, AB>), dim3((n_envs + EPB - 1) / EPB), dim3(HF_THREADS), 0, st, n_envs, ray_xy, \
+                       n_points, root, aux, ter, min_h, max_h, out, out_stride, head)
+#define HF_LAUNCH(FS, EPB)                                                                                               \
+    hipLaunchKernelGGL((hf_gather_kernel<FS, EPB>), dim3((n_envs + EPB - 1) / EPB), dim3(HF_THREADS), 0, st, n_envs, ray_xy, \
+                       n_points, root, aux, ter, min_h, max_h, out, out_stride, head)
+    const int epb = g_hf_epb;
+    if (from_state && g_hf_abl == 1) HF_LAUNCH3(true, 2, 1);
+    else if (from_state && g_hf_abl == 2) HF_LAUNCH3(true, 2, 2);
+    else if (from_state && g_hf_abl == 3) HF_LAUNCH3(true, 2, 3);
+    else if (from_state && g_hf_abl == 4) HF_LAUNCH3(true, 2, 4);
+    else if (from_state && g_hf_abl == 5) HF_LAUNCH3(true, 2, 5);
+    else if (from_state) {
+        if (epb == 1) HF_LAUNCH(true, 1);
+        else if (epb == 4) HF_LAUNCH(true, 4);
+        else if (epb == 8) HF_LAUNCH(true, 8);
+        else HF_LAUNCH(true, 2);
+    } else {
+        if (epb == 1) HF_LAUNCH(false, 1);
+        else if (epb == 4) HF_LAUNCH(false, 4);
+        else if (epb == 8) HF_LAUNCH(false, 8);
+        else HF_LAUNCH(false, 2);
+    }
+#undef HF_LAUNCH
     PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+// tuning knob (envs per workgroup of the heightmap kernel: 1, 2, 4 or 8); not part of the stable ABI
+extern "C" int parc_tune_hf_ablation(int a) {
+    g_hf_abl = a;
+    return PARC_OK;
+}
+
+extern "C" int parc_tune_hf_envs_per_block(int epb) {
+    if (epb != 1 && epb != 2 && epb != 4 && epb != 8) return PARC_EINVAL;
+    g_hf_epb = epb;
     return PARC_OK;
 }
 
@@ -493,11 +562,13 @@ extern "C" int parc_forward_kinematics(void *stream, parc_char_model_t model, in
 // The observation row (columns [0, obs_dim - P)) is assembled in LDS and written with float4 stores.
 // =============================================================================================
 #define POST_THREADS 128
-#define POST_MAX_ROW 1024
+#define POST_MAX_ROW 1408
+#define POST_MAX_RAY_PER_THREAD 4
 
 __global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_model_t m, parc_motion_lib_t ml, parc_terrain_t ter,
                                                                  parc_track_cfg_t cfg, parc_env_buffers_t buf,
-                                                                 const int64_t *__restrict__ env_ids, int what) {
+                                                                 const int64_t *__restrict__ env_ids, int what,
+                                                                 const float *__restrict__ ray_xy) {
     __shared__ __attribute__((aligned(16))) float row[POST_MAX_ROW];
     const int tid = threadIdx.x;
     const int g = tid / GRP, b = tid % GRP;
@@ -521,6 +592,26 @@ __global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_mode
     int key_slot = -1;
     for (int k = 0; k < K; ++k)
         if (cfg.key_body_ids[k] == b) key_slot = k;
+
+    // ---- K5 fused (PARC_POST_HF): the 441-point local heightmap goes straight into the LDS row.  The gathers
+    // are issued first so their L2 latency hides under the pose math below.  Same affine cell-unit form as
+    // hf_gather_kernel (RefCharEnv._refresh_ray_obs_hfs mgdm_dm_util.py:158-179, ig_parkour_env.py:636-656).
+    float hfv[POST_MAX_RAY_PER_THREAD];
+    const bool do_hf = (what & PARC_POST_HF) != 0;
+    if (do_hf) {
+        hf_env_prm pr = hf_env_params<true>(e, buf.root_state, buf.env_offsets, ter, 1.0f / ter.dx, 1.0f / ter.dy);
+        const float max_i = (float)(ter.dim_x - 1), max_j = (float)(ter.dim_y - 1);
+#pragma unroll
+        for (int i = 0; i < POST_MAX_RAY_PER_THREAD; ++i) {
+            int p = min(tid + i * POST_THREADS, cfg.num_ray_points - 1);
+            float rx = ray_xy[2 * p], ry = ray_xy[2 * p + 1];
+            float ui = fmaf(rx, pr.ax, fmaf(ry, pr.bx, pr.cx));
+            float uj = fmaf(rx, pr.ay, fmaf(ry, pr.by, pr.cy));
+            ui = __builtin_amdgcn_fmed3f(rintf(ui), 0.f, max_i);
+            uj = __builtin_amdgcn_fmed3f(rintf(uj), 0.f, max_j);
+            hfv[i] = __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - pr.gz, cfg.min_obs_h, cfg.max_obs_h);
+        }
+    }
 
     // ---- phase A: every group gets its pose (root transform + one joint rotation per lane)
     const bool is_char = g == 0, is_ref = g == 1, is_tar = g >= 2 && g - 2 < S;
@@ -705,26 +796,39 @@ __global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_mode
         }
     }
     if (what & PARC_POST_OBS) {
+        int out_len = row_len;
+        if (do_hf) {
+#pragma unroll
+            for (int i = 0; i < POST_MAX_RAY_PER_THREAD; ++i) {
+                int p = tid + i * POST_THREADS;
+                if (p < cfg.num_ray_points) row[row_len + p] = hfv[i];
+            }
+            out_len = cfg.obs_dim;
+        }
         __syncthreads();
         float *dst = buf.obs + (size_t)e * cfg.obs_dim;
-        const int n4 = row_len >> 2;
+        const int n4 = out_len >> 2;
         for (int i = tid; i < n4; i += POST_THREADS) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(row)[i];
-        for (int i = 4 * n4 + tid; i < row_len; i += POST_THREADS) dst[i] = row[i];
+        for (int i = 4 * n4 + tid; i < out_len; i += POST_THREADS) dst[i] = row[i];
     }
 }
 
 extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
-                                    parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what) {
+                                    parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
+                                    const float *ray_xy) {
     if (!model_ok(model) || mlib.num_bodies != model.num_bodies || mlib.dof_size != model.dof_size) return PARC_EINVAL;
     if (cfg.num_tar_steps < 0 || cfg.num_tar_steps > PARC_MAX_TAR_STEPS || cfg.num_key_bodies > PARC_MAX_KEY_BODIES) return PARC_EUNSUPPORTED;
     const int B = model.num_bodies, J = B - 1, D = model.dof_size, K = cfg.num_key_bodies, S = cfg.num_tar_steps;
     const int row_len = (12 + 6 * J + D + 3 * K) + S * (9 + 6 * J + 3 * K) + S * B + B;
-    if (row_len + cfg.num_ray_points != cfg.obs_dim || row_len > POST_MAX_ROW || (cfg.obs_dim & 3)) return PARC_EINVAL;
+    if (row_len + cfg.num_ray_points != cfg.obs_dim || cfg.obs_dim > POST_MAX_ROW || (cfg.obs_dim & 3)) return PARC_EINVAL;
+    if (what & PARC_POST_HF) {
+        if (!(what & PARC_POST_OBS) || !ray_xy || !terrain.hf || cfg.num_ray_points > POST_MAX_RAY_PER_THREAD * POST_THREADS) return PARC_EINVAL;
+    }
     if (((uintptr_t)buf.obs & 15) || ((uintptr_t)mlib.frames & 15) || (mlib.row_stride & 3)) return PARC_EINVAL;
     int n = env_ids ? n_sel : buf.num_envs;
     if (n < 0) return PARC_EINVAL;
     if (n == 0) return PARC_OK;
-    hipLaunchKernelGGL(track_post_kernel, dim3(n), dim3(POST_THREADS), 0, (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, what);
+    hipLaunchKernelGGL(track_post_kernel, dim3(n), dim3(POST_THREADS), 0, (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, what, ray_xy);
     PARC_CHECK_LAUNCH();
     return PARC_OK;
 }

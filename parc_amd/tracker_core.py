@@ -188,7 +188,8 @@ class TrackerCore:
         else:
             n, ids = 0, _hip.c_vp(0)
         _hip.check(_hip.lib().parc_track_post_step(_hip.stream(), self.km.c_struct(), self.mlib.c_struct(), self._terrain_struct,
-                                                   self.cfg.struct, self.buffers(), ids, n, what), "parc_track_post_step")
+                                                   self.cfg.struct, self.buffers(), ids, n, what, _hip.ptr(self.ray_xy_points)),
+                   "parc_track_post_step")
 
     def update_fail_rates(self, fail_rates, ema_w):
         _hip.check(_hip.lib().parc_update_fail_rates(_hip.stream(), self.N, self.mlib.num_motions(), _hip.ptr(self.motion_ids),

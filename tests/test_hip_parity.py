@@ -197,6 +197,25 @@ def test_g6_fused_post_step(km, mlib, oracle, ref_char, ref_mlib):
     close(obs[:, :871], o_obs[:, :871], atol=3e-5)
 
 
+def test_g6_fused_heightmap_equals_standalone(km, mlib):
+    """PARC_POST_HF: the fused kernel writes the whole 1312-float row; same values as K5 + post-step."""
+    from parc_amd import _hip
+    core, z = _core_from_golden(km, mlib)
+    core.refresh_obs_hfs()
+    core.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE)
+    two = core.obs.clone()
+    core.obs[:] = -5.0
+    core.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF)
+    assert torch.equal(core.obs, two)
+    _hf_check(core.ray_hfs, z["ray_hfs"], z["hf_boundary"])
+    close(core.obs[:, :871], z["obs"][:, :871], atol=3e-5)
+    # subset ids: only those rows change, heightmap columns included
+    core.obs[:] = -5.0
+    ids = torch.tensor([0, 63], dtype=torch.int64, device=DEV)
+    core.post_step(_hip.POST_OBS | _hip.POST_HF, ids)
+    assert torch.equal(core.obs[[0, 63]], two[[0, 63]]) and torch.all(core.obs[1:63] == -5.0)
+
+
 def test_g6_post_step_subset_and_contact_bodies(km, mlib):
     """reset path: observations only, for a subset of env ids; and the fall-contact termination branch."""
     from parc_amd import _hip

@@ -69,6 +69,22 @@ def main():
     def k5():
         L.parc_refresh_obs_hfs(_hip.stream(), n, _hip.ptr(rays), P, _hip.ptr(root_state), _hip.ptr(env_off), ter, -3.0, 3.0, dst, 1312)
 
+    # empty-ish kernel floor: K5 on 1 env (one workgroup)
+    def k5_one():
+        L.parc_refresh_obs_hfs(_hip.stream(), 1, _hip.ptr(rays), P, _hip.ptr(root_state), _hip.ptr(env_off), ter, -3.0, 3.0, dst, 1312)
+    print(json.dumps({"kernel": "hf_gather_kernel(1 env)", "us_per_launch_back_to_back": time_loop(k5_one, args.iters)}))
+    for nn in (256, 1024, 2048, 4096):
+        if nn <= n:
+            def k5n(nn=nn):
+                L.parc_refresh_obs_hfs(_hip.stream(), nn, _hip.ptr(rays), P, _hip.ptr(root_state), _hip.ptr(env_off), ter, -3.0, 3.0, dst, 1312)
+            print(json.dumps({"kernel": "hf_gather_kernel", "envs": nn, "us_per_launch_back_to_back": time_loop(k5n, args.iters)}))
+    for epb in (1, 2, 4, 8):
+        L.parc_tune_hf_envs_per_block(epb)
+        print(json.dumps({"kernel": "hf_gather_kernel", "epb": epb, "envs": n, "us_per_launch_back_to_back": time_loop(k5, args.iters)}))
+    L.parc_tune_hf_envs_per_block(2)
+    for ab in (1, 2, 3, 4, 5, 0):
+        L.parc_tune_hf_ablation(ab)
+        print(json.dumps({"kernel": "hf_gather_kernel", "ablation": ab, "us": time_loop(k5, args.iters)}))
     us_loop = time_loop(k5, args.iters)
     us_med, us_min = time_single(k5, 100)
     alg_bytes = n * (16 + P * 4 + P * 4)
@@ -76,5 +92,49 @@ def main():
                       "us_single_min": us_min, "algorithmic_bytes": alg_bytes, "GBps_back_to_back": alg_bytes / us_loop / 1e3}))
 
 
+def bench_post_step(n, iters):
+    """Fused post-physics pass on the synthetic 64-clip box-terrain workload (BASELINE config 3 shape)."""
+    from parc_amd import synthetic
+    from parc_amd.anim.kin_char_model import KinCharModel
+    from parc_amd.anim.motion_lib import MotionLib
+    from parc_amd.assets import humanoid_spec
+    from parc_amd.envs.ig_parkour.default_config import default_env_config
+    from parc_amd.tracker_core import TrackerConfig, TrackerCore
+    from parc_amd.util.terrain_util import SubTerrain
+    dev = "cuda:0"
+    km = KinCharModel(dev)
+    km.load_char_file(humanoid_spec.write_mjcf())
+    clips = synthetic.make_dataset(64, seed=0)
+    mlib = MotionLib(clips, km, dev, init_type="clips", contact_info=True)
+    hf, mn, dxdy, offs = synthetic.tile_square(clips)
+    rays = geom_util.get_xy_points_cone(torch.zeros(2), 0.05, 2, 60, 3, 3, 0.26179938779)
+    cfg = TrackerConfig(default_env_config()["env"], km, rays.shape[0])
+    core = TrackerCore(n, dev, km, mlib, cfg, rays)
+    core.set_terrain(SubTerrain.from_arrays(hf, mn, dxdy, device=dev))
+    g = torch.Generator().manual_seed(0)
+    core.motion_ids[:] = torch.randint(0, 64, (n,), generator=g).to(dev)
+    core.motion_xy_offset[:] = torch.tensor(offs[:, 0]).to(dev)[core.motion_ids]
+    core.motion_time_offsets[:] = (torch.rand(n, generator=g) * 3.0).to(dev)
+    core.time_buf[:] = (torch.randint(1, 60, (n,), generator=g).float() / 30.0).to(dev)
+    # put the simulated character on its reference pose
+    core.post_step(_hip.POST_REF)
+    core.root_state[:, 0:3] = core.ref_root_pos
+    core.root_state[:, 3:7] = core.ref_root_rot
+    core.dof_state.view(n, 28, 2)[..., 0] = core.ref_dof_pos
+    core.rigid_body_state.view(n, 15, 13)[..., 0:3] = core.ref_body_pos
+    full = _hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF
+    us_fused = time_loop(lambda: core.post_step(full), iters)
+    us_nohf = time_loop(lambda: core.post_step(full & ~_hip.POST_HF), iters)
+    # algorithmic bytes per env (SURVEY.md 8d): K5 3544 + K3 7*760 + state 456 + obs cols [0,871) 3484 + bodies 780 + 8 out
+    alg = n * (3544 + 7 * 760 + 456 + 3484 + 780 + 8)
+    print(json.dumps({"kernel": "track_post_kernel(fused hf)", "envs": n, "us_per_launch": us_fused, "algorithmic_bytes": alg,
+                      "GBps": alg / us_fused / 1e3, "us_without_hf": us_nohf, "mean_reward": core.reward.mean().item(),
+                      "done_frac": (core.done != 0).float().mean().item()}))
+
+
 if __name__ == "__main__":
+    if "--post" in sys.argv:
+        sys.argv.remove("--post")
+        bench_post_step(4096, 300)
+        sys.exit(0)
     main()
