@@ -1,0 +1,56 @@
+"""ctypes binding of the HOST build of the simulator core (oracle/sim_host.cpp) -- TEST INFRASTRUCTURE ONLY."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libparc_sim_host.so")
+_lib = None
+
+
+class TerrainS(ctypes.Structure):
+    _fields_ = [("hf", ctypes.c_void_p), ("dim_x", ctypes.c_int32), ("dim_y", ctypes.c_int32), ("min_x", ctypes.c_float),
+                ("min_y", ctypes.c_float), ("dx", ctypes.c_float), ("dy", ctypes.c_float)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+        _lib = ctypes.CDLL(_LIB)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class HostSim:
+    """State arrays in the Isaac Gym layouts, stepped on the CPU."""
+
+    def __init__(self, model_struct, n, hf, min_point, dxdy, num_bodies=15, dof_size=28):
+        self.m = model_struct
+        self.n, self.B, self.D = n, num_bodies, dof_size
+        self.hf = np.ascontiguousarray(hf, dtype=np.float32)
+        self.ter = TerrainS(_p(self.hf), self.hf.shape[0], self.hf.shape[1], float(min_point[0]), float(min_point[1]),
+                            float(dxdy[0]), float(dxdy[1]))
+        self.root_state = np.zeros((n, 13), np.float32)
+        self.root_state[:, 6] = 1.0
+        self.dof_state = np.zeros((n, dof_size, 2), np.float32)
+        self.rigid_body_state = np.zeros((n, num_bodies, 13), np.float32)
+        self.contact_forces = np.zeros((n, num_bodies, 3), np.float32)
+        self.env_offsets = np.zeros((n, 3), np.float32)
+        self.act_lo = np.full(dof_size, -10.0, np.float32)
+        self.act_hi = np.full(dof_size, 10.0, np.float32)
+
+    def step(self, action, n_sub=4, h=1.0 / 120.0):
+        action = np.ascontiguousarray(action, dtype=np.float32)
+        lib().sim_host_step(ctypes.byref(self.m), self.ter, self.n, _p(self.root_state), _p(self.dof_state), _p(self.rigid_body_state),
+                            _p(self.contact_forces), _p(self.env_offsets), _p(action), _p(self.act_lo), _p(self.act_hi),
+                            ctypes.c_int(n_sub), ctypes.c_float(h))
+
+    def refresh_bodies(self):
+        lib().sim_host_refresh_bodies(ctypes.byref(self.m), self.n, _p(self.root_state), _p(self.dof_state), _p(self.rigid_body_state),
+                                      _p(self.contact_forces))

@@ -84,7 +84,7 @@ def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into parc_amd/lib/libparc_hip.so (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
-        [os.path.join(os.path.dirname(_HERE), "include", "parc_hip.h")]
+        [os.path.join(os.path.dirname(_HERE), "include", "parc_hip.h"), os.path.join(os.path.dirname(_HERE), "include", "parc_sim.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)

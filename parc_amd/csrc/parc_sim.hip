@@ -1,0 +1,65 @@
+// Device entry points of the articulated-body simulator: one env per lane, 64 envs per workgroup.
+#include <hip/hip_runtime.h>
+
+#include "parc_sim_core.h"
+
+#define SIM_THREADS 64
+
+__global__ __launch_bounds__(SIM_THREADS) void sim_step_kernel(const parc_sim_model_t *__restrict__ model, parc_terrain_t ter, int n_envs,
+                                                               float *root_state, float *dof_state, float *rigid_body_state,
+                                                               float *contact_forces, const float *__restrict__ env_offsets,
+                                                               const float *__restrict__ action, const float *__restrict__ act_lo,
+                                                               const float *__restrict__ act_hi, int n_sub, float h) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_envs) return;
+    const parc_sim_model_t &m = *model;
+    const int B = m.num_bodies, D = m.dof_size;
+    parc_sim::Scratch s;
+    parc_sim::env_step(m, ter, env_offsets + 3 * (size_t)e, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e,
+                       rigid_body_state + 13 * (size_t)B * e, contact_forces + 3 * (size_t)B * e, action + (size_t)D * e, act_lo, act_hi,
+                       n_sub, h, s);
+}
+
+__global__ __launch_bounds__(SIM_THREADS) void sim_refresh_kernel(const parc_sim_model_t *__restrict__ model, int n, const int64_t *__restrict__ env_ids,
+                                                                  const float *__restrict__ root_state, const float *__restrict__ dof_state,
+                                                                  float *rigid_body_state, float *contact_forces) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int e = env_ids ? (int)env_ids[k] : k;
+    const parc_sim_model_t &m = *model;
+    const int B = m.num_bodies, D = m.dof_size;
+    parc_sim::State x;
+    float zero_act[PARC_SIM_MAX_DOFS], lo[PARC_SIM_MAX_DOFS], hi[PARC_SIM_MAX_DOFS];
+    for (int d = 0; d < D; ++d) {
+        zero_act[d] = 0.f;
+        lo[d] = -1.f;
+        hi[d] = 1.f;
+    }
+    parc_sim::load_state(m, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e, zero_act, lo, hi, x);
+    parc_sim::publish_bodies(m, x, rigid_body_state + 13 * (size_t)B * e, contact_forces + 3 * (size_t)B * e);
+}
+
+extern "C" int parc_sim_step(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,
+                             float *dof_state, float *rigid_body_state, float *contact_forces, const float *env_offsets,
+                             const float *action, const float *action_low, const float *action_high, int n_substeps, float h) {
+    if (!model || n_envs < 0 || n_substeps <= 0 || !(h > 0.f) || !terrain.hf) return PARC_EINVAL;
+    if (n_envs == 0) return PARC_OK;
+    hipLaunchKernelGGL(sim_step_kernel, dim3((n_envs + SIM_THREADS - 1) / SIM_THREADS), dim3(SIM_THREADS), 0, (hipStream_t)stream, model,
+                       terrain, n_envs, root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low,
+                       action_high, n_substeps, h);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}
+
+extern "C" int parc_sim_refresh_bodies(void *stream, const parc_sim_model_t *model, int n_envs, const int64_t *env_ids, int n_sel,
+                                       const float *root_state, const float *dof_state, float *rigid_body_state, float *contact_forces) {
+    if (!model || n_envs < 0) return PARC_EINVAL;
+    int n = env_ids ? n_sel : n_envs;
+    if (n <= 0) return n == 0 ? PARC_OK : PARC_EINVAL;
+    hipLaunchKernelGGL(sim_refresh_kernel, dim3((n + SIM_THREADS - 1) / SIM_THREADS), dim3(SIM_THREADS), 0, (hipStream_t)stream, model, n,
+                       env_ids, root_state, dof_state, rigid_body_state, contact_forces);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}
+
+extern "C" int parc_sim_abi(void) { return 1; }

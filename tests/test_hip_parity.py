@@ -302,3 +302,48 @@ def test_full_size_properties(km, mlib):
     done_all = torch.ones((Tn, n), dtype=torch.int32, device=DEV)
     ret1 = rl_util.compute_td_lambda_return(r, v, done_all, 0.99, 0.95)   # reset everywhere -> one-step TD
     assert torch.allclose(ret1, r + 0.99 * v, atol=1e-5)
+
+
+def test_sim_device_matches_host_build(km):
+    """The simulator kernel against the HOST build of the same source (oracle/sim_host.cpp): a few env steps of
+    random actions on a bumpy terrain, 64 envs.  fp32 with different libm / contraction: tolerance 1e-3 after
+    3 steps (contacts make the dynamics locally stiff)."""
+    from parc_amd import _hip
+    from parc_amd.sim_model import SimModel
+    from oracle.sim_host import HostSim
+    rng = np.random.default_rng(2)
+    sm = SimModel(km)
+    n = 64
+    hf = (rng.random((40, 40)) * 0.3).astype(np.float32)
+    host = HostSim(sm.struct, n, hf, [-4.0, -4.0], [0.4, 0.4])
+    host.root_state[:, 0:2] = rng.random((n, 2)) * 6.0
+    host.root_state[:, 2] = 1.15 + rng.random(n) * 0.2
+    host.root_state[:, 7:13] = rng.standard_normal((n, 6)) * 0.3
+    host.dof_state[:, :, 0] = rng.standard_normal((n, 28)) * 0.2
+    host.dof_state[:, :, 1] = rng.standard_normal((n, 28)) * 0.5
+    host.env_offsets[:, 0] = rng.random(n) * 2.0
+    rs, ds = T(host.root_state.copy()), T(host.dof_state.copy())
+    rb, cf = torch.zeros((n, 15, 13), device=DEV), torch.zeros((n, 15, 3), device=DEV)
+    eo, lo, hi = T(host.env_offsets), T(host.act_lo), T(host.act_hi)
+    d_hf = T(hf)
+    ter = _hip.terrain_struct(d_hf, [-4.0, -4.0], [0.4, 0.4])
+    L = _hip.lib()
+    for step in range(3):
+        act = (rng.standard_normal((n, 28)) * 0.5).astype(np.float32)
+        host.step(act, n_sub=4, h=1.0 / 120.0)
+        a = T(act)
+        _hip.check(L.parc_sim_step(_hip.stream(), sm.device_ptr(DEV), ter, n, _hip.ptr(rs), _hip.ptr(ds), _hip.ptr(rb), _hip.ptr(cf),
+                                   _hip.ptr(eo), _hip.ptr(a), _hip.ptr(lo), _hip.ptr(hi), 4, 1.0 / 120.0), "parc_sim_step")
+        torch.cuda.synchronize()
+    assert torch.isfinite(rs).all() and torch.isfinite(ds).all()
+    close(rs[:, 0:7], host.root_state[:, 0:7], atol=1e-3)
+    close(rs[:, 7:13], host.root_state[:, 7:13], atol=2e-2)
+    close(ds[..., 0], host.dof_state[..., 0], atol=2e-3)
+    close(rb[..., 0:3], host.rigid_body_state[..., 0:3], atol=2e-3)
+    # refresh kernel == host refresh
+    rb2, cf2 = torch.ones((n, 15, 13), device=DEV), torch.ones((n, 15, 3), device=DEV)
+    ids = torch.arange(0, n, 2, device=DEV)
+    _hip.check(L.parc_sim_refresh_bodies(_hip.stream(), sm.device_ptr(DEV), n, _hip.ptr(ids), int(ids.numel()), _hip.ptr(rs), _hip.ptr(ds),
+                                         _hip.ptr(rb2), _hip.ptr(cf2)), "refresh")
+    close(rb2[0::2, :, 0:7], rb[0::2, :, 0:7], atol=1e-4)
+    assert torch.all(rb2[1::2] == 1.0) and torch.all(cf2[0::2] == 0.0)

@@ -1,0 +1,206 @@
+"""Physical invariants of the articulated-body simulator, checked on the HOST build of the very same source
+(parc_amd/csrc/parc_sim_core.h compiled by g++, oracle/sim_host.cpp).  The dynamics have no arithmetic reference
+(Isaac Gym is an absent third-party binary): parity unpinned, so correctness is argued from conservation laws,
+closed forms and rest states."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO  # noqa: F401
+
+
+@pytest.fixture(scope="module")
+def model():
+    from parc_amd.anim.kin_char_model import KinCharModel
+    from parc_amd.assets import humanoid_spec
+    from parc_amd.sim_model import SimModel
+    km = KinCharModel("cpu")
+    km.load_char_file(humanoid_spec.write_mjcf())
+    return km, SimModel(km)
+
+
+def make(model, n=1, hf=None, **over):
+    from oracle.sim_host import HostSim
+    km, sm = model
+    s = copy.deepcopy(sm.struct)
+    for k, v in over.items():
+        setattr(s, k, v)
+    if hf is None:
+        hf = np.full((20, 20), -100.0, np.float32)   # ground far away: free flight
+    return HostSim(s, n, hf, [-4.0, -4.0], [0.4, 0.4])
+
+
+def rotm(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def momentum(model, sim, e=0):
+    """linear momentum, angular momentum about the world origin, kinetic energy from rigid_body_state"""
+    _, sm = model
+    P, L, T = np.zeros(3), np.zeros(3), 0.0
+    for b in range(sim.B):
+        bs = sim.rigid_body_state[e, b].astype(np.float64)
+        R = rotm(bs[3:7])
+        w, v0 = bs[10:13], bs[7:10]
+        c = R @ sm.body_com[b]
+        vc = v0 + np.cross(w, c)
+        xc = bs[0:3] + c
+        I = R @ sm.body_inertia_com[b] @ R.T
+        m = sm.body_mass[b]
+        P += m * vc
+        L += I @ w + m * np.cross(xc, vc)
+        T += 0.5 * m * vc @ vc + 0.5 * w @ I @ w
+    return P, L, T
+
+
+def test_mass_properties(model):
+    _, sm = model
+    assert 40.0 < sm.total_mass < 55.0          # DeepMimic humanoid: ~45 kg nominal, ~50 kg from the geom volumes
+    assert np.all(sm.body_mass > 0.1)
+    for b in range(15):
+        assert np.all(np.linalg.eigvalsh(sm.body_inertia_com[b]) > 0)
+    assert sm.struct.num_spheres == 50
+
+
+def test_free_fall_closed_form(model):
+    sim = make(model)
+    sim.root_state[0, 2] = 5.0
+    sim.root_state[0, 7:10] = [0.3, -0.2, 1.0]
+    h, steps = 1.0 / 120.0, 30
+    for _ in range(steps):
+        sim.step(np.zeros((1, 28)), n_sub=4, h=h)
+    k = steps * 4
+    g = 9.81
+    # semi-implicit Euler: v_k = v0 - g k h ; z_k = z0 + sum_{i=1..k} v_i h
+    vz = 1.0 - g * k * h
+    z = 5.0 + h * (k * 1.0 - g * h * k * (k + 1) / 2)
+    P, _, _ = momentum(model, sim)
+    _, sm = model
+    vcom = P / sm.total_mass
+    assert abs(vcom[2] - vz) < 2e-3
+    assert abs(vcom[0] - 0.3) < 2e-3 and abs(vcom[1] + 0.2) < 2e-3
+    assert abs(sim.root_state[0, 2] - z) < 0.02     # root ~ com for the held pose
+
+
+def _momentum_drift(model, h, n_sub, steps=60):
+    rng = np.random.default_rng(0)
+    sim = make(model, gravity=0.0)
+    sim.root_state[0, 0:3] = [0.1, -0.3, 2.0]
+    sim.root_state[0, 7:13] = rng.standard_normal(6) * 0.5
+    sim.dof_state[0, :, 0] = rng.standard_normal(28) * 0.3
+    sim.dof_state[0, :, 1] = rng.standard_normal(28) * 2.0
+    sim.refresh_bodies()
+    P0, L0, _ = momentum(model, sim)
+    act = rng.standard_normal((1, 28)) * 0.5
+    for _ in range(steps):
+        sim.step(act, n_sub=n_sub, h=h)
+    P1, L1, _ = momentum(model, sim)
+    assert np.all(np.isfinite(sim.root_state))
+    return np.abs(P1 - P0).max(), np.abs(L1 - L0).max(), np.linalg.norm(P0), np.linalg.norm(L0)
+
+
+def test_momentum_conservation_zero_gravity(model):
+    """Joint drives and limits are internal forces: total linear and angular momentum are constants of the
+    motion.  The semi-implicit Euler step conserves them to first order: the drift over 0.5 s of violent motion
+    (joint rates ~2 rad/s) is small at the production step (1/120 s) and shrinks 4x when the step does."""
+    dP1, dL1, nP, nL = _momentum_drift(model, 1.0 / 120.0, 4)
+    dP4, dL4, _, _ = _momentum_drift(model, 1.0 / 480.0, 16)
+    assert dP1 / nP < 0.04 and dL1 / nL < 0.15
+    assert 3.0 < dP1 / dP4 < 5.0 and 3.0 < dL1 / dL4 < 5.0
+
+
+def test_energy_without_drives(model):
+    """No gravity, no PD, no limits, no contact: kinetic energy is conserved up to the integrator's O(h) drift."""
+    rng = np.random.default_rng(1)
+    km, sm = model
+    sim = make(model, gravity=0.0, limit_kp=0.0, limit_kd=0.0)
+    for d in range(28):
+        sim.m.kp[d] = 0.0
+        sim.m.kd[d] = 0.0
+    sim.root_state[0, 2] = 2.0
+    sim.root_state[0, 10:13] = rng.standard_normal(3) * 0.5
+    sim.dof_state[0, :, 1] = rng.standard_normal(28) * 1.0
+    sim.refresh_bodies()
+    _, _, T0 = momentum(model, sim)
+    for _ in range(30):
+        sim.step(np.zeros((1, 28)), n_sub=8, h=1.0 / 240.0)
+    _, _, T1 = momentum(model, sim)
+    assert abs(T1 - T0) / T0 < 0.05
+
+
+def test_stand_on_flat_ground(model):
+    """PD holds the zero pose; the feet carry the weight: sum of contact forces = m g, the root stays up.
+    (Checked 0.8 s after the drop: the zero pose has its centre of mass over the heels and slowly tips over
+    afterwards, as a real passive humanoid would.)"""
+    km, sm = model
+    sim = make(model, hf=np.zeros((20, 20), np.float32))
+    sim.root_state[0, 2] = 0.92
+    for _ in range(25):
+        sim.step(np.zeros((1, 28)), n_sub=4, h=1.0 / 120.0)
+    assert np.all(np.isfinite(sim.root_state))
+    fz = sim.contact_forces[0, :, 2].sum()
+    assert abs(fz - sm.total_mass * 9.81) / (sm.total_mass * 9.81) < 0.05
+    assert 0.8 < sim.root_state[0, 2] < 0.95
+    feet = sim.contact_forces[0, [11, 14], 2]
+    assert np.all(feet > 50.0)                          # both feet loaded
+    others = np.delete(sim.contact_forces[0, :, 2], [11, 14])
+    assert np.all(np.abs(others) < 1e-3)
+    assert np.linalg.norm(sim.root_state[0, 7:10]) < 0.3
+
+
+def test_friction_stops_sliding(model):
+    km, sm = model
+    sim = make(model, hf=np.zeros((40, 40), np.float32))
+    sim.root_state[0, 2] = 0.9
+    sim.root_state[0, 7] = 1.0      # sliding start
+    for _ in range(60):
+        sim.step(np.zeros((1, 28)), n_sub=4, h=1.0 / 120.0)
+    assert abs(sim.rigid_body_state[0, 11, 7]) < 0.2   # foot no longer slides
+
+
+def test_wall_blocks_motion(model):
+    """A column 1 m high next to the character stops a ballistic pelvis: side contact gives a horizontal normal."""
+    km, sm = model
+    hf = np.zeros((40, 40), np.float32)
+    hf[25:, :] = 3.0                                      # wall at x >= -4 + 24.5*0.4 = 5.8
+    sim = make(model, hf=hf, gravity=0.0)
+    sim.root_state[0, 0:3] = [5.0, 0.0, 1.0]             # feet just above the ground, no gravity
+    sim.root_state[0, 7] = 3.0
+    for _ in range(40):
+        sim.step(np.zeros((1, 28)), n_sub=4, h=1.0 / 120.0)
+    assert sim.root_state[0, 0] < 5.9                     # did not tunnel into the wall
+    assert sim.root_state[0, 7] < 0.5
+
+
+def test_joint_limits_hold(model):
+    km, sm = model
+    sim = make(model, gravity=0.0)
+    for d in range(28):
+        sim.m.kp[d] = 0.0
+        sim.m.kd[d] = 0.0
+    sim.root_state[0, 2] = 2.0
+    sim.dof_state[0, 17, 1] = 8.0           # right knee (range 0..160 deg) driven into hyper-extension
+    sim.dof_state[0, 17, 0] = 0.05
+    sim.dof_state[0, 24, 1] = -8.0
+    for _ in range(40):
+        sim.step(np.zeros((1, 28)), n_sub=4, h=1.0 / 120.0)
+    assert sim.dof_state[0, 24, 0] > -0.25
+    assert sim.dof_state[0, 17, 0] < np.deg2rad(160) + 0.25
+
+
+def test_random_actions_stay_finite(model):
+    rng = np.random.default_rng(5)
+    hf = (rng.random((40, 40)) * 0.6).astype(np.float32)
+    sim = make(model, n=16, hf=hf)
+    sim.root_state[:, 0:2] = rng.random((16, 2)) * 4.0
+    sim.root_state[:, 2] = 1.6
+    for _ in range(120):
+        sim.step(rng.standard_normal((16, 28)) * 1.5, n_sub=4, h=1.0 / 120.0)
+    assert np.all(np.isfinite(sim.root_state)) and np.all(np.isfinite(sim.dof_state))
+    assert np.all(np.abs(sim.root_state[:, 7:13]) < 120.0)
+    assert np.all(sim.root_state[:, 2] > -0.2)          # nobody fell through the ground
