@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of the tracker training loop (rollout + train data + PPO update).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One bench "step" = one PPO iteration of the reference's loop (learning/dm_ppo_agent.py:230-272, base_agent.py:290-309):
+T = 32 env steps on every one of the 4096 envs of the rank (simulator + fused post-step kernel + policy forward +
+experience record + resets), critic passes + TD(lambda) + advantage normalisation, then 5 epochs x 8 minibatches of
+16384 samples with the gradient all-reduced over RCCL per minibatch (the reference's cadence).  Per-GPU work is fixed as
+N grows ("weak").  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# fp32 throughout, like the reference (torch 1.13 default: no TF32; gfx950 has no TF32 path anyway)
+torch.backends.cuda.matmul.allow_tf32 = False
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+# algorithmic bytes per env of the fused post-step kernel: K5 heightmap gather 3544 (16 in + 441*4 gathered +
+# 441*4 stored) + K3 7 queries x 760 + simulator state read 456 + observation columns [0,871) 3484 + body states 780 + 8 out
+POST_STEP_BYTES_PER_ENV = 3544 + 7 * 760 + 456 + 3484 + 780 + 8
+
+
+def cpu_baseline(env, clips, tiled, budget_s=12.0):
+    """The CPU oracle (C port of the reference's kinematic / observation / reward path, OpenMP) on the same 4096-env
+    state, timed on this box's host cores.  Physics and the policy are NOT part of it (the reference's physics is the
+    GPU-only Isaac Gym binary)."""
+    from oracle import oracle as orc
+    c = env._core
+    km = env._kin_char_model
+    z = lambda t: t.detach().cpu().numpy()
+    char = orc.Char(z(km._parent_indices), z(km._local_translation), z(km._local_rotation), [j.joint_type.value for j in km._joints],
+                    [z(j.axis) if j.axis is not None else np.zeros(3, np.float32) for j in km._joints], [j.dof_idx for j in km._joints])
+    mlib = orc.MotionLib(char, [cl["frames"] for cl in clips], [cl["fps"] for cl in clips], [cl["loop"] for cl in clips],
+                         [cl["weight"] for cl in clips], [cl["contacts"] for cl in clips])
+    n = env.get_num_envs()
+    mids, times = z(c.motion_ids), z(c.time_buf + c.motion_time_offsets)
+    off = z(c.motion_xy_offset - c.env_offsets[:, 0:2])
+    rs, ds = z(c.root_state), z(c.dof_state).reshape(n, 28, 2)
+    cf = z(c.contact_forces).reshape(n, 15, 3)
+    rb = z(c.rigid_body_state).reshape(n, 15, 13)[..., 0:3]
+    rays = z(c.ray_xy_points)
+    s = env._cfg.struct
+    tar_dt = np.array(list(s.tar_dt), np.float32)
+    st = dict(char_root_pos=rs[:, 0:3], char_root_rot=rs[:, 3:7], char_root_vel=rs[:, 7:10], char_root_ang_vel=rs[:, 10:13],
+              char_dof_pos=np.ascontiguousarray(ds[..., 0]), char_dof_vel=np.ascontiguousarray(ds[..., 1]), char_rigid_body_pos=rb,
+              contact_forces=cf)
+    jw, dw, cw, w5 = list(s.joint_err_w)[:14], list(s.dof_err_w)[:28], list(s.contact_w)[:15], list(s.reward_w)
+
+    def one_step():
+        ref = orc.update_ref_motion(char, mlib, mids, times, off)
+        glob = rs[:, 0:3] + z(c.env_offsets)
+        hfs = orc.refresh_ray_obs_hfs(rays, glob, orc.calc_heading(rs[:, 3:7]), tiled[0], tiled[1], tiled[2])
+        orc.compute_obs(char, mlib, tar_dt, env._cfg.key_body_ids, mids, times, off, st["char_root_pos"], st["char_root_rot"],
+                        st["char_root_vel"], st["char_root_ang_vel"], st["char_dof_pos"], st["char_dof_vel"], cf, hfs)
+        orc.compute_reward(char, env._cfg.key_body_ids, st, ref, jw, dw, cw, w5)
+    one_step()
+    t0 = time.time()
+    k = 0
+    while time.time() - t0 < budget_s:
+        one_step()
+        k += 1
+    dt = time.time() - t0
+    return {"value": n * k / dt, "unit": "env-steps/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": "{} env steps x {} envs of the kinematic/observation/reward path (K3 K2 K4 K5 K6-K9) in the C oracle with OpenMP; "
+                      "no physics, no policy: the reference's physics is the GPU-only Isaac Gym binary".format(k, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--workload", default="boxes_64clips")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    dev = "cuda:{}".format(local_rank)
+    torch.cuda.set_device(dev)
+    from parc_amd import _hip, workloads
+    from parc_amd.util import mp_util
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
+    mp_util.init(rank, world, dev)
+    torch.manual_seed(0 + 41 * rank)       # run.py:90 of the reference
+    np.random.seed(41 * rank)
+
+    env, clips, tiled = workloads.build_env(args.workload, args.envs, dev, seed=0)
+    agent = workloads.build_agent(env, dev, mp_scale_rollout=False)
+    N, T = env.get_num_envs(), agent._steps_per_iter
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        agent._train_iter()
+    env._core.timing_events = []
+    rollout_s = [0.0]
+    orig_rollout = agent._rollout_train
+
+    def timed_rollout(n):
+        torch.cuda.synchronize()
+        t = time.time()
+        orig_rollout(n)
+        torch.cuda.synchronize()
+        rollout_s[0] += time.time() - t
+    agent._rollout_train = timed_rollout
+
+    barrier()
+    t0 = time.time()
+    info = None
+    for _ in range(args.steps):
+        info = agent._train_iter()
+    barrier()
+    elapsed = time.time() - t0
+    agent._rollout_train = orig_rollout
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    # dominant env kernel: the fused post-step launch (heightmap gather + reference pose + obs + reward + done)
+    evs = env._core.timing_events
+    env._core.timing_events = None
+    kern_us = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3 if evs else float("nan")
+    full = _hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF
+    for _ in range(10):
+        env._core.post_step(full)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(200):
+        env._core.post_step(full)
+    e.record()
+    torch.cuda.synchronize()
+    kern_b2b_us = s.elapsed_time(e) * 1e3 / 200
+    alg_bytes = N * POST_STEP_BYTES_PER_ENV
+    achieved = alg_bytes / (kern_b2b_us * 1e-6) / 1e9
+
+    if rank == 0:
+        total_env_steps = world * N * T * args.steps
+        out = {
+            "metric": "env-steps/sec (whole node), humanoid tracker training loop",
+            "value": total_env_steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "{} envs/GPU tracker on procgen box heightfields, 64 synthetic clips (BASELINE.json configs[2])".format(N)
+                       if args.workload == "boxes_64clips" else args.workload,
+                       "envs_per_gpu": N, "env_steps_per_bench_step": N * T, "rollout_steps": T, "update_epochs": agent._update_epochs,
+                       "minibatch": agent._batch_size * N, "sim_substeps": env._sim_steps * env._substeps, "parallelism": "dp{}".format(world),
+                       "grad_allreduce": "per minibatch (reference cadence)"},
+            "roofline": {"kernel": "track_post_kernel (fused K5 heightmap gather + K3 K2 K4 K6-K10)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": kern_b2b_us,
+                         "us_per_launch_event_pairs_in_timed_region": kern_us, "launches_in_timed_region": len(evs)},
+            "rollout_env_steps_per_s": world * N * T * args.steps / max(rollout_s[0], 1e-9),
+            "rollout_fraction_of_time": rollout_s[0] / elapsed,
+            "mean_episode_return": info["mean_return"] if info else None,
+            "mean_episode_length": info["mean_ep_len"] if info else None,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(env, clips, tiled)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

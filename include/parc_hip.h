@@ -104,6 +104,7 @@ typedef struct {
     float episode_length, contact_eps, min_obs_h, max_obs_h;
     int32_t num_ray_points;                      /* 441 */
     int32_t obs_dim;                             /* 1312 */
+    float task1_w, task2_w, target_radius;       /* task reward terms, logged only while rel_task_w == 0 */
 } parc_track_cfg_t;
 
 /*
@@ -121,13 +122,14 @@ typedef struct {
     const float *motion_time_offsets; /* [N]   dm_env.py:100 */
     const float *motion_xy_offset;  /* [N,2] = motion_offsets[motion_id, terrain_id]  (dm_env.py:604-615) */
     const float *time_buf;          /* [N] */
+    const float *target_xy;         /* [N,2]   ig_parkour_env.py:791 (task reward only) */
     /* outputs */
     float *ref_root_pos, *ref_root_rot, *ref_root_vel, *ref_root_ang_vel; /* [N,3] [N,4] [N,3] [N,3] */
     float *ref_joint_rot, *ref_dof_vel, *ref_dof_pos;                     /* [N,J,4] [N,D] [N,D] */
     float *ref_contacts, *ref_body_pos;                                   /* [N,B] [N,B,3] */
     float *obs;                     /* [N,obs_dim]; columns [obs_dim-P, obs_dim) belong to parc_refresh_obs_hfs */
     float *reward;                  /* [N] */
-    float *reward_terms;            /* [6,N]: pose_r vel_r root_pos_r root_vel_r key_pos_r contact_penalty */
+    float *reward_terms;            /* [9,N]: pose_r vel_r root_pos_r root_vel_r key_pos_r contact_penalty task_r1 task_r2 total_task_r */
     int32_t *done;                  /* [N]  DoneFlags after the motion-end override (dm_env.py:782) */
     int32_t *done_kind;             /* [N]  0 none, 1 failed, 2 ended without failing (feeds parc_update_fail_rates) */
 } parc_env_buffers_t;

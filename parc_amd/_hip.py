@@ -63,14 +63,15 @@ class TrackCfgS(ctypes.Structure):
                 ("root_pos_termination_dist", c_f), ("root_rot_termination_angle", c_f), ("termination_height", c_f),
                 ("num_contact_bodies", c_i32), ("contact_body_mask", c_i32 * MAX_BODIES),
                 ("episode_length", c_f), ("contact_eps", c_f), ("min_obs_h", c_f), ("max_obs_h", c_f),
-                ("num_ray_points", c_i32), ("obs_dim", c_i32)]
+                ("num_ray_points", c_i32), ("obs_dim", c_i32),
+                ("task1_w", c_f), ("task2_w", c_f), ("target_radius", c_f)]
 
 
 class EnvBuffersS(ctypes.Structure):
     _fields_ = [("num_envs", c_i32),
                 ("root_state", c_vp), ("dof_state", c_vp), ("rigid_body_state", c_vp), ("contact_forces", c_vp),
                 ("env_offsets", c_vp), ("motion_ids", c_vp), ("motion_time_offsets", c_vp), ("motion_xy_offset", c_vp),
-                ("time_buf", c_vp),
+                ("time_buf", c_vp), ("target_xy", c_vp),
                 ("ref_root_pos", c_vp), ("ref_root_rot", c_vp), ("ref_root_vel", c_vp), ("ref_root_ang_vel", c_vp),
                 ("ref_joint_rot", c_vp), ("ref_dof_vel", c_vp), ("ref_dof_pos", c_vp),
                 ("ref_contacts", c_vp), ("ref_body_pos", c_vp),

@@ -749,6 +749,24 @@ __global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_mode
                     buf.reward_terms[3 * (size_t)N + e] = root_vel_r;
                     buf.reward_terms[4 * (size_t)N + e] = key_r;
                     buf.reward_terms[5 * (size_t)N + e] = cp;
+                    {
+                        // task terms  ig_parkour_env.py:1346-1393 (logged; they scale the reward only if rel_task_w > 0)
+                        float tx = buf.target_xy[2 * e] - c_pos.x, ty = buf.target_xy[2 * e + 1] - c_pos.y;
+                        float terr = tx * tx + ty * ty;
+                        float task_r1 = expf(-0.075f * terr);
+                        float tl = sqrtf(terr);
+                        float dxn = tl > 0.01f ? tx / tl : 0.f, dyn = tl > 0.01f ? ty / tl : 0.f;
+                        float mve = fmaxf(2.0f - (dxn * rs[7] + dyn * rs[8]), 0.f);
+                        float min_vel_r = expf(-(mve * mve));
+                        float hd = calc_heading(c_rot);
+                        float he = fmaxf(1.0f - (dxn * cosf(hd) + dyn * sinf(hd)), 0.f);
+                        float task2 = min_vel_r * expf(-(he * he));
+                        float task_r = cfg.task1_w * task_r1 + cfg.task2_w * task2;
+                        if (terr < cfg.target_radius * cfg.target_radius) task_r = 1.0f;
+                        buf.reward_terms[6 * (size_t)N + e] = task_r1;
+                        buf.reward_terms[7 * (size_t)N + e] = task2;
+                        buf.reward_terms[8 * (size_t)N + e] = task_r;
+                    }
                     // done
                     const float tm = buf.time_buf[e];
                     int done = PARC_DONE_NULL;

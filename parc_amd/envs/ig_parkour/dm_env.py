@@ -1,0 +1,213 @@
+"""DeepMimic sub-environment: clip database, terrain tiling, reset sampling, per-clip failure rates.
+
+Host-side mirror of the reference's ``envs/ig_parkour/dm_env.py`` (DeepMimicEnv :23-116, 188-356, 493-684, 786-875)
+and of the ``RefCharEnv`` parts it inherits (envs/ig_parkour/mgdm_dm_util.py:23-136,232-276).  The per-step
+arithmetic (reference pose sampling, target observations, termination, failure-rate EMA) runs in the HIP
+kernels; this class owns the bookkeeping tensors and the sampling logic that the reference also does with torch
+RNG calls (multinomial / rand) at reset time.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from ...anim import motion_lib
+from ...util import terrain_util
+from .. import base_env
+
+
+class DeepMimicEnv:
+    def __init__(self, config, num_envs, device, visualize, char_model, core=None, motion_input=None):
+        env_config = config["env"]
+        dm = env_config["dm"]
+        self._num_envs = num_envs
+        self._device = device
+        self._visualize = visualize
+        self._kin_char_model = char_model
+        self._timestep = 1.0 / env_config["control_freq"]
+        self._rand_root_pos_offset_scale = env_config["rand_root_pos_offset_scale"]
+        self._root_pos_offset = None
+        self._root_rot_offset = None
+        self._max_obs_h = env_config["max_obs_h"]
+        self._min_obs_h = env_config["min_obs_h"]
+        self._random_reset_pos = dm.get("random_reset_pos", False)
+        self._min_motion_weight = dm.get("min_motion_weight", 0.01)
+        self._demo_mode = env_config["demo_mode"]
+        self._rand_reset = env_config["rand_reset"]
+        self._target_xy_future_time_max = dm["target_xy_future_time_max"]
+        self._target_xy_future_time_min = dm["target_xy_future_time_min"]
+        self._ignore_fail_rates = dm.get("ignore_fail_rates", False)
+        self._terrains_per_motion = dm["terrains_per_motion"]
+        self._fail_rate_quantiles = torch.tensor(dm["fail_rate_quantiles"], dtype=torch.float32, device=device)
+        self._one_motion_mode = False
+        self._selected_motion_id = 0
+        self._terrain_build_mode = dm.get("terrain_build_mode", "square")
+        self._motion_classes = dm.get("motion_classes", [])
+        self._has_motion_classes = False
+
+        if motion_input is not None:            # in-memory clips (parc_amd.synthetic)
+            self._motion_lib = motion_lib.MotionLib(motion_input, char_model, device, init_type="clips", contact_info=True)
+        else:
+            self._motion_lib = motion_lib.MotionLib(dm["motion_file"], char_model, device, contact_info=True,
+                                                    unsafe_pickle=bool(dm.get("unsafe_pickle", False)))
+        M = self._motion_lib.num_motions()
+        if "fail_rates_path" in dm:
+            self._motion_id_fail_rates = torch.load(dm["fail_rates_path"], weights_only=True).to(dtype=torch.float32, device=device)
+        else:
+            self._motion_id_fail_rates = torch.ones(M, dtype=torch.float32, device=device)
+        self._ema_weight = 0.01
+        self._motion_start_time_fraction = torch.zeros(num_envs, dtype=torch.float32, device=device)
+        self._core = core
+        self._dm_motion_offsets = None
+        self._terrain = None
+
+    # ------------------------------------------------------------------ buffers shared with the kernels
+    def attach(self, core):
+        self._core = core
+        self._motion_ids = core.motion_ids
+        self._motion_terrain_ids = core.motion_terrain_ids
+        self._motion_time_offsets = core.motion_time_offsets
+        self._time_buf = core.time_buf
+        self._timestep_buf = core.timestep_buf
+        self._done_buf = core.done
+        self._ray_hfs = core.ray_hfs
+        self._ray_xy_points = core.ray_xy_points
+
+    # ------------------------------------------------------------------ terrain (reference :118-126,188-356,493-507)
+    def build_terrain(self, env_config, terrain_save_path, x_offset=0.0, y_offset=0.0):
+        if self._terrain_build_mode != "square":
+            raise NotImplementedError("terrain_build_mode '{}' (square tiling is the tracker default)".format(self._terrain_build_mode))
+        hm = env_config["dm"]["heightmap"]
+        dx = float(hm["horizontal_scale"])
+        npad = hm["padding"] / dx
+        assert abs(round(npad) - npad) < 1e-5
+        npad = int(round(npad))
+        assert self._terrains_per_motion == 1
+        ters = self._motion_lib._terrains
+        M = self._motion_lib.num_motions()
+        assert all(t is not None for t in ters), "every clip needs its terrain for the tiled layout"
+        dim_x = max(int(t.dims[0].item()) for t in ters) + 2 * npad
+        dim_y = max(int(t.dims[1].item()) for t in ters) + 2 * npad
+        n_side = int(np.ceil(np.sqrt(M)))
+        first_x = -dim_x * n_side * dx / 2.0 + x_offset
+        first_y = -dim_y * n_side * dx / 2.0 + y_offset
+        glob = terrain_util.SubTerrain("heightmap", dim_x * n_side, dim_y * n_side, dx, dx, first_x, first_y, device=self._device)
+        offsets = torch.zeros((M, self._terrains_per_motion, 2), dtype=torch.float32, device=self._device)
+        k = 0
+        for i in range(n_side):
+            for j in range(n_side):
+                if k >= M:
+                    break
+                t = ters[k]
+                t.pad(npad, torch.min(t.hf).item())                 # :245-249 pads with the clip terrain's minimum
+                xo, yo = first_x + i * dim_x * dx, first_y + j * dim_y * dx
+                offsets[k, 0, 0] = xo - t.min_point[0]
+                offsets[k, 0, 1] = yo - t.min_point[1]
+                sx, sy = i * dim_x, j * dim_y
+                glob.hf[sx:sx + t.hf.shape[0], sy:sy + t.hf.shape[1]] = t.hf
+                glob.hf_mask[sx:sx + t.hf.shape[0], sy:sy + t.hf.shape[1]] = t.hf_mask
+                k += 1
+        self._terrain = glob
+        self._dm_motion_offsets = offsets
+        if terrain_save_path:
+            os.makedirs(os.path.dirname(terrain_save_path) or ".", exist_ok=True)
+            cpu_t = glob.torch_copy()
+            cpu_t.set_device("cpu")
+            with open(terrain_save_path, "wb") as f:
+                pickle.dump({"terrain": cpu_t.numpy_copy(), "terrains_per_motion": self._terrains_per_motion,
+                             "motion_offsets": offsets.cpu().numpy(), "all_terrain_verts": [], "all_terrain_tris": []}, f)
+        return [], []
+
+    def load_terrain(self, terrain_save_path):
+        from ...util import safe_pickle
+        data = safe_pickle.load_motion_file_safe(terrain_save_path)
+        t = data["terrain"]
+        if not isinstance(t, dict) or not isinstance(data.get("motion_offsets"), np.ndarray):
+            raise RuntimeError("{} is not a terrain cache this reader can open without executing it; delete it to "
+                               "rebuild".format(terrain_save_path))
+        self._terrain = terrain_util.SubTerrain.from_arrays(t["hf"], t["min_point"], t["dxdy"], t.get("hf_mask"), t.get("hf_maxmin"),
+                                                            device=self._device)
+        self._terrains_per_motion = int(data["terrains_per_motion"])
+        self._dm_motion_offsets = torch.tensor(data["motion_offsets"], dtype=torch.float32, device=self._device)
+        return [], []
+
+    def set_tiled(self, hf, min_point, dxdy, motion_offsets):
+        """Install an already tiled global heightfield (parc_amd.synthetic.tile_square)."""
+        self._terrain = terrain_util.SubTerrain.from_arrays(hf, min_point, dxdy, device=self._device)
+        self._dm_motion_offsets = torch.tensor(motion_offsets, dtype=torch.float32, device=self._device)
+
+    # ------------------------------------------------------------------ reset (reference :517-568,656-684)
+    def _get_motion_times(self, env_ids=None):
+        if env_ids is None:
+            return self._time_buf + self._motion_time_offsets
+        return self._time_buf[env_ids] + self._motion_time_offsets[env_ids]
+
+    def sample_reset(self, env_ids):
+        """Pick clip, tile and start time for the given envs and write the bookkeeping buffers.  The reference
+        state itself is then produced by the post-step kernel (PARC_POST_REF) for these envs."""
+        n = len(env_ids)
+        ml = self._motion_lib
+        if self._demo_mode:
+            motion_ids = env_ids % ml.num_motions()
+        elif self._one_motion_mode:
+            motion_ids = torch.full_like(env_ids, self._selected_motion_id)
+        elif self._ignore_fail_rates:
+            motion_ids = ml.sample_motions(n)
+        else:
+            w = torch.clamp(self._motion_id_fail_rates, min=self._min_motion_weight) * ml._motion_weights
+            motion_ids = ml.sample_motions(n, w)
+        terrain_ids = torch.randint(high=self._terrains_per_motion, size=(n,), dtype=torch.int64, device=self._device)
+        if self._rand_reset:
+            motion_times = ml.sample_time(motion_ids)
+        else:
+            motion_times = ml.get_motion_length(motion_ids) * self._motion_start_time_fraction[env_ids]
+        self._motion_ids[env_ids] = motion_ids
+        self._motion_terrain_ids[env_ids] = terrain_ids
+        self._motion_time_offsets[env_ids] = motion_times
+        self._core.motion_xy_offset[env_ids] = self._dm_motion_offsets[motion_ids, terrain_ids]
+        self._timestep_buf[env_ids] = 0
+        self._time_buf[env_ids] = 0.0
+        self._done_buf[env_ids] = base_env.DoneFlags.NULL.value
+
+    # ------------------------------------------------------------------ accessors used by agent / recorder
+    def set_rand_root_pos_offset_scale(self, val):
+        self._rand_root_pos_offset_scale = val
+
+    def set_root_pos_offset(self, val=None):
+        self._root_pos_offset = val
+
+    def set_root_rot_offset(self, val=None):
+        self._root_rot_offset = val
+
+    def set_demo_mode(self, val=None):
+        self._demo_mode = (not self._demo_mode) if val is None else val
+        return self._demo_mode
+
+    def set_motion_start_time_fraction(self, val):
+        self._motion_start_time_fraction = val
+
+    def get_env_motion_length(self, env_ids):
+        return self._motion_lib.get_motion_length(self._motion_ids[env_ids])
+
+    def get_env_motion_time(self, env_ids):
+        return self._get_motion_times(env_ids)
+
+    def get_env_motion_name(self, env_id):
+        return self._motion_lib.get_motion_names()[self._motion_ids[env_id].item()]
+
+    def post_test_update(self):
+        return
+
+    def get_extra_log_info(self):
+        """Per-clip failure rates and their quantiles (reference :786-845)."""
+        names = self._motion_lib.get_motion_names()
+        fr = self._motion_id_fail_rates
+        top, _ = torch.sort(fr, descending=True)
+        q = torch.quantile(top, self._fail_rate_quantiles)
+        info = {"MOTION_FAIL_RATES": {names[i]: fr[i].item() * 100.0 for i in range(len(names))},
+                "Misc": {"top fail rate": top[0].item() * 100.0}}
+        for i in range(self._fail_rate_quantiles.shape[0]):
+            key = "Fail Rate at " + str(round(self._fail_rate_quantiles[i].item() * 100.0)) + "% Quantile"
+            info["Misc"][key] = q[i].item() * 100.0
+        return info

@@ -1,0 +1,439 @@
+"""Vectorised humanoid tracking environment on MI355X.
+
+Drop-in for the reference's ``envs/ig_parkour/ig_parkour_env.py`` IGParkourEnv (+ its bases
+``envs/ig_char_env.py`` IGCharEnv and ``envs/ig_env.py`` IGEnv): same constructor, ``reset`` / ``step`` /
+``get_obs_space`` / ``get_action_space`` surface, the same persistent buffers returned by reference, and the
+attribute names the agent / recorder reach into.  Isaac Gym is replaced by the HIP simulator
+(include/parc_sim.h); reference-pose sampling, observations, reward and termination are one fused HIP launch
+per step (include/parc_hip.h parc_track_post_step).
+
+Only the DeepMimic sub-environment (``fraction_dm_envs: 1.0``, the tracker default) is implemented; the
+motion-generator sub-env (mgdm) is outside the hot path.
+"""
+import os
+import pickle
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from ... import _hip
+from ...anim import kin_char_model
+from ...gym_spaces import Box
+from ...sim_model import SimModel, action_bounds_pd
+from ...tracker_core import TrackerConfig, TrackerCore
+from ...util import geom_util, terrain_util
+from .. import base_env
+from . import dm_env
+
+SIM_CHAR_IDX = 0
+
+
+class IGParkourEnv(base_env.BaseEnv):
+    NAME = "ig_parkour"
+
+    def __init__(self, config, num_envs, device, visualize, motion_input=None, tiled_terrain=None):
+        super().__init__(visualize=visualize)
+        if visualize:
+            raise NotImplementedError("the MI355X build has no viewer; run with visualize=False")
+        self._start_compute_time = time.time()
+        env_config = config["env"]
+        self._config = config
+        self._num_envs = num_envs
+        self._device = device
+        self._episode_length = env_config["episode_length"]
+        self._env_spacing = env_config.get("env_spacing", 5)
+        self._global_obs = env_config["global_obs"]
+        self._fraction_dm_envs = env_config["fraction_dm_envs"]
+        self._num_dm_envs = min(int(self._fraction_dm_envs * num_envs), num_envs)
+        if self._num_dm_envs != num_envs:
+            raise NotImplementedError("fraction_dm_envs < 1 needs the motion-generator sub-env (out of the tracker hot path)")
+        self._num_mgdm_envs = 0
+        self._output_motion_dir = env_config.get("output_motion_dir", "output/_motions/recorded_motions/")
+        self._never_done = env_config.get("never_done", False)
+        self._report_tracking_error = env_config.get("report_tracking_error", False)
+        self._use_heightmap = True
+        self._use_contact_info = env_config["use_contact_info"]
+        self._enable_tar_obs = env_config.get("enable_tar_obs", True)
+        self._rand_reset = env_config.get("rand_reset", True)
+        self._demo_mode = env_config["demo_mode"]
+        self._bypass_record_fail = False
+        self._write_agent_states_flag = False
+        self._record_obs = False
+
+        # sim timing (envs/ig_env.py:100-118, YAML `sim:` block)
+        sim_freq = env_config.get("sim_freq", 60)
+        control_freq = env_config.get("control_freq", 10)
+        assert sim_freq >= control_freq and sim_freq % control_freq == 0
+        self._control_freq = control_freq
+        self._timestep = 1.0 / control_freq
+        self._sim_steps = int(sim_freq / control_freq)
+        self._substeps = int(config.get("sim", {}).get("substeps", 2))
+        self._sim_h = 1.0 / (sim_freq * self._substeps)
+
+        # character
+        self._kin_char_model = kin_char_model.KinCharModel(device)
+        self._kin_char_model.load_char_file(env_config["char_file"])
+        km = self._kin_char_model
+        assert env_config["control_mode"] == "pd", "only the PD control mode of the tracker config is implemented"
+        self._sim_model = SimModel(km)
+        low, high = action_bounds_pd(km)
+        self._action_space = Box(low=low.astype(np.float32), high=high.astype(np.float32))
+        self._action_bound_low = torch.tensor(low, dtype=torch.float32, device=device)
+        self._action_bound_high = torch.tensor(high, dtype=torch.float32, device=device)
+
+        # heightmap ray fan (ig_parkour_env.py:139-155)
+        self._ray_xy_points = geom_util.get_xy_points_cone(
+            center=torch.zeros(2), dx=env_config["ray_dx"], num_neg=env_config["ray_points_behind"],
+            num_pos=env_config["ray_points_ahead"], num_rays_neg=env_config["ray_num_left"],
+            num_rays_pos=env_config["ray_num_right"], angle_between_rays=env_config["ray_angle"]).to(device)
+
+        # DeepMimic sub-env: clips + terrain
+        self._dm_env = dm_env.DeepMimicEnv(config, num_envs, device, visualize, km, motion_input=motion_input)
+        self._cfg = TrackerConfig(env_config, km, self._ray_xy_points.shape[0])
+        self._core = TrackerCore(num_envs, device, km, self._dm_env._motion_lib, self._cfg, self._ray_xy_points)
+        self._dm_env.attach(self._core)
+        self._build_terrains(env_config, tiled_terrain)
+        self._core.set_terrain(self._dm_env._terrain)
+
+        # env placement (ig_parkour_env.py:492-501)
+        n_row = int(np.sqrt(num_envs))
+        idx = torch.arange(num_envs, device=device)
+        self._env_offsets = self._core.env_offsets
+        self._env_offsets[:, 0] = self._env_spacing * 2 * (idx % n_row)
+        self._env_offsets[:, 1] = self._env_spacing * 2 * torch.div(idx, n_row, rounding_mode="floor")
+
+        self._build_sim_tensors(env_config)
+        self._build_data_buffers()
+        self.set_write_agent_states_flag(env_config.get("write_agent_states", False))
+        if self.is_writing_agent_states():
+            self.build_agent_states_dict()
+
+    # ------------------------------------------------------------------ construction helpers
+    def _build_terrains(self, env_config, tiled_terrain):
+        dm = self._dm_env
+        if tiled_terrain is not None:
+            dm.set_tiled(*tiled_terrain)
+            return
+        path = env_config["dm"].get("terrain_save_path")
+        if path and os.path.exists(path):
+            dm.load_terrain(path)
+        else:
+            dm.build_terrain(env_config, path)
+
+    def _build_sim_tensors(self, env_config):
+        """Views with the reference's names onto the Isaac-Gym-layout state tensors (ig_char_env.py:166-217,
+        ig_parkour_env.py:685-718)."""
+        c = self._core
+        N, B, D = self._num_envs, self._cfg.num_bodies, self._cfg.dof_size
+        self._root_state, self._dof_state = c.root_state, c.dof_state
+        self._rigid_body_state, self._contact_forces = c.rigid_body_state, c.contact_forces
+        self._char_root_pos = c.root_state[:, 0:3]
+        self._char_root_rot = c.root_state[:, 3:7]
+        self._char_root_vel = c.root_state[:, 7:10]
+        self._char_root_ang_vel = c.root_state[:, 10:13]
+        ds = c.dof_state.view(N, D, 2)
+        self._char_dof_pos = ds[..., 0]
+        self._char_dof_vel = ds[..., 1]
+        rb = c.rigid_body_state.view(N, B, 13)
+        self._char_rigid_body_pos = rb[..., 0:3]
+        self._char_rigid_body_rot = rb[..., 3:7]
+        self._char_rigid_body_vel = rb[..., 7:10]
+        self._char_rigid_body_ang_vel = rb[..., 10:13]
+        self._char_contact_forces = c.contact_forces.view(N, B, 3)
+        self._ref_root_pos, self._ref_root_rot = c.ref_root_pos, c.ref_root_rot
+        self._ref_root_vel, self._ref_root_ang_vel = c.ref_root_vel, c.ref_root_ang_vel
+        self._ref_body_pos, self._ref_joint_rot = c.ref_body_pos, c.ref_joint_rot
+        self._ref_dof_pos, self._ref_dof_vel, self._ref_contacts = c.ref_dof_pos, c.ref_dof_vel, c.ref_contacts
+        self._key_body_ids = torch.tensor(self._cfg.key_body_ids, dtype=torch.long, device=self._device)
+        self._contact_body_ids = torch.tensor(self._cfg.contact_body_ids, dtype=torch.long, device=self._device)
+        self._num_rbs = B
+        self._action_buffer = torch.zeros((N, D), dtype=torch.float32, device=self._device)
+        init_pose = env_config.get("init_pose", None)
+        self._init_pose = torch.tensor(init_pose if init_pose is not None else [0.0] * (6 + D), dtype=torch.float32, device=self._device)
+
+    def _build_data_buffers(self):
+        c = self._core
+        N = self._num_envs
+        self._reward_buf, self._done_buf = c.reward, c.done
+        self._timestep_buf, self._time_buf = c.timestep_buf, c.time_buf
+        self._ep_num_buf = torch.zeros(N, device=self._device, dtype=torch.int64)
+        self._obs_buf = c.obs
+        self._ray_hfs = c.ray_hfs
+        self._target_xy, self._next_target_xy_time = c.target_xy, c.next_target_xy_time
+        self._info = dict()
+        self._all_env_ids = torch.arange(N, device=self._device, dtype=torch.long)
+        names = ["pose_r", "vel_r", "root_pos_r", "root_vel_r", "key_pos_r", "contact_penalty", "task_r1", "task_r2", "total_task_r"]
+        self._reward_term_views = OrderedDict((n, c.reward_terms[i]) for i, n in enumerate(names))
+
+    # ------------------------------------------------------------------ env API (envs/base_env.py, envs/ig_env.py:51-98)
+    def get_num_envs(self):
+        return self._num_envs
+
+    def get_reward_bounds(self):
+        return (0.0, 1.0)
+
+    def get_obs_space(self):
+        return Box(low=-np.inf, high=np.inf, shape=[self._cfg.obs_dim], dtype=np.float32)
+
+    def has_dm_envs(self):
+        return True
+
+    def has_mgdm_envs(self):
+        return False
+
+    def get_dm_env(self):
+        return self._dm_env
+
+    def get_replan_time_buf(self):
+        return torch.zeros(1, dtype=torch.float32, device=self._device)
+
+    def get_replan_counter(self):
+        return torch.zeros(self._num_envs, dtype=torch.int64, device=self._device)
+
+    def apply_hard_reset(self):
+        return
+
+    def set_rand_reset(self, val=None):
+        val = (not self._dm_env._rand_reset) if val is None else val
+        self._dm_env._rand_reset = val
+        self._rand_reset = val
+
+    def set_demo_mode(self, val):
+        self._demo_mode = val
+        self._dm_env._demo_mode = val
+
+    def set_rand_root_pos_offset_scale(self, val):
+        self._dm_env.set_rand_root_pos_offset_scale(val)
+
+    def get_extra_log_info(self):
+        return self._dm_env.get_extra_log_info()
+
+    def post_test_update(self):
+        self._dm_env.post_test_update()
+
+    # ------------------------------------------------------------------ reset (ig_parkour_env.py:1012-1041, dm_env.py:656-684)
+    def reset(self, env_ids=None):
+        if env_ids is None:
+            env_ids = self._all_env_ids
+        c = self._core
+        if len(env_ids) > 0:
+            env_ids = env_ids.to(torch.long)
+            dm = self._dm_env
+            dm.sample_reset(env_ids)
+            c.post_step(_hip.POST_REF, env_ids)                       # reference state at the sampled clip time
+            # RefCharEnv._char_state_init_from_ref + add_noise_to_char_state (mgdm_dm_util.py:119-136)
+            self._char_root_pos[env_ids] = c.ref_root_pos[env_ids]
+            self._char_root_rot[env_ids] = c.ref_root_rot[env_ids]
+            self._char_root_vel[env_ids] = c.ref_root_vel[env_ids]
+            self._char_root_ang_vel[env_ids] = c.ref_root_ang_vel[env_ids]
+            self._char_dof_pos[env_ids] = c.ref_dof_pos[env_ids]
+            self._char_dof_vel[env_ids] = c.ref_dof_vel[env_ids]
+            if dm._rand_root_pos_offset_scale != 0.0:
+                noise = torch.rand((env_ids.shape[0], 2), device=self._device, dtype=torch.float32) * 2.0 - 1.0
+                self._char_root_pos[env_ids, 0:2] += dm._rand_root_pos_offset_scale * noise
+            if dm._root_pos_offset is not None:
+                self._char_root_pos[env_ids] += dm._root_pos_offset[env_ids]
+            if dm._root_rot_offset is not None:
+                raise NotImplementedError("root rotation offsets at reset")
+            self._next_target_xy_time[env_ids] = 0.0
+            # publish body poses of the new state, then observations for these envs only
+            _hip.check(_hip.lib().parc_sim_refresh_bodies(_hip.stream(), self._sim_model.device_ptr(self._device), self._num_envs,
+                                                          _hip.ptr(env_ids), int(env_ids.shape[0]), _hip.ptr(c.root_state),
+                                                          _hip.ptr(c.dof_state), _hip.ptr(c.rigid_body_state), _hip.ptr(c.contact_forces)),
+                       "parc_sim_refresh_bodies")
+            self._update_motion_targets()
+            c.post_step(_hip.POST_OBS | _hip.POST_HF, env_ids)
+            self._ep_num_buf[env_ids] += 1
+        self._update_info()
+        return self._obs_buf, self._info
+
+    # ------------------------------------------------------------------ step (ig_env.py:68-86,839-848)
+    def step(self, action):
+        c = self._core
+        act = action.to(dtype=torch.float32).contiguous()
+        # _pre_physics_step + _physics_step: PD targets = clipped action, sim_steps x substeps at h
+        _hip.check(_hip.lib().parc_sim_step(_hip.stream(), self._sim_model.device_ptr(self._device), c._terrain_struct, self._num_envs,
+                                            _hip.ptr(c.root_state), _hip.ptr(c.dof_state), _hip.ptr(c.rigid_body_state),
+                                            _hip.ptr(c.contact_forces), _hip.ptr(c.env_offsets), _hip.ptr(act),
+                                            _hip.ptr(self._action_bound_low), _hip.ptr(self._action_bound_high),
+                                            self._sim_steps * self._substeps, self._sim_h), "parc_sim_step")
+        # _update_time (ig_env.py:862-865)
+        self._timestep_buf += 1
+        torch.mul(self._timestep_buf, self._timestep, out=self._time_buf)
+        self._update_motion_targets()
+        # _update_misc/_update_observations/_update_reward/_update_done in one launch
+        c.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF)
+        c.update_fail_rates(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight)
+        if self._never_done:
+            self._done_buf[:] = base_env.DoneFlags.NULL.value
+        self._update_info(step=True)
+        if self._write_agent_states_flag:
+            self.write_agent_states()
+        return self._obs_buf, self._reward_buf, self._done_buf, self._info
+
+    def _update_motion_targets(self):
+        """DeepMimicEnv._update_motion_targets (dm_env.py:617-654) without the host sync of boolean indexing: every
+        env draws a candidate, only those whose timer expired take it.  Feeds the logged task reward only."""
+        c = self._core
+        dm = self._dm_env
+        N = self._num_envs
+        due = self._time_buf >= self._next_target_xy_time
+        fut = torch.rand(N, dtype=torch.float32, device=self._device)
+        fut = fut * (dm._target_xy_future_time_max - dm._target_xy_future_time_min) + dm._target_xy_future_time_min
+        times = dm._get_motion_times() + fut
+        root_pos = dm._motion_lib.calc_motion_frame(c.motion_ids, times)[0]
+        xy = root_pos[:, 0:2] + c.motion_xy_offset - c.env_offsets[:, 0:2] + torch.randn((N, 2), device=self._device) * 0.05
+        self._target_xy[:] = torch.where(due.unsqueeze(-1), xy, self._target_xy)
+        self._next_target_xy_time[:] = torch.where(due, self._time_buf + fut, self._next_target_xy_time)
+
+    def _update_info(self, step=False):
+        info = self._info
+        info["timestep"] = self._timestep_buf.clone()
+        info["ep_num"] = self._ep_num_buf.clone()
+        info["compute_time"] = time.time() - self._start_compute_time
+        info["char_contact_forces"] = self._char_contact_forces.clone()
+        if step:
+            r = dict(self._reward_term_views)
+            r["total_r"] = self._reward_buf.clone()
+            info["rewards"] = r
+            if self._report_tracking_error:
+                info["tracking_error"] = self._compute_tracking_error()
+
+    def _compute_tracking_error(self):
+        """compute_tracking_error (mgdm_dm_util.py:578-611) with torch ops on the published state (test-time metric)."""
+        km = self._kin_char_model
+        c = self._core
+        jr = km.dof_to_rot(self._char_dof_pos.contiguous())
+        bp, br = km.forward_kinematics(self._char_root_pos.contiguous(), self._char_root_rot.contiguous(), jr)
+        rbp, rbr = km.forward_kinematics(c.ref_root_pos, c.ref_root_rot, c.ref_joint_rot)
+
+        def qangle(q0, q1):
+            d = torch.abs(torch.sum(q0 * q1, dim=-1)).clamp(max=1.0)
+            return 2.0 * torch.acos(d)
+        pose_err = qangle(br, rbr).mean(dim=-1)
+        root_pos_err = torch.linalg.vector_norm(c.ref_root_pos - self._char_root_pos, dim=-1)
+        body_err = torch.linalg.vector_norm((rbp - c.ref_root_pos.unsqueeze(1)) - (bp - self._char_root_pos.unsqueeze(1)), dim=-1).mean(dim=-1)
+        root_rot_err = qangle(self._char_root_rot, c.ref_root_rot)
+        dof_vel_err = (c.ref_dof_vel - self._char_dof_vel).abs().mean(dim=-1)
+        rv = (c.ref_root_vel - self._char_root_vel).abs().mean(dim=-1)
+        rav = (c.ref_root_ang_vel - self._char_root_ang_vel).abs().mean(dim=-1)
+        return torch.stack([root_pos_err, root_rot_err, body_err, pose_err, dof_vel_err, rv, rav], dim=-1)
+
+    # ------------------------------------------------------------------ observation helpers used by the agent
+    def _compute_obs(self, env_ids=None, ret_obs_shapes=False):
+        """Observation rows for env_ids (all if None); with ret_obs_shapes the ordered segment table the agent uses to
+        build the normaliser's index set (ig_parkour_env.py:1163-1239, learning/dm_ppo_agent.py:91-109)."""
+        cfg = self._cfg
+        B = cfg.num_bodies
+        S = len(cfg.tar_obs_steps)
+        if ret_obs_shapes:
+            shapes = OrderedDict()
+            shapes["char_obs"] = {"use_normalizer": True, "shape": torch.Size([cfg.char_obs_dim])}
+            shapes["tar_obs"] = {"use_normalizer": True, "shape": torch.Size([S, cfg.tar_obs_dim])}
+            shapes["tar_contacts"] = {"use_normalizer": False, "shape": torch.Size([S, B])}
+            shapes["char_contacts"] = {"use_normalizer": False, "shape": torch.Size([B])}
+            shapes["hf"] = {"use_normalizer": False, "shape": torch.Size([self._ray_xy_points.shape[0]])}
+            return shapes
+        ids = env_ids if env_ids is not None else None
+        self._core.post_step(_hip.POST_OBS | _hip.POST_HF, ids)
+        return self._obs_buf if env_ids is None else self._obs_buf[env_ids]
+
+    # ------------------------------------------------------------------ motion recording (ig_parkour_env.py:850-995,1594-1620)
+    def set_write_agent_states_flag(self, val):
+        self._write_agent_states_flag = val
+
+    def is_writing_agent_states(self):
+        return self._write_agent_states_flag
+
+    def is_writing_env_state(self, env_id):
+        return self._writing_env_state[env_id]
+
+    def set_writing_env_state(self, env_id, val):
+        self._writing_env_state[env_id] = val
+
+    def set_env_success_state(self, env_id, val):
+        self._env_success_state[env_id] = val
+
+    def get_env_success_states(self):
+        return self._env_success_state
+
+    def build_agent_states_dict(self, name_suffix="", record_obs=False):
+        obs_shapes = self._compute_obs(ret_obs_shapes=True) if record_obs else None
+        self._dm_agent_motion = []
+        for _ in range(self._num_envs):
+            d = {"fps": int(self._control_freq), "loop_mode": "CLAMP", "frames": [], "contacts": []}
+            if record_obs:
+                d["obs"] = []
+                d["obs_shapes"] = OrderedDict((k, {"use_normalizer": v["use_normalizer"], "shape": tuple(v["shape"])})
+                                              for k, v in obs_shapes.items())
+            self._dm_agent_motion.append(d)
+        self._record_obs = record_obs
+        self.set_write_agent_states_flag(True)
+        self._writing_env_state = [True] * self._num_envs
+        self._env_success_state = [False] * self._num_envs
+        self._save_motion_name_suffix = name_suffix
+        os.makedirs(self._output_motion_dir, exist_ok=True)
+
+    def _get_char_state_all(self):
+        """[N, 34] frames (root pos | root exp map | dofs) and [N, 15] binary contacts of every env in one go."""
+        q = self._char_root_rot
+        q = torch.where(q[:, 3:4] < 0, -q, q)
+        l = torch.linalg.vector_norm(q[:, 0:3], dim=-1, keepdim=True)
+        ang = 2.0 * torch.atan2(l, q[:, 3:4])
+        axis = torch.where(l > 1e-5, q[:, 0:3] / l.clamp_min(1e-12), torch.tensor([0.0, 0.0, 1.0], device=q.device).expand_as(q[:, 0:3]))
+        em = torch.where(l > 1e-5, ang, torch.zeros_like(ang)) * axis
+        frames = torch.cat([self._char_root_pos, em, self._char_dof_pos], dim=-1)
+        contacts = (torch.linalg.vector_norm(self._char_contact_forces, dim=-1) > 1e-5).to(torch.float32)
+        return frames, contacts
+
+    def write_agent_states(self):
+        if not self.is_writing_agent_states():
+            return
+        frames, contacts = self._get_char_state_all()
+        frames, contacts = frames.cpu().numpy(), contacts.cpu().numpy()
+        obs = self._obs_buf.cpu().numpy() if self._record_obs else None
+        done = self._done_buf.cpu().numpy()
+        dm = self._dm_env
+        mlen = dm._motion_lib._motion_lengths[dm._motion_ids].cpu().numpy()
+        mtime = dm._get_motion_times().cpu().numpy()
+        any_writing = False
+        for e in range(self._num_envs):
+            if not self._writing_env_state[e]:
+                continue
+            any_writing = True
+            rec = self._dm_agent_motion[e]
+            rec["frames"].append(frames[e].copy())
+            rec["contacts"].append(contacts[e].copy())
+            if self._record_obs:
+                rec["obs"].append(obs[e].copy())
+            if done[e] == base_env.DoneFlags.FAIL.value:
+                self._writing_env_state[e] = False
+                name = dm.get_env_motion_name(e)
+                if not self._bypass_record_fail and mtime[e] < mlen[e] - self._timestep * 2.0:
+                    print("env", e, "failed to track motion", name)
+                    continue
+                self._env_success_state[e] = True
+                self.save_agent_states_to_file(e, name + self._save_motion_name_suffix)
+        self.set_write_agent_states_flag(any_writing)
+
+    def save_agent_states_to_file(self, env_id, output_motion_name=None):
+        rec = self._dm_agent_motion[env_id]
+        frames = np.stack(rec["frames"]).astype(np.float32)
+        frames[:, 0:2] += self._env_offsets[env_id, 0:2].cpu().numpy()
+        out = dict(rec)
+        out["contacts"] = np.stack(rec["contacts"]).astype(np.float32)
+        if self._record_obs:
+            out["obs"] = np.stack(rec["obs"]).astype(np.float32)
+        ter = self._dm_env._terrain
+        pad = round(1.0 // ter.dxdy[0].item()) * ter.dxdy[0].item()
+        sliced, frames = terrain_util.slice_terrain_around_motion(frames, ter, padding=pad)
+        out["terrain"] = sliced.numpy_copy()
+        out["frames"] = frames
+        if output_motion_name is None:
+            output_motion_name = "dm_motion_" + str(env_id).zfill(3)
+        path = os.path.join(self._output_motion_dir, output_motion_name + ".pkl")
+        with open(path, "wb") as f:
+            pickle.dump(out, f)
+        print("wrote motion data to", path, "num frames =", frames.shape[0])

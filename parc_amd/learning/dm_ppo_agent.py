@@ -1,0 +1,457 @@
+"""PPO learner of the tracker (DeepMimic-style imitation).
+
+Host-side mirror of the reference's agent stack -- learning/base_agent.py BaseAgent, learning/ppo_agent.py PPOAgent and
+learning/dm_ppo_agent.py DMPPOAgent -- as one class with the same method names, config keys, experience-buffer layout
+(learning/experience_buffer.py, buffers added at base_agent.py:224-253, ppo_agent.py:62-80, dm_ppo_agent.py:281-313), loss
+(ppo_agent.py:212-330) and checkpoint keys.  What changes is where the work runs:
+  * TD(lambda) and the advantage normalisation are HIP kernels (parc_amd/learning/rl_util.py) instead of a Python loop;
+  * the minibatch sampler gathers only the six buffers the loss reads;
+  * the large-critic-loss guard and the NaN trap are evaluated on the device (no ``.item()`` per minibatch);
+  * gradients live in one flat buffer that RCCL all-reduces in place (learning/mp_optimizer.py).
+"""
+import enum
+import os
+import time
+
+import numpy as np
+import torch
+
+from ..envs import base_env
+from ..gym_spaces import Box
+from ..util import mp_util
+from ..util.logger import Logger
+from . import dm_ppo_model, experience_buffer, mp_optimizer, normalizer, rl_util
+from .dm_ppo_return_tracker import DMPPOReturnTracker
+
+
+class AgentMode(enum.Enum):
+    TRAIN = 0
+    TEST = 1
+
+
+_LOSS_KEYS = ["obs", "action", "a_logp", "tar_val", "adv", "rand_action_mask"]
+
+
+class DMPPOAgent(torch.nn.Module):
+    NAME = "DM_PPO"
+
+    def __init__(self, config, env, device):
+        super().__init__()
+        self._env = env
+        self._device = device
+        self._iter = 0
+        self._sample_count = 0
+        self._config = config
+        self._is_terrain_runner = env.NAME in ("ig_terrain_runner", "ig_parkour")
+        self._has_target_task = env.NAME in ("ig_terrain_runner", "ig_deepmimic_terrain", "ig_parkour")
+        self._load_params(config)
+        self._build_normalizers()
+        self._model = dm_ppo_model.DMPPOModel(config["model"], env)
+        self.to(self._device)
+        params = [p for p in self.parameters() if p.requires_grad]
+        self._optimizer = mp_optimizer.MPOptimizer(config["optimizer"], params)
+        self._build_exp_buffer(config)
+        self._train_return_tracker = DMPPOReturnTracker(self.get_num_envs(), self._device, self._has_target_task)
+        self._test_return_tracker = DMPPOReturnTracker(self.get_num_envs(), self._device, self._has_target_task)
+        self._mode = AgentMode.TRAIN
+        self._curr_obs = None
+        self._curr_info = None
+        self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self._device)
+
+    # ------------------------------------------------------------------ config (base_agent.py:170-182, ppo_agent.py:21-51)
+    def _load_params(self, config):
+        # the reference divides the rollout length and the minibatch by the world size (base_agent.py:179-180,
+        # ppo_agent.py:27-29) so samples/iteration stay constant; "mp_scale_rollout: false" keeps per-rank work fixed
+        P = mp_util.get_num_procs() if config.get("mp_scale_rollout", True) else 1
+        self._discount = config["discount"]
+        self._iters_per_output = config["iters_per_output"]
+        self._iters_per_checkpoint = config["iters_per_checkpoint"]
+        self._normalizer_samples = config.get("normalizer_samples", np.inf)
+        self._test_episodes = config["test_episodes"]
+        self._steps_per_iter = int(np.ceil(config["steps_per_iter"] / P))
+        self._update_epochs = config["update_epochs"]
+        self._batch_size = int(np.ceil(config["batch_size"] / P))
+        self._td_lambda = config["td_lambda"]
+        self._ppo_clip_ratio = config["ppo_clip_ratio"]
+        self._norm_adv_clip = config["norm_adv_clip"]
+        self._action_bound_weight = config["action_bound_weight"]
+        self._action_entropy_weight = config["action_entropy_weight"]
+        self._action_reg_weight = config["action_reg_weight"]
+        self._critic_loss_weight = config["critic_loss_weight"]
+        self._exp_anneal_samples = config.get("exp_anneal_samples", np.inf)
+        self._exp_prob_beg = config.get("exp_prob_beg", 1.0)
+        self._exp_prob_end = config.get("exp_prob_end", 1.0)
+        self._clip_grad_norm = config.get("clip_grad_norm", False)
+        self._max_grad_norm = config.get("max_grad_norm", 0.5)
+        self._critic_loss_type = config.get("critic_loss_type", "L2")
+
+    def _build_normalizers(self):
+        """Observation normaliser that leaves the contact / heightmap segments untouched (dm_ppo_agent.py:78-117),
+        action normaliser from the action bounds (base_agent.py:195-203)."""
+        obs_space = self._env.get_obs_space()
+        shapes = self._env._compute_obs(ret_obs_shapes=True)
+        idx, cur = [], 0
+        for key in shapes:
+            shape = shapes[key]["shape"]
+            flat = shape[0] * shape[1] if len(shape) >= 2 else shape[0]
+            if not shapes[key]["use_normalizer"]:
+                idx.append(torch.arange(cur, cur + flat, dtype=torch.int64, device=self._device))
+            cur += flat
+        non_norm = torch.cat(idx) if idx else None
+        self._obs_norm = normalizer.Normalizer(obs_space.shape, device=self._device, dtype=torch.float32, non_norm_indices=non_norm,
+                                               clip=self._config["norm_obs_clip"])
+        a_space = self._env.get_action_space()
+        assert isinstance(a_space, Box)
+        a_mean = torch.tensor(0.5 * (a_space.high + a_space.low), device=self._device, dtype=torch.float32)
+        a_std = torch.tensor(0.5 * (a_space.high - a_space.low), device=self._device, dtype=torch.float32)
+        self._a_norm = normalizer.Normalizer(a_mean.shape, device=self._device, init_mean=a_mean, init_std=a_std, dtype=torch.float32)
+
+    def _build_exp_buffer(self, config):
+        T, N, dev = self._steps_per_iter, self.get_num_envs(), self._device
+        self._exp_buffer = experience_buffer.ExperienceBuffer(buffer_length=T, batch_size=N, device=dev)
+        obs_dim = list(self._env.get_obs_space().shape)
+        a_dim = list(self._env.get_action_space().shape)
+        B = self._env._cfg.num_bodies if hasattr(self._env, "_cfg") else 15
+
+        def add(name, shape, dtype=torch.float32):
+            self._exp_buffer.add_buffer(name, torch.zeros([T, N] + shape, device=dev, dtype=dtype))
+        add("obs", obs_dim)
+        add("next_obs", obs_dim)
+        add("action", a_dim)
+        add("reward", [])
+        add("done", [], torch.int)
+        add("a_logp", [])
+        add("tar_val", [])
+        add("adv", [])
+        add("rand_action_mask", [])
+        add("timestep", [], torch.int)
+        add("ep_num", [], torch.int)
+        add("compute_time", [])
+        add("prev_char_contact_forces", [B, 3])
+        add("next_char_contact_forces", [B, 3])
+        add("env_id", [], torch.int64)
+        self._env_ids = torch.arange(0, N, 1, device=dev, dtype=torch.int64)
+        if self._is_terrain_runner:
+            add("replan_timer", [])
+            add("replan_counter", [], torch.int64)
+
+    # ------------------------------------------------------------------ small helpers
+    def get_num_envs(self):
+        return self._env.get_num_envs()
+
+    def get_action_size(self):
+        return int(np.prod(self._env.get_action_space().shape))
+
+    def calc_num_params(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def set_mode(self, mode):
+        self._mode = mode
+        self._env.set_mode(base_env.EnvMode.TRAIN if mode == AgentMode.TRAIN else base_env.EnvMode.TEST)
+
+    def save(self, out_file):
+        if mp_util.is_root_proc():
+            torch.save(self.state_dict(), out_file)
+
+    def load(self, in_file):
+        self.load_state_dict(torch.load(in_file, map_location=self._device, weights_only=True))
+        self._optimizer.sync()
+        Logger.print("Loaded model parameters from {:s}".format(in_file))
+
+    def _get_exp_prob(self):
+        if np.isfinite(self._exp_anneal_samples):
+            l = float(np.clip(float(self._sample_count) / self._exp_anneal_samples, 0.0, 1.0))
+            return (1.0 - l) * self._exp_prob_beg + l * self._exp_prob_end
+        return self._exp_prob_beg
+
+    def _need_normalizer_update(self):
+        return self._sample_count < self._normalizer_samples
+
+    # ------------------------------------------------------------------ acting (ppo_agent.py:87-119)
+    @torch.no_grad()
+    def _decide_action(self, obs, info):
+        norm_obs = self._obs_norm.normalize(obs)
+        dist = self._model.eval_actor(norm_obs)
+        if self._mode == AgentMode.TRAIN:
+            exp_prob = self._get_exp_prob()
+            if exp_prob >= 1.0:
+                norm_a = dist.sample()
+                mask = torch.ones_like(norm_a[..., 0])
+            else:
+                mask = torch.bernoulli(torch.full([obs.shape[0], 1], exp_prob, device=self._device))
+                norm_a = torch.where(mask == 1.0, dist.sample(), dist.mode)
+                mask = mask.squeeze(-1)
+        else:
+            norm_a = dist.mode
+            mask = torch.zeros_like(norm_a[..., 0])
+        logp = dist.log_prob(norm_a)
+        a = self._a_norm.unnormalize(norm_a)
+        return a, {"a_logp": logp, "rand_action_mask": mask}
+
+    def step(self):
+        action, action_info = self._decide_action(self._curr_obs, self._curr_info)
+        next_obs, r, done, next_info = self._env.step(action)
+        return next_obs, r, done, next_info, action, action_info
+
+    def _record_data_pre_step(self, obs, info, action, action_info):
+        eb = self._exp_buffer
+        eb.record("obs", obs)
+        eb.record("action", action)
+        if self._need_normalizer_update():
+            self._obs_norm.record(obs)
+        eb.record("a_logp", action_info["a_logp"])
+        eb.record("rand_action_mask", action_info["rand_action_mask"])
+        eb.record("prev_char_contact_forces", info["char_contact_forces"])
+
+    def _record_data_post_step(self, next_obs, r, done, next_info):
+        eb = self._exp_buffer
+        eb.record("next_obs", next_obs)
+        eb.record("reward", r)
+        eb.record("done", done)
+        eb.record("timestep", next_info["timestep"])
+        eb.record("ep_num", next_info["ep_num"])
+        eb.get_data("compute_time")[eb._buffer_head].fill_(float(next_info["compute_time"]))
+        eb.record("next_char_contact_forces", next_info["char_contact_forces"])
+        eb.record("env_id", self._env_ids)
+        if self._is_terrain_runner:
+            eb.record("replan_timer", self._env.get_replan_time_buf().expand(self.get_num_envs()))
+            eb.record("replan_counter", self._env.get_replan_counter())
+
+    def _reset_done_envs(self, done):
+        done_indices = (done != base_env.DoneFlags.NULL.value).nonzero(as_tuple=False).flatten()
+        return self._env.reset(done_indices)
+
+    def _rollout_train(self, num_steps):
+        for _ in range(num_steps):
+            action, action_info = self._decide_action(self._curr_obs, self._curr_info)
+            self._record_data_pre_step(self._curr_obs, self._curr_info, action, action_info)
+            next_obs, r, done, next_info = self._env.step(action)
+            self._train_return_tracker.update(next_info, done)
+            self._record_data_post_step(next_obs, r, done, next_info)
+            self._curr_obs, self._curr_info = self._reset_done_envs(done)
+            self._exp_buffer.inc()
+
+    def _rollout_test(self, num_episodes):
+        self._test_return_tracker.reset()
+        if num_episodes == 0:
+            return {"mean_return": 0.0, "mean_ep_len": 0.0, "num_eps": 0}
+        min_eps_per_env = int(np.ceil(num_episodes / self.get_num_envs()))
+        while True:
+            action, _ = self._decide_action(self._curr_obs, self._curr_info)
+            _, _, done, next_info = self._env.step(action)
+            self._test_return_tracker.update(next_info, done)
+            self._curr_obs, self._curr_info = self._reset_done_envs(done)
+            if torch.all(self._test_return_tracker.get_eps_per_env() > min_eps_per_env - 1):
+                break
+        return {"mean_return": self._test_return_tracker.get_mean_return().item(),
+                "mean_ep_len": self._test_return_tracker.get_mean_ep_len().item(),
+                "num_eps": self._test_return_tracker.get_episodes()}
+
+    def hard_reset_envs(self):
+        if self._is_terrain_runner:
+            self._env.apply_hard_reset()
+        self._curr_obs, self._curr_info = self._env.reset()
+
+    def test_model(self, num_episodes):
+        self.eval()
+        self.set_mode(AgentMode.TEST)
+        self.hard_reset_envs()
+        P = mp_util.get_num_procs()
+        return self._rollout_test(int(np.ceil(num_episodes / P)))
+
+    # ------------------------------------------------------------------ train data (dm_ppo_agent.py:343-411)
+    @torch.no_grad()
+    def _build_train_data(self):
+        self.eval()
+        eb = self._exp_buffer
+        obs, next_obs = eb.get_data("obs"), eb.get_data("next_obs")
+        r, done = eb.get_data("reward"), eb.get_data("done")
+        mask = eb.get_data("rand_action_mask")
+        next_vals = self._model.eval_critic(self._obs_norm.normalize(next_obs)).squeeze(-1)
+        r_min, r_max = self._env.get_reward_bounds()
+        next_vals = torch.clamp(next_vals, r_min / (1.0 - self._discount), r_max / (1.0 - self._discount))
+        succ_val = self._env.get_reward_succ() / (1.0 - self._discount)
+        fail_val = self._env.get_reward_fail() / (1.0 - self._discount)
+        next_vals = torch.where(done == base_env.DoneFlags.SUCC.value, torch.full_like(next_vals, succ_val), next_vals)
+        next_vals = torch.where(done == base_env.DoneFlags.FAIL.value, torch.full_like(next_vals, fail_val), next_vals)
+        new_vals = rl_util.compute_td_lambda_return(r, next_vals, done, self._discount, self._td_lambda)      # K16 (HIP)
+        vals = self._model.eval_critic(self._obs_norm.normalize(obs)).squeeze(-1)
+        norm_adv, mean_std = rl_util.normalize_advantage(new_vals, vals, mask, self._norm_adv_clip)            # K17 (HIP)
+        eb.set_data("tar_val", new_vals)
+        eb.set_data("adv", norm_adv)
+        return {"adv_mean": mean_std[0], "adv_std": mean_std[1]}
+
+    # ------------------------------------------------------------------ update (ppo_agent.py:186-330)
+    def _compute_loss(self, batch):
+        norm_obs = self._obs_norm.normalize(batch["obs"])
+        norm_a = self._a_norm.normalize(batch["action"])
+        pred = self._model.eval_critic(norm_obs).squeeze(-1)
+        diff = batch["tar_val"] - pred
+        critic_loss = torch.mean(torch.square(diff)) if self._critic_loss_type == "L2" else torch.mean(torch.abs(diff))
+        m = (batch["rand_action_mask"] == 1.0).to(torch.float32)
+        cnt = m.sum().clamp_min(1.0)
+        # masked means == the reference's boolean-index selection of random-action samples, without the host sync
+        a_dist = self._model.eval_actor(norm_obs)
+        a_logp = a_dist.log_prob(norm_a)
+        ratio = torch.exp(a_logp - batch["a_logp"])
+        adv = batch["adv"]
+        l0 = adv * ratio
+        l1 = adv * torch.clamp(ratio, 1.0 - self._ppo_clip_ratio, 1.0 + self._ppo_clip_ratio)
+        actor_loss = -(torch.minimum(l0, l1) * m).sum() / cnt
+        info = {"critic_loss": critic_loss.detach(), "clip_frac": (((torch.abs(ratio - 1.0) > self._ppo_clip_ratio).float() * m).sum() / cnt).detach(),
+                "imp_ratio": ((ratio * m).sum() / cnt).detach()}
+        if self._action_bound_weight != 0:
+            vmin = torch.clamp_max(a_dist.mode + 1.0, 0.0)
+            vmax = torch.clamp_min(a_dist.mode - 1.0, 0.0)
+            viol = torch.sum(torch.square(vmin), dim=-1) + torch.sum(torch.square(vmax), dim=-1)
+            abl = (viol * m).sum() / cnt
+            actor_loss = actor_loss + self._action_bound_weight * abl
+            info["action_bound_loss"] = abl.detach()
+        if self._action_entropy_weight != 0:
+            ent = (a_dist.entropy() * m).sum() / cnt
+            actor_loss = actor_loss - self._action_entropy_weight * ent
+            info["action_entropy"] = ent.detach()
+        if self._action_reg_weight != 0:
+            reg = (a_dist.param_reg() * m).sum() / cnt
+            actor_loss = actor_loss + self._action_reg_weight * reg
+            info["action_reg_loss"] = reg.detach()
+        info["actor_loss"] = actor_loss.detach()
+        # "LARGE CRITIC LOSS" guard (ppo_agent.py:225-238): stop the actor gradient when the critic is off, on device
+        actor_term = torch.where(critic_loss.detach() > 20.0, actor_loss.detach(), actor_loss)
+        loss = actor_term + self._critic_loss_weight * critic_loss
+        self._nan_flag |= torch.isnan(loss.detach()).to(torch.int32)      # NaN trap, checked once per iteration
+        info["loss"] = loss
+        return info
+
+    def _update_model(self):
+        self.train()
+        N = self.get_num_envs()
+        num_samples = self._exp_buffer.get_sample_count()
+        batch_size = self._batch_size * N
+        num_batches = int(np.ceil(float(num_samples) / batch_size))
+        acc = dict()
+        for _ in range(self._update_epochs):
+            for _ in range(num_batches):
+                batch = self._exp_buffer.sample(batch_size, keys=_LOSS_KEYS)
+                info = self._compute_loss(batch)
+                if self._clip_grad_norm:
+                    self._optimizer.step(info["loss"], model=self._model, max_norm=self._max_grad_norm)
+                else:
+                    self._optimizer.step(info["loss"])
+                for k, v in info.items():
+                    v = v.detach()
+                    acc[k] = acc[k] + v if k in acc else v.clone()
+        steps = self._update_epochs * num_batches
+        return {k: v / steps for k, v in acc.items()}
+
+    def _train_iter(self):
+        self._exp_buffer.reset()
+        self.eval()
+        self.set_mode(AgentMode.TRAIN)
+        self._rollout_train(self._steps_per_iter)
+        data_info = self._build_train_data()
+        train_info = self._update_model()
+        if self._nan_flag.item() != 0:
+            raise FloatingPointError("NaN loss during the PPO update (reference behaviour: dump batch and exit)")
+        if self._need_normalizer_update():
+            self._obs_norm.update()
+        info = {**train_info, **data_info}
+        tr = self._train_return_tracker
+        info["mean_return"] = tr.get_mean_return().item()
+        info["mean_ep_len"] = tr.get_mean_ep_len().item()
+        info["num_eps"] = tr.get_episodes()
+        for key in tr._mean_returns:
+            info[key] = tr.get_specific_mean_return(key).item()
+        return info
+
+    def _init_train(self):
+        self._iter = 0
+        self._sample_count = 0
+        self._exp_buffer.clear()
+        self._train_return_tracker.reset()
+        self._test_return_tracker.reset()
+
+    def _update_sample_count(self):
+        return mp_util.reduce_sum(self._exp_buffer.get_total_samples())
+
+    def _build_logger(self, log_file):
+        log = Logger()
+        log.set_step_key("Samples")
+        if mp_util.is_root_proc():
+            log.configure_output_file(log_file)
+        return log
+
+    def _log_train_info(self, train_info, test_info, start_time):
+        L = self._logger
+        L.log("Iteration", self._iter, collection="1_Info")
+        L.log("Wall_Time", (time.time() - start_time) / 3600.0, collection="1_Info")
+        L.log("Samples", self._sample_count, collection="1_Info")
+        L.log("Test_Return", test_info["mean_return"], collection="0_Main")
+        L.log("Test_Episode_Length", test_info["mean_ep_len"], collection="0_Main", quiet=True)
+        L.log("Test_Episodes", mp_util.reduce_sum(test_info["num_eps"]), collection="1_Info", quiet=True)
+        L.log("Train_Return", train_info.pop("mean_return"), collection="0_Main")
+        L.log("Train_Episode_Length", train_info.pop("mean_ep_len"), collection="0_Main", quiet=True)
+        L.log("Train_Episodes", mp_util.reduce_sum(train_info.pop("num_eps")), collection="1_Info", quiet=True)
+        for k, v in train_info.items():
+            if k == "loss":
+                v = v.detach()
+            L.log(k.title(), v)
+        L.log("Exp_Prob", self._get_exp_prob())
+        if self._is_terrain_runner:
+            L.log("replan timer", self._env.get_replan_time_buf().item())
+
+    def _output_train_model(self, it, out_model_file, int_output_dir):
+        self.save(out_model_file)
+        if int_output_dir != "":
+            self.save(os.path.join(int_output_dir, "model_{:010d}.pt".format(it)))
+            if mp_util.is_root_proc() and self._env.has_dm_envs():
+                torch.save(self._env.get_dm_env()._motion_id_fail_rates, os.path.join(int_output_dir, "fail_rates_{:010d}.pt".format(it)))
+
+    def train_model(self, max_samples, out_model_file, int_output_dir, log_file, logger_type=None):
+        """Outer loop (dm_ppo_agent.py:230-272)."""
+        start_time = time.time()
+        self._curr_obs, self._curr_info = self._env.reset()
+        self._logger = self._build_logger(log_file)
+        self._init_train()
+        test_info = {"mean_return": 0.0, "mean_ep_len": 0.0, "num_eps": 0}
+        while self._sample_count < max_samples:
+            train_info = self._train_iter()
+            output_iter = (self._iter % self._iters_per_output == 0)
+            if output_iter:
+                test_info = self.test_model(self._test_episodes)
+                extra = self._env.get_extra_log_info()
+                for coll in extra:
+                    for k, v in extra[coll].items():
+                        self._logger.log(k, v, collection=coll, quiet=True)
+                self._env.post_test_update()
+            self._sample_count = self._update_sample_count()
+            self._log_train_info(train_info, test_info, start_time)
+            self._logger.print_log()
+            if output_iter:
+                self._logger.write_log()
+                self._train_return_tracker.reset()
+                self.hard_reset_envs()
+            if self._iter % self._iters_per_checkpoint == 0:
+                self._output_train_model(self._iter, out_model_file, int_output_dir)
+            self._iter += 1
+
+    # ------------------------------------------------------------------ motion recording (dm_ppo_agent.py:414-533)
+    def record_motions(self, max_steps=None):
+        """Deterministic rollout of every env on its own clip from t=0; clips tracked to the end are written to the env's
+        output_motion_dir.  Returns the list of per-env success flags."""
+        self.eval()
+        self.set_mode(AgentMode.TEST)
+        env = self._env
+        env.set_rand_reset(False)
+        env.set_demo_mode(True)
+        env.set_rand_root_pos_offset_scale(0.0)
+        env._episode_length = 1000.0
+        env._cfg.struct.episode_length = 1000.0
+        env.build_agent_states_dict(name_suffix="_dm", record_obs=True)
+        self._curr_obs, self._curr_info = env.reset()
+        steps = 0
+        while env.is_writing_agent_states() and (max_steps is None or steps < max_steps):
+            action, _ = self._decide_action(self._curr_obs, self._curr_info)
+            self._curr_obs, _, _, self._curr_info = env.step(action)
+            steps += 1
+        return env.get_env_success_states()

@@ -1,0 +1,82 @@
+"""Time-major rollout storage [T, N, ...] (mirror of the reference's learning/experience_buffer.py:3-115: same buffer
+names, same flat [T*N, ...] view, same randperm-walking sampler).  ``sample`` takes an optional ``keys`` list so the
+update gathers only the six buffers the PPO loss reads instead of all seventeen (11.9 KB/sample in the reference)."""
+import torch
+
+
+class ExperienceBuffer:
+    def __init__(self, buffer_length, batch_size, device):
+        self._buffer_length = buffer_length
+        self._batch_size = batch_size
+        self._device = device
+        self._buffer_head = 0
+        self._total_samples = 0
+        self._buffers = dict()
+        self._flat_buffers = dict()
+        self._sample_buf = torch.randperm(buffer_length * batch_size, device=device, dtype=torch.long)
+        self._sample_buf_head = 0
+
+    def add_buffer(self, name, buffer):
+        assert len(buffer.shape) >= 2 and buffer.shape[0] == self._buffer_length and buffer.shape[1] == self._batch_size
+        assert name not in self._buffers
+        self._buffers[name] = buffer
+        self._flat_buffers[name] = buffer.view([buffer.shape[0] * buffer.shape[1]] + list(buffer.shape[2:]))
+
+    def reset(self):
+        self._buffer_head = 0
+        self._reset_sample_buf()
+
+    def clear(self):
+        self.reset()
+        self._total_samples = 0
+
+    def inc(self):
+        self._buffer_head = (self._buffer_head + 1) % self._buffer_length
+        self._total_samples += self._batch_size
+
+    def get_total_samples(self):
+        return self._total_samples
+
+    def get_sample_count(self):
+        return min(self._total_samples, self._buffer_length * self._batch_size)
+
+    def record(self, name, data):
+        assert data.shape[0] == self._batch_size
+        self._buffers[name][self._buffer_head] = data
+
+    def get_data(self, name):
+        return self._buffers[name]
+
+    def get_data_flat(self, name):
+        return self._flat_buffers[name]
+
+    def set_data(self, name, data):
+        buf = self._buffers[name]
+        assert buf.shape[0] == data.shape[0] and buf.shape[1] == data.shape[1]
+        buf[:] = data
+
+    def set_data_flat(self, name, data):
+        self._flat_buffers[name][:] = data
+
+    def sample(self, n, keys=None):
+        idx = self._sample_rand_idx(n)
+        names = self._flat_buffers.keys() if keys is None else keys
+        return {k: self._flat_buffers[k][idx] for k in names}
+
+    def _reset_sample_buf(self):
+        self._sample_buf[:] = torch.randperm(self._buffer_length * self._batch_size, device=self._device, dtype=torch.long)
+        self._sample_buf_head = 0
+
+    def _sample_rand_idx(self, n):
+        L = self._sample_buf.shape[0]
+        assert n <= L
+        if self._sample_buf_head + n <= L:
+            idx = self._sample_buf[self._sample_buf_head:self._sample_buf_head + n]
+            self._sample_buf_head += n
+        else:
+            head = self._sample_buf[self._sample_buf_head:].clone()
+            rem = n - (L - self._sample_buf_head)
+            self._reset_sample_buf()
+            idx = torch.cat([head, self._sample_buf[:rem]], dim=0)
+            self._sample_buf_head = rem
+        return torch.remainder(idx, self.get_sample_count())

@@ -1,0 +1,65 @@
+"""Data-parallel optimizer step: SGD/AdamW on one process per GPU with ONE RCCL all-reduce per step.
+
+Mirror of the reference's learning/mp_optimizer.py:5-90 (MPOptimizer.step/sync/_check_synced).  Difference in
+mechanics, not semantics: every parameter's ``.grad`` is a view into one persistent flat fp32 buffer, so the
+all-reduce (mean over ranks) runs in place on that buffer with no gather/scatter copies (the reference packs with
+parameters_to_vector and unpacks again each step)."""
+import torch
+
+from ..util import mp_util
+
+
+class MPOptimizer:
+    CHECK_SYNC_STEPS = 1000
+
+    def __init__(self, config, param_list):
+        self._param_list = param_list
+        self._steps = 0
+        lr = float(config["learning_rate"])
+        wd = float(config.get("weight_decay", 0.0))
+        if config["type"] == "SGD":
+            self._optimizer = torch.optim.SGD(param_list, lr, momentum=0.9, weight_decay=wd)
+        elif config["type"] == "Adam":
+            self._optimizer = torch.optim.AdamW(param_list, lr, weight_decay=wd)
+        else:
+            raise AssertionError("Unsupported optimizer type: " + config["type"])
+        n = sum(p.numel() for p in param_list)
+        self._flat_grad = torch.zeros(n, dtype=param_list[0].dtype, device=param_list[0].device)
+        off = 0
+        for p in param_list:
+            p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.sync()
+
+    def step(self, loss, **kwargs):
+        self._flat_grad.zero_()
+        loss.backward()
+        if mp_util.enable_mp():
+            torch.distributed.all_reduce(self._flat_grad, op=torch.distributed.ReduceOp.SUM)
+            self._flat_grad /= mp_util.get_num_procs()
+        if "model" in kwargs:
+            # the gradient norm of the flat buffer == norm over model parameters (all trainable params are in it)
+            max_norm = kwargs["max_norm"]
+            norm = torch.linalg.vector_norm(self._flat_grad)
+            self._flat_grad *= torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        self._optimizer.step()
+        if mp_util.enable_mp() and self._steps % self.CHECK_SYNC_STEPS == 0:
+            assert self._check_synced(), "Network parameters desynchronized"
+        self._steps += 1
+
+    def get_steps(self):
+        return self._steps
+
+    def sync(self):
+        with torch.no_grad():
+            for p in self._param_list:
+                p.copy_(mp_util.broadcast(p))
+
+    def _check_synced(self):
+        synced = True
+        for p in self._param_list:
+            if not torch.equal(p, mp_util.broadcast(p)):
+                synced = False
+        buf = torch.tensor([int(synced)], dtype=torch.int, device=self._param_list[0].device)
+        mp_util.reduce_inplace_min(buf)
+        return buf.item() != 0

@@ -90,6 +90,9 @@ class TrackerConfig:
         s.min_obs_h = float(env_config["min_obs_h"])
         s.max_obs_h = float(env_config["max_obs_h"])
         s.num_ray_points = int(num_ray_points)
+        s.task1_w = float(env_config.get("task1_w", 0.7))
+        s.task2_w = float(env_config.get("task2_w", 0.3))
+        s.target_radius = float(env_config.get("target_radius", 1.0))
         K, S = len(keys), len(steps)
         self.char_obs_dim = 12 + 6 * J + D + 3 * K
         self.tar_obs_dim = 9 + 6 * J + 3 * K
@@ -139,7 +142,9 @@ class TrackerCore:
         self.ref_body_pos = z((N, B, 3), **f32)
         self.obs = z((N, cfg.obs_dim), **f32)
         self.reward = z((N,), **f32)
-        self.reward_terms = z((6, N), **f32)
+        self.reward_terms = z((9, N), **f32)
+        self.target_xy = z((N, 2), **f32)
+        self.next_target_xy_time = z((N,), **f32)
         self.done = z((N,), dtype=torch.int, device=device)
         self.done_kind = z((N,), dtype=torch.int, device=device)
         self.ray_xy_points = ray_xy_points.to(device=device, dtype=torch.float32).contiguous()
@@ -150,6 +155,7 @@ class TrackerCore:
         self.terrain = None
         self._terrain_struct = None
         self._buf_struct = None
+        self.timing_events = None      # bench.py: list of (start, end) torch.cuda.Event pairs around full post-step launches
 
     def set_terrain(self, terrain):
         self.terrain = terrain
@@ -163,6 +169,7 @@ class TrackerCore:
             self._buf_struct = _hip.EnvBuffersS(
                 self.N, p(self.root_state), p(self.dof_state), p(self.rigid_body_state), p(self.contact_forces),
                 p(self.env_offsets), p(self.motion_ids), p(self.motion_time_offsets), p(self.motion_xy_offset), p(self.time_buf),
+                p(self.target_xy),
                 p(self.ref_root_pos), p(self.ref_root_rot), p(self.ref_root_vel), p(self.ref_root_ang_vel),
                 p(self.ref_joint_rot), p(self.ref_dof_vel), p(self.ref_dof_pos), p(self.ref_contacts), p(self.ref_body_pos),
                 p(self.obs), p(self.reward), p(self.reward_terms), p(self.done), p(self.done_kind))
@@ -187,9 +194,16 @@ class TrackerCore:
             ids = _hip.ptr(env_ids)
         else:
             n, ids = 0, _hip.c_vp(0)
+        timed = self.timing_events is not None and env_ids is None and (what & _hip.POST_REWARD_DONE)
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         _hip.check(_hip.lib().parc_track_post_step(_hip.stream(), self.km.c_struct(), self.mlib.c_struct(), self._terrain_struct,
                                                    self.cfg.struct, self.buffers(), ids, n, what, _hip.ptr(self.ray_xy_points)),
                    "parc_track_post_step")
+        if timed:
+            ev1.record()
+            self.timing_events.append((ev0, ev1))
 
     def update_fail_rates(self, fail_rates, ema_w):
         _hip.check(_hip.lib().parc_update_fail_rates(_hip.stream(), self.N, self.mlib.num_motions(), _hip.ptr(self.motion_ids),

@@ -114,3 +114,31 @@ def get_local_hf_from_terrain(xy_points, terrain):
     the HIP kernel parc_refresh_obs_hfs instead)."""
     g = terrain.get_grid_index(xy_points)
     return terrain.hf[g[..., 0], g[..., 1]]
+
+
+def slice_terrain_around_motion(motion_frames, terrain, padding=1.0):
+    """Cut the heightfield window under a recorded motion and re-centre both on the first frame
+    (reference: util/terrain_util.py:1675-1759, localize=True).  motion_frames: numpy [T, >=3] with global xy;
+    returns (SubTerrain on CPU, localized numpy frames)."""
+    frames = np.array(motion_frames, dtype=np.float32, copy=True)
+    t = terrain.torch_copy()
+    t.set_device("cpu")
+    mn = torch.tensor([frames[:, 0].min(), frames[:, 1].min()], dtype=torch.float32) - padding
+    mx = torch.tensor([frames[:, 0].max(), frames[:, 1].max()], dtype=torch.float32) + padding
+    gmin = torch.round((mn - t.min_point) / t.dxdy) * t.dxdy + t.min_point
+    gmax = torch.round((mx - t.min_point) / t.dxdy) * t.dxdy + t.min_point
+    xs = torch.arange(gmin[0].item(), (gmax[0] + t.dxdy[0]).item(), step=t.dxdy[0].item())
+    ys = torch.arange(gmin[1].item(), (gmax[1] + t.dxdy[1]).item(), step=t.dxdy[1].item())
+    x, y = torch.meshgrid(xs, ys, indexing="ij")
+    g = t.get_grid_index(torch.stack([x, y], dim=-1))
+    canon = frames[0, 0:2].copy()
+    frames[:, 0:2] -= canon
+    out = SubTerrain("terrain", g.shape[0], g.shape[1], t.dxdy[0].item(), t.dxdy[1].item(), gmin[0].item() - float(canon[0]),
+                     gmin[1].item() - float(canon[1]), device="cpu")
+    out.hf = t.hf[g[..., 0], g[..., 1]].clone()
+    out.hf_mask = t.hf_mask[g[..., 0], g[..., 1]].clone()
+    out.hf_maxmin = t.hf_maxmin[g[..., 0], g[..., 1]].clone()
+    z0 = out.get_hf_val_from_points(torch.tensor(frames[0, 0:2])).item()
+    frames[:, 2] -= z0
+    out.hf = out.hf - z0
+    return out, frames

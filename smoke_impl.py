@@ -1,0 +1,68 @@
+"""smoke(): one tiny pass of the hot path on cuda:0 -- reset, 3 env steps (simulator + fused post-step kernel) and one
+PPO iteration -- with the kinematic outputs checked against the CPU oracle on the state the GPU produced."""
+import numpy as np
+import torch
+
+
+def run():
+    assert torch.cuda.is_available(), "smoke() needs the GPU"
+    from oracle import oracle as orc
+    from parc_amd import _hip, workloads
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    env, clips, tiled = workloads.build_env("boxes_64clips", 64, dev, seed=0)
+    agent = workloads.build_agent(env, dev, steps_per_iter=4, update_epochs=1, batch_size=2)
+    obs, info = env.reset()
+    assert obs.shape == (64, 1312) and torch.isfinite(obs).all()
+    for _ in range(3):
+        a, _ = agent._decide_action(obs, info)
+        obs, r, done, info = env.step(a)
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(r).all()
+    # ---- oracle check of obs / reward / done on the state the simulator produced
+    c = env._core
+    km = env._kin_char_model
+    z = lambda t: t.detach().cpu().numpy()
+    par = z(km._parent_indices)
+    char = orc.Char(par, z(km._local_translation), z(km._local_rotation), [j.joint_type.value for j in km._joints],
+                    [z(j.axis) if j.axis is not None else np.zeros(3, np.float32) for j in km._joints], [j.dof_idx for j in km._joints])
+    mlib = orc.MotionLib(char, [cl["frames"] for cl in clips], [cl["fps"] for cl in clips], [cl["loop"] for cl in clips],
+                         [cl["weight"] for cl in clips], [cl["contacts"] for cl in clips])
+    n = 64
+    mids = z(c.motion_ids)
+    times = z(c.time_buf + c.motion_time_offsets)
+    off = z(c.motion_xy_offset - c.env_offsets[:, 0:2])
+    ref = orc.update_ref_motion(char, mlib, mids, times, off)
+    np.testing.assert_allclose(z(c.ref_root_pos), ref["ref_root_pos"], atol=2e-5)
+    np.testing.assert_allclose(z(c.ref_body_pos), ref["ref_body_pos"], atol=5e-5)
+    rs = z(c.root_state)
+    ds = z(c.dof_state).reshape(n, 28, 2)
+    glob = rs[:, 0:3] + z(c.env_offsets)
+    hfs = orc.refresh_ray_obs_hfs(z(c.ray_xy_points), glob, orc.calc_heading(rs[:, 3:7]), tiled[0], tiled[1], tiled[2])
+    tar_dt = np.array(list(env._cfg.struct.tar_dt), np.float32)
+    o_obs = orc.compute_obs(char, mlib, tar_dt, env._cfg.key_body_ids, mids, times, off, rs[:, 0:3], rs[:, 3:7], rs[:, 7:10], rs[:, 10:13],
+                            ds[..., 0], ds[..., 1], z(c.contact_forces).reshape(n, 15, 3), hfs)
+    g_obs = z(obs)
+    # 1e-3: the reference's slerp switches to a plain average when sin(half angle) < 1e-3 (util/torch_util.py:465); for
+    # nearly identical consecutive frames fp32 rounding decides the branch, the two branches differ by up to ~5e-4
+    np.testing.assert_allclose(g_obs[:, :871], o_obs[:, :871], atol=1e-3, rtol=1e-4)
+    assert np.mean(np.abs(g_obs[:, :871] - o_obs[:, :871]) > 1e-4) < 2e-3
+    assert np.mean(g_obs[:, 871:] != o_obs[:, 871:]) < 5e-3          # nearest-cell flips only at cell boundaries
+    st = dict(char_root_pos=rs[:, 0:3], char_root_rot=rs[:, 3:7], char_root_vel=rs[:, 7:10], char_root_ang_vel=rs[:, 10:13],
+              char_dof_pos=ds[..., 0], char_dof_vel=ds[..., 1], char_rigid_body_pos=z(c.rigid_body_state).reshape(n, 15, 13)[..., 0:3],
+              contact_forces=z(c.contact_forces).reshape(n, 15, 3))
+    s = env._cfg.struct
+    o_r, _ = orc.compute_reward(char, env._cfg.key_body_ids, st, ref, list(s.joint_err_w)[:14], list(s.dof_err_w)[:28], list(s.contact_w)[:15],
+                                list(s.reward_w))
+    np.testing.assert_allclose(z(r), o_r, atol=1e-3)
+    # ---- one PPO iteration end to end
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    tinfo = agent._train_iter()
+    assert np.isfinite(tinfo["critic_loss"].item()) and np.isfinite(tinfo["actor_loss"].item())
+    print("smoke ok: mean reward {:.4f}, critic_loss {:.4f}, done frac {:.3f}".format(r.mean().item(), tinfo["critic_loss"].item(),
+                                                                                  (done != 0).float().mean().item()))
+
+
+if __name__ == "__main__":
+    run()
