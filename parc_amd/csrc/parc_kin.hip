@@ -854,27 +854,42 @@ extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_
 // =============================================================================================
 // Fail-rate EMA: one thread per clip walks the envs in order (dm_env.py:758-772)
 // =============================================================================================
-__global__ void fail_rate_kernel(int n_envs, int n_motions, const int64_t *__restrict__ motion_ids,
-                                 const int32_t *__restrict__ done_kind, float ema_w, float *fail_rates) {
-    int mi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (mi >= n_motions) return;
-    float fr = fail_rates[mi];
-    bool touched = false;
-    for (int e = 0; e < n_envs; ++e) {
+// One wave per clip.  The EMA update x -> (1-w) x + (failed ? w : 0) is an affine map; lane l composes the maps of its
+// contiguous chunk of envs in env order, then the 64 chunk maps are composed in lane order: the result equals the
+// reference's sequential loop over done envs (dm_env.py:758-772) up to fp32 reassociation.
+__global__ __launch_bounds__(64) void fail_rate_kernel(int n_envs, int n_motions, const int64_t *__restrict__ motion_ids,
+                                                       const int32_t *__restrict__ done_kind, float ema_w, float *fail_rates) {
+    const int mi = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int chunk = (n_envs + 63) / 64;
+    const int e0 = lane * chunk, e1 = min(e0 + chunk, n_envs);
+    float A = 1.f, Bc = 0.f;
+    const float keep = 1.0f - ema_w;
+    for (int e = e0; e < e1; ++e) {
         int k = done_kind[e];
         if (k != 0 && motion_ids[e] == mi) {
-            fr = (k == 1) ? fr * (1.0f - ema_w) + ema_w : fr * (1.0f - ema_w);
+            A *= keep;
+            Bc = Bc * keep + (k == 1 ? ema_w : 0.f);
+        }
+    }
+    // ordered composition over lanes: f_total = f_63 o ... o f_0
+    float fr = fail_rates[mi];
+    bool touched = false;
+    for (int l = 0; l < 64; ++l) {
+        float a = __shfl(A, l, 64), b = __shfl(Bc, l, 64);
+        if (a != 1.f || b != 0.f) {
+            fr = a * fr + b;
             touched = true;
         }
     }
-    if (touched) fail_rates[mi] = fr;
+    if (lane == 0 && touched) fail_rates[mi] = fr;
 }
 
 extern "C" int parc_update_fail_rates(void *stream, int n_envs, int n_motions, const int64_t *motion_ids, const int32_t *done_kind,
                                       float ema_w, float *fail_rates) {
     if (n_envs < 0 || n_motions <= 0) return PARC_EINVAL;
-    hipLaunchKernelGGL(fail_rate_kernel, dim3((n_motions + 63) / 64), dim3(64), 0, (hipStream_t)stream, n_envs, n_motions, motion_ids,
-                       done_kind, ema_w, fail_rates);
+    hipLaunchKernelGGL(fail_rate_kernel, dim3(n_motions), dim3(64), 0, (hipStream_t)stream, n_envs, n_motions, motion_ids, done_kind,
+                       ema_w, fail_rates);
     PARC_CHECK_LAUNCH();
     return PARC_OK;
 }

@@ -1,0 +1,77 @@
+"""Data-parallel path on CPU with gloo, world_size 2: the flat-gradient all-reduce of MPOptimizer, the normaliser merge
+and the desync detector (reference: learning/mp_optimizer.py:20-90, learning/normalizer.py:28-58)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    from parc_amd.learning import mp_optimizer, normalizer
+    from parc_amd.util import mp_util
+    mp_util.init(rank, world, "cpu", port)
+    torch.manual_seed(100 + rank)                       # different init per rank: sync() must broadcast rank 0's weights
+    model = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
+    opt = mp_optimizer.MPOptimizer({"type": "SGD", "learning_rate": 0.1}, list(model.parameters()))
+    w_init = [p.detach().clone() for p in model.parameters()]
+    torch.manual_seed(7)
+    x_all = torch.randn(8, 6)
+    y_all = torch.randn(8, 1)
+    x, y = x_all[rank * 4:(rank + 1) * 4], y_all[rank * 4:(rank + 1) * 4]      # each rank sees its own half
+    loss = torch.mean(torch.square(model(x) - y))
+    opt.step(loss, model=model, max_norm=1000.0)
+    assert opt._check_synced()
+    nrm = normalizer.Normalizer((3,), device="cpu", non_norm_indices=torch.tensor([2]))
+    nrm.record(torch.full((5, 3), float(rank + 1)))
+    nrm.update()
+    # plain numpy in the queue: torch tensors would be handed over through shared-memory handles that die with the child
+    out.put((rank, [p.detach().numpy().copy() for p in model.parameters()], [w.numpy().copy() for w in w_init],
+             nrm._mean.detach().numpy().copy(), nrm._count.item(), mp_util.reduce_sum(rank + 1)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_dp_optimizer_and_normalizer_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    T = torch.from_numpy
+    res = [(r, [T(a) for a in w], [T(a) for a in i], T(m), c, s) for r, w, i, m, c, s in res]
+    (r0, w0, init0, m0, c0, s0), (r1, w1, init1, m1, c1, s1) = res
+    for a, b in zip(init0, init1):
+        assert torch.equal(a, b)                        # broadcast from rank 0 at construction
+    for a, b in zip(w0, w1):
+        assert torch.equal(a, b)                        # identical after the all-reduced step
+    # single-process reference: gradient of the mean over the two halves == mean of the per-rank gradients
+    model = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
+    with torch.no_grad():
+        for p, w in zip(model.parameters(), init0):
+            p.copy_(w)
+    torch.manual_seed(7)
+    x_all, y_all = torch.randn(8, 6), torch.randn(8, 1)
+    loss = 0.5 * (torch.mean(torch.square(model(x_all[:4]) - y_all[:4])) + torch.mean(torch.square(model(x_all[4:]) - y_all[4:])))
+    loss.backward()
+    for p, w in zip(model.parameters(), w0):
+        assert torch.allclose(p.detach() - 0.1 * p.grad, w, atol=1e-6)
+    assert c0 == 10 and c1 == 10 and torch.allclose(m0, torch.tensor([1.5, 1.5, 0.0])) and torch.equal(m0, m1)
+    assert s0 == 3 and s1 == 3

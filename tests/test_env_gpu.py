@@ -1,0 +1,127 @@
+"""Drop-in surface of the environment and agent on the GPU: shapes, dtypes, aliasing conventions,
+reset semantics, kinematic-replay upper bound of the reward, checkpoint key names, one training iteration."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def env():
+    from parc_amd import workloads
+    torch.manual_seed(0)
+    e, clips, tiled = workloads.build_env("boxes_64clips", 96, DEV, seed=0)
+    return e
+
+
+def test_spaces_and_buffers(env):
+    assert env.NAME == "ig_parkour" and env.get_num_envs() == 96
+    o, a = env.get_obs_space(), env.get_action_space()
+    assert tuple(o.shape) == (1312,) and tuple(a.shape) == (28,)
+    assert np.all(a.high > a.low)
+    # G13: PD action bounds derived from the MJCF ranges with the reference's formula (ig_char_env.py:308-348)
+    assert abs(a.high[9] - (0.5 * np.deg2rad(160) + 0.7 * np.deg2rad(160))) < 1e-5      # right elbow hinge 0..160 deg
+    assert abs(a.high[0] - 1.2 * np.deg2rad(90)) < 1e-5                                 # abdomen spherical: 1.2 * max |limit|
+    assert env.get_reward_bounds() == (0.0, 1.0) and env.get_reward_fail() == 0.0
+    shapes = env._compute_obs(ret_obs_shapes=True)
+    assert list(shapes.keys()) == ["char_obs", "tar_obs", "tar_contacts", "char_contacts", "hf"]
+    assert [v["use_normalizer"] for v in shapes.values()] == [True, True, False, False, False]
+
+
+def test_reset_and_step_semantics(env):
+    obs, info = env.reset()
+    assert obs.data_ptr() == env._obs_buf.data_ptr() and obs.shape == (96, 1312) and obs.dtype == torch.float32
+    assert torch.isfinite(obs).all()
+    assert set(["timestep", "ep_num", "compute_time", "char_contact_forces"]) <= set(info.keys())
+    ep0 = env._ep_num_buf.clone()
+    # at reset the simulated character sits on the reference pose (+ xy noise <= 0.075 m)
+    d = (env._char_root_pos - env._ref_root_pos).abs()
+    assert d[:, 0:2].max() <= 0.0751 and d[:, 2].max() < 1e-6
+    assert torch.allclose(env._char_dof_pos, env._ref_dof_pos)
+    # empty id list: no-op (not the same as None)
+    before = obs.clone()
+    env.reset(torch.zeros(0, dtype=torch.long, device=DEV))
+    assert torch.equal(env._obs_buf, before) and torch.equal(env._ep_num_buf, ep0)
+    act = torch.zeros((96, 28), device=DEV)
+    o2, r, done, info = env.step(act)
+    assert o2.data_ptr() == env._obs_buf.data_ptr()
+    assert r.shape == (96,) and r.dtype == torch.float32 and done.dtype == torch.int32
+    assert torch.all(env._timestep_buf == 1) and torch.allclose(env._time_buf, torch.full((96,), 1.0 / 30.0, device=DEV))
+    assert set(info["rewards"].keys()) == {"pose_r", "vel_r", "root_pos_r", "root_vel_r", "key_pos_r", "contact_penalty", "task_r1",
+                                           "task_r2", "total_task_r", "total_r"}
+    assert info["char_contact_forces"].shape == (96, 15, 3) and info["char_contact_forces"].data_ptr() != env._char_contact_forces.data_ptr()
+    assert torch.isfinite(r).all() and r.min() >= -1.7 and r.max() <= 1.7   # 5 exp kernels in [0,1] + contact term in [-5/3, 5/3]*mean
+    assert set(done.unique().tolist()) <= {0, 1, 3}
+    # subset reset touches only those rows
+    ids = torch.tensor([5, 17], device=DEV)
+    snap = env._obs_buf.clone()
+    env.reset(ids)
+    same = torch.ones(96, dtype=torch.bool, device=DEV)
+    same[ids] = False
+    assert torch.equal(env._obs_buf[same], snap[same]) and not torch.equal(env._obs_buf[ids], snap[ids])
+    assert torch.all(env._timestep_buf[ids] == 0) and torch.all(env._ep_num_buf[ids] == ep0[ids] + 1)
+
+
+def test_kinematic_replay_reward_upper_bound(env):
+    """A character teleported onto the reference pose gets reward 1 (all five exp kernels at 1, zero contact term)."""
+    from parc_amd import _hip
+    env.reset()
+    c = env._core
+    c.time_buf += 0.5
+    c.post_step(_hip.POST_REF)
+    env._char_root_pos[:] = c.ref_root_pos
+    env._char_root_rot[:] = c.ref_root_rot
+    env._char_root_vel[:] = c.ref_root_vel
+    env._char_root_ang_vel[:] = c.ref_root_ang_vel
+    env._char_dof_pos[:] = c.ref_dof_pos
+    env._char_dof_vel[:] = c.ref_dof_vel
+    _hip.check(_hip.lib().parc_sim_refresh_bodies(_hip.stream(), env._sim_model.device_ptr(DEV), 96, _hip.c_vp(0), 0, _hip.ptr(c.root_state),
+                                                  _hip.ptr(c.dof_state), _hip.ptr(c.rigid_body_state), _hip.ptr(c.contact_forces)), "refresh")
+    c.post_step(_hip.POST_REF | _hip.POST_REWARD_DONE)
+    assert torch.allclose(c.reward, torch.ones(96, device=DEV), atol=2e-3)
+    assert torch.all(c.done[c.time_buf + c.motion_time_offsets < env._dm_env._motion_lib._motion_lengths[c.motion_ids]] == 0)
+    c.time_buf -= 0.5
+
+
+def test_long_rollout_stays_finite(env):
+    env.reset()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    lo, hi = env._action_bound_low, env._action_bound_high
+    n_done = 0
+    for _ in range(150):
+        a = lo + (hi - lo) * torch.rand((96, 28), device=DEV, generator=g)
+        obs, r, done, info = env.step(a)
+        ids = (done != 0).nonzero().flatten()
+        n_done += int(ids.numel())
+        env.reset(ids)
+    assert torch.isfinite(obs).all() and torch.isfinite(env._root_state).all() and torch.isfinite(env._dof_state).all()
+    assert n_done > 0
+    fr = env._dm_env._motion_id_fail_rates
+    assert torch.all((fr > 0) & (fr <= 1.0))
+
+
+def test_agent_checkpoint_keys_and_training_iteration(env, tmp_path):
+    from parc_amd import workloads
+    agent = workloads.build_agent(env, DEV, steps_per_iter=4, update_epochs=2, batch_size=2)
+    keys = set(agent.state_dict().keys())
+    expect = {"_model._actor_layers.0.weight", "_model._actor_layers.2.bias", "_model._actor_layers.4.weight",
+              "_model._action_dist._mean_net.weight", "_model._action_dist._logstd_net", "_model._critic_layers.0.weight",
+              "_model._critic_out.bias", "_obs_norm._count", "_obs_norm._mean", "_obs_norm._std", "_a_norm._mean", "_a_norm._std"}
+    assert expect <= keys
+    assert agent.calc_num_params() == 10638877             # the 42.6 MB flat fp32 gradient of SURVEY.md 2.2
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    w0 = agent._model._actor_layers[0].weight.clone()
+    info = agent._train_iter()
+    assert np.isfinite(info["critic_loss"].item()) and np.isfinite(info["actor_loss"].item())
+    assert not torch.equal(w0, agent._model._actor_layers[0].weight)
+    assert agent._obs_norm._count.item() == 4 * 96
+    # non-normalised segments keep mean 0 / std 1 (contacts + heightmap = 546 dims)
+    assert torch.all(agent._obs_norm._mean[766:] == 0) and torch.all(agent._obs_norm._std[766:] == 1)
+    p = tmp_path / "model.pt"
+    agent.save(str(p))
+    agent.load(str(p))
+    res = agent.test_model(2)
+    assert np.isfinite(res["mean_return"]) and res["num_eps"] >= 96
