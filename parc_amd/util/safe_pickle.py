@@ -144,7 +144,10 @@ def load_inert(data):
         elif n == "REDUCE":
             args = stack.pop()
             func = stack.pop()
-            stack.append(Call(func, args))
+            if isinstance(func, Global) and func.module == "collections" and func.name == "OrderedDict" and args == ():
+                stack.append(OrderedDict())      # an empty ordered dict is data, not code
+            else:
+                stack.append(Call(func, args))
         elif n in ("NEWOBJ",):
             args = stack.pop()
             cls = stack.pop()

@@ -1,0 +1,80 @@
+"""End-to-end drop-in path on the GPU, driven exactly like the reference's stage scripts drive run.py
+(parc_3_tracker.py:8-78 writes env/agent YAML and calls run.main; parc_4_phys_record.py:8-65 runs --mode record):
+motion pickles + dataset YAML on disk -> env_builder / agent_builder from YAML files -> train a few iterations ->
+checkpoint -> reload -> record mode writes motion files in the PARC motion format."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_dataset(tmp, n_clips=4):
+    import parc_amd
+    from parc_amd import synthetic
+    from parc_amd.util.terrain_util import SubTerrain
+    parc_amd.install_reference_aliases()
+    clips = synthetic.make_dataset(n_clips, seed=3, frames_range=(50, 70), flat=True)
+    entries = []
+    for c in clips:
+        ter = SubTerrain.from_arrays(c["hf"], c["min_point"], c["dxdy"], device="cpu").numpy_copy()
+        p = os.path.join(tmp, c["name"] + ".pkl")
+        with open(p, "wb") as f:
+            pickle.dump({"fps": 30, "loop_mode": "CLAMP", "frames": c["frames"], "contacts": c["contacts"], "terrain": ter}, f)
+        entries.append({"file": p, "weight": 1.0})
+    ypath = os.path.join(tmp, "motions.yaml")
+    with open(ypath, "w") as f:
+        yaml.safe_dump({"motions": entries}, f)
+    return ypath
+
+
+def test_train_checkpoint_record_through_run_main(tmp_path):
+    import parc_amd
+    from parc_amd import run as parc_run
+    from parc_amd.assets import humanoid_spec
+    from parc_amd.envs.ig_parkour.default_config import default_agent_config, default_env_config
+    from parc_amd.util import safe_pickle
+    tmp = str(tmp_path)
+    motions = _write_dataset(tmp)
+    env_cfg = default_env_config(char_file=humanoid_spec.write_mjcf(), motion_file=motions, terrain_save_path=os.path.join(tmp, "terrain.pkl"))
+    env_cfg["env"]["output_motion_dir"] = os.path.join(tmp, "recorded")
+    agent_cfg = default_agent_config()
+    agent_cfg.update(steps_per_iter=8, update_epochs=1, iters_per_output=1000, iters_per_checkpoint=1)
+    env_yaml, agent_yaml = os.path.join(tmp, "dm_env.yaml"), os.path.join(tmp, "agent_config.yaml")
+    with open(env_yaml, "w") as f:
+        yaml.safe_dump(env_cfg, f)
+    with open(agent_yaml, "w") as f:
+        yaml.safe_dump(agent_cfg, f)
+    model = os.path.join(tmp, "model.pt")
+    argv = ["run.py", "--env_config", env_yaml, "--agent_config", agent_yaml, "--mode", "train", "--num_envs", "32", "--device", "cuda:0",
+            "--visualize", "False", "--max_samples", str(2 * 8 * 32), "--out_model_file", model, "--int_output_dir", os.path.join(tmp, "ckpt"),
+            "--log_file", os.path.join(tmp, "log.txt"), "--rand_seed", "0"]
+    parc_run.main(argv)
+    assert os.path.exists(model) and os.path.exists(os.path.join(tmp, "terrain.pkl")) and os.path.getsize(os.path.join(tmp, "log.txt")) > 0
+    sd = torch.load(model, weights_only=True)
+    assert "_model._actor_layers.0.weight" in sd and "_obs_norm._mean" in sd
+    assert os.path.exists(os.path.join(tmp, "ckpt", "model_0000000000.pt")) and os.path.exists(os.path.join(tmp, "ckpt", "fail_rates_0000000000.pt"))
+    # second construction loads the cached terrain (ig_parkour_env.py:600-611) and the checkpoint; record mode: one env per clip
+    from parc_amd.envs import env_builder
+    from parc_amd.learning import agent_builder
+    env = env_builder.build_env(env_yaml, 4, "cuda:0", False)
+    agent = agent_builder.build_agent(agent_yaml, env, "cuda:0")
+    agent.load(model)
+    env._bypass_record_fail = True            # an untrained policy falls early; still exercise the file writer
+    succ = agent.record_motions(max_steps=80)
+    files = sorted(os.listdir(env._output_motion_dir))
+    assert len(succ) == 4 and len(files) >= 1
+    rec = safe_pickle.load_motion_file_safe(os.path.join(env._output_motion_dir, files[0]))
+    T = rec["frames"].shape[0]
+    assert rec["fps"] == 30 and rec["loop_mode"] == "CLAMP" and rec["frames"].shape == (T, 34) and rec["contacts"].shape == (T, 15)
+    assert rec["obs"].shape == (T, 1312) and rec["terrain"]["hf"].ndim == 2
+    assert list(rec["obs_shapes"].keys()) == ["char_obs", "tar_obs", "tar_contacts", "char_contacts", "hf"]
+    assert np.allclose(rec["frames"][0, 0:2], 0.0, atol=1e-5)          # localized on the first frame
+    # the recorded clip is itself a valid motion file: it loads back into a MotionLib
+    from parc_amd.anim.motion_lib import MotionLib
+    ml = MotionLib(os.path.join(env._output_motion_dir, files[0]), env._kin_char_model, "cuda:0", contact_info=True)
+    assert ml.num_motions() == 1 and abs(ml._motion_lengths[0].item() - (T - 1) / 30.0) < 1e-5
