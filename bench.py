@@ -91,13 +91,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
-    dev = "cuda:{}".format(local_rank)
+    n_dev = torch.cuda.device_count()
+    dev = "cuda:{}".format(local_rank % max(n_dev, 1))     # (rehearsal on a 1-GPU box: ranks share the device, gloo backend)
     torch.cuda.set_device(dev)
     from parc_amd import _hip, workloads
     from parc_amd.util import mp_util
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world)
+        torch.distributed.init_process_group(os.environ.get("PARC_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     mp_util.init(rank, world, dev)
     torch.manual_seed(0 + 41 * rank)       # run.py:90 of the reference
     np.random.seed(41 * rank)

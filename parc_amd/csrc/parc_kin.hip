@@ -555,25 +555,40 @@ extern "C" int parc_forward_kinematics(void *stream, parc_char_model_t model, in
 }
 
 // =============================================================================================
-// Fused post-physics pass: one 128-thread workgroup per env = 8 pose groups of 16 body lanes
-//   group 0      simulated character  -> char_obs, char_contacts
-//   group 1      reference pose at t  -> ref_* state, reward, done
-//   group 2..7   target poses t+dt_s  -> tar_obs, tar_contacts
-// The observation row (columns [0, obs_dim - P)) is assembled in LDS and written with float4 stores.
+// Fused post-physics pass.  A pose (simulated character, reference at t, 6 targets at t+dt_s) is handled by a
+// 16-lane group, lane b = body b; the observation rows are assembled in LDS and written with float4 stores.
 // =============================================================================================
-#define POST_THREADS 128
+#define POST_EPB 4            // envs per workgroup
+#define POST_MAX_THREADS 512  // 64 * (2 + PARC_MAX_TAR_STEPS)
 #define POST_MAX_ROW 1408
-#define POST_MAX_RAY_PER_THREAD 4
 
-__global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_model_t m, parc_motion_lib_t ml, parc_terrain_t ter,
-                                                                 parc_track_cfg_t cfg, parc_env_buffers_t buf,
-                                                                 const int64_t *__restrict__ env_ids, int what,
-                                                                 const float *__restrict__ ray_xy) {
-    __shared__ __attribute__((aligned(16))) float row[POST_MAX_ROW];
+// Workgroup = POST_EPB envs, one ROLE per wave so no wave diverges:
+//   wave 0      the simulated character of the 4 envs   (4 x 16 body lanes)
+//   wave 1      their reference poses at t              -> ref_* state, reward, done
+//   wave 2..    target poses: group k = (wave-2)*4 + g covers env k / S, step k % S
+// Phase 1 writes the pose-derived columns of the 4 observation rows into LDS, phase 2 (all threads) gathers the
+// 4 x 441 heightmap samples into the same rows, phase 3 streams the rows out as aligned float4.
+__global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_model_t m, parc_motion_lib_t ml, parc_terrain_t ter,
+                                                                     parc_track_cfg_t cfg, parc_env_buffers_t buf,
+                                                                     const int64_t *__restrict__ env_ids, int n_total, int what,
+                                                                     const float *__restrict__ ray_xy) {
+    __shared__ __attribute__((aligned(16))) float rows[POST_EPB][POST_MAX_ROW];
+    __shared__ float hfp[POST_EPB][8];
     const int tid = threadIdx.x;
-    const int g = tid / GRP, b = tid % GRP;
-    const int e = env_ids ? (int)env_ids[blockIdx.x] : (int)blockIdx.x;
+    const int wv = tid >> 6, gg = (tid & 63) >> 4, b = tid & 15;
     const int B = m.num_bodies, J = B - 1, D = m.dof_size, K = cfg.num_key_bodies, S = cfg.num_tar_steps;
+    const bool is_char = wv == 0, is_ref = wv == 1, is_tar = wv >= 2;
+    int le = gg, s_idx = 0;
+    if (is_tar) {
+        int k = (wv - 2) * 4 + gg;
+        le = k / S;
+        s_idx = k - le * S;
+    }
+    const int el = blockIdx.x * POST_EPB + le;
+    const bool live = el < n_total;
+    const int elc = live ? el : n_total - 1;
+    const int e = env_ids ? (int)env_ids[elc] : elc;
+    float *row = rows[le];
     const int Wc = 12 + 6 * J + D + 3 * K;   // char_obs width (136)
     const int Wt = 9 + 6 * J + 3 * K;        // one target step (105)
     const int row_len = cfg.obs_dim - cfg.num_ray_points;  // 871
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_mode
     const float *rs = buf.root_state + (size_t)e * 13;
     const v3 c_pos = ld3(rs);
     const q4 c_rot = ld4(rs + 3);
-    const q4 hinv = calc_heading_quat_inv(c_rot);
+    const q4 hinv = calc_heading_quat_inv_alg(c_rot);
     const int64_t mid = buf.motion_ids[e];
     const float mtime = buf.time_buf[e] + buf.motion_time_offsets[e];   // dm_env.py:597-602
     const float offx = buf.motion_xy_offset[2 * e] - buf.env_offsets[3 * e];          // dm_env.py:604-615
@@ -592,29 +607,11 @@ __global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_mode
     int key_slot = -1;
     for (int k = 0; k < K; ++k)
         if (cfg.key_body_ids[k] == b) key_slot = k;
-
-    // ---- K5 fused (PARC_POST_HF): the 441-point local heightmap goes straight into the LDS row.  The gathers
-    // are issued first so their L2 latency hides under the pose math below.  Same affine cell-unit form as
-    // hf_gather_kernel (RefCharEnv._refresh_ray_obs_hfs mgdm_dm_util.py:158-179, ig_parkour_env.py:636-656).
-    float hfv[POST_MAX_RAY_PER_THREAD];
     const bool do_hf = (what & PARC_POST_HF) != 0;
-    if (do_hf) {
-        hf_env_prm pr = hf_env_params<true>(e, buf.root_state, buf.env_offsets, ter, 1.0f / ter.dx, 1.0f / ter.dy);
-        const float max_i = (float)(ter.dim_x - 1), max_j = (float)(ter.dim_y - 1);
-#pragma unroll
-        for (int i = 0; i < POST_MAX_RAY_PER_THREAD; ++i) {
-            int p = min(tid + i * POST_THREADS, cfg.num_ray_points - 1);
-            float rx = ray_xy[2 * p], ry = ray_xy[2 * p + 1];
-            float ui = fmaf(rx, pr.ax, fmaf(ry, pr.bx, pr.cx));
-            float uj = fmaf(rx, pr.ay, fmaf(ry, pr.by, pr.cy));
-            ui = __builtin_amdgcn_fmed3f(rintf(ui), 0.f, max_i);
-            uj = __builtin_amdgcn_fmed3f(rintf(uj), 0.f, max_j);
-            hfv[i] = __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - pr.gz, cfg.min_obs_h, cfg.max_obs_h);
-        }
-    }
+    // diagnostic role ablations (timing only): bits 16/17/18 drop the target / reference / character waves
+    if (((what & 0x10000) && is_tar) || ((what & 0x20000) && is_ref) || ((what & 0x40000) && is_char)) return;
 
     // ---- phase A: every group gets its pose (root transform + one joint rotation per lane)
-    const bool is_char = g == 0, is_ref = g == 1, is_tar = g >= 2 && g - 2 < S;
     frame_query fq;
     q4 jq = mk4(0.f, 0.f, 0.f, 1.f);
     v3 p_root = c_pos;
@@ -623,7 +620,7 @@ __global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_mode
         if (valid && b > 0) jq = joint_dof_to_rot(m, b, dofs, 2);      // K1 (kin_char_model.py:478-491)
     } else {
         // K3: MotionLib.calc_motion_frame at t (ref) or t + dt_s (targets); dm_env.py:570-582, mgdm_dm_util.py:279-302
-        const float t = mtime + (is_tar ? cfg.tar_dt[g - 2] : 0.f);
+        const float t = mtime + (is_tar ? cfg.tar_dt[s_idx] : 0.f);
         fq = make_query(ml, mid, t);
         if (valid) jq = query_quat(fq, b);
         p_root = query_root_pos(ml, fq, mid);
@@ -649,6 +646,10 @@ __global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_mode
             }
             for (int d = b; d < D; d += GRP) row[12 + 6 * J + d] = dofs[2 * d + 1];
             if (key_slot >= 0) st3(row + 12 + 6 * J + D + 3 * key_slot, quat_rotate(hinv, pos - c_pos));
+            if (b == 0 && do_hf) {
+                hf_env_prm pr = hf_env_params<true>(e, buf.root_state, buf.env_offsets, ter, 1.0f / ter.dx, 1.0f / ter.dy);
+                hfp[le][0] = pr.ax; hfp[le][1] = pr.bx; hfp[le][2] = pr.cx; hfp[le][3] = pr.ay; hfp[le][4] = pr.by; hfp[le][5] = pr.cy; hfp[le][6] = pr.gz;
+            }
             // char contacts  ig_parkour_env.py:841-848
             if (valid) {
                 v3 f = ld3(buf.contact_forces + ((size_t)e * B + b) * 3);
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_mode
             const q4 rq = jq;
             float r_contact = valid ? lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend) : 0.f;
             v3 r_vel = ld3(fq.row0 + ml.off_root_vel), r_avel = ld3(fq.row0 + ml.off_root_ang_vel);
-            if (what & PARC_POST_REF) {
+            if ((what & PARC_POST_REF) && live) {
                 if (b == 0) {
                     st3(buf.ref_root_pos + 3 * (size_t)e, r_pos);
                     st4(buf.ref_root_rot + 4 * (size_t)e, r_rot);
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_mode
                 pose_fail = any16(pose_fail);
                 fall_contact = any16(fall_contact);
                 fall_height = any16(fall_height);
-                if (b == 0) {
+                if (b == 0 && live) {
                     v3 dp = r_pos - c_pos;
                     float root_pos_err = dot3(dp, dp);
                     float rre = quat_diff_angle(c_rot, r_rot);
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_mode
     } else if (is_tar) {
         if (what & PARC_POST_OBS) {
             // DeepMimicEnv.compute_tar_obs + compute_tar_obs  dm_env.py:686-718, mgdm_dm_util.py:462-519
-            const int s = g - 2;
+            const int s = s_idx;
             float *o = row + Wc + s * Wt;
             v3 rpo = quat_rotate(hinv, p_root - c_pos);
             if (b == 0) {
@@ -814,20 +815,35 @@ __global__ __launch_bounds__(POST_THREADS) void track_post_kernel(parc_char_mode
         }
     }
     if (what & PARC_POST_OBS) {
+        __syncthreads();
+        const int nthr = blockDim.x;
         int out_len = row_len;
         if (do_hf) {
-#pragma unroll
-            for (int i = 0; i < POST_MAX_RAY_PER_THREAD; ++i) {
-                int p = tid + i * POST_THREADS;
-                if (p < cfg.num_ray_points) row[row_len + p] = hfv[i];
+            // K5 fused: RefCharEnv._refresh_ray_obs_hfs (mgdm_dm_util.py:158-179) for the 4 envs of this workgroup,
+            // same affine cell-unit form as hf_gather_kernel
+            const int P = cfg.num_ray_points;
+            const float max_i = (float)(ter.dim_x - 1), max_j = (float)(ter.dim_y - 1);
+            for (int idx = tid; idx < POST_EPB * P; idx += nthr) {
+                int l2 = idx / P, p = idx - l2 * P;
+                float rx = ray_xy[2 * p], ry = ray_xy[2 * p + 1];
+                float ui = fmaf(rx, hfp[l2][0], fmaf(ry, hfp[l2][1], hfp[l2][2]));
+                float uj = fmaf(rx, hfp[l2][3], fmaf(ry, hfp[l2][4], hfp[l2][5]));
+                ui = __builtin_amdgcn_fmed3f(rintf(ui), 0.f, max_i);
+                uj = __builtin_amdgcn_fmed3f(rintf(uj), 0.f, max_j);
+                rows[l2][row_len + p] = __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - hfp[l2][6], cfg.min_obs_h, cfg.max_obs_h);
             }
             out_len = cfg.obs_dim;
+            __syncthreads();
         }
-        __syncthreads();
-        float *dst = buf.obs + (size_t)e * cfg.obs_dim;
         const int n4 = out_len >> 2;
-        for (int i = tid; i < n4; i += POST_THREADS) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(row)[i];
-        for (int i = 4 * n4 + tid; i < out_len; i += POST_THREADS) dst[i] = row[i];
+        for (int l2 = 0; l2 < POST_EPB; ++l2) {
+            int el2 = blockIdx.x * POST_EPB + l2;
+            if (el2 >= n_total) break;
+            int e2 = env_ids ? (int)env_ids[el2] : el2;
+            float *dst = buf.obs + (size_t)e2 * cfg.obs_dim;
+            for (int i = tid; i < n4; i += nthr) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(rows[l2])[i];
+            for (int i = 4 * n4 + tid; i < out_len; i += nthr) dst[i] = rows[l2][i];
+        }
     }
 }
 
@@ -840,13 +856,14 @@ extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_
     const int row_len = (12 + 6 * J + D + 3 * K) + S * (9 + 6 * J + 3 * K) + S * B + B;
     if (row_len + cfg.num_ray_points != cfg.obs_dim || cfg.obs_dim > POST_MAX_ROW || (cfg.obs_dim & 3)) return PARC_EINVAL;
     if (what & PARC_POST_HF) {
-        if (!(what & PARC_POST_OBS) || !ray_xy || !terrain.hf || cfg.num_ray_points > POST_MAX_RAY_PER_THREAD * POST_THREADS) return PARC_EINVAL;
+        if (!(what & PARC_POST_OBS) || !ray_xy || !terrain.hf) return PARC_EINVAL;
     }
     if (((uintptr_t)buf.obs & 15) || ((uintptr_t)mlib.frames & 15) || (mlib.row_stride & 3)) return PARC_EINVAL;
     int n = env_ids ? n_sel : buf.num_envs;
     if (n < 0) return PARC_EINVAL;
     if (n == 0) return PARC_OK;
-    hipLaunchKernelGGL(track_post_kernel, dim3(n), dim3(POST_THREADS), 0, (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, what, ray_xy);
+    hipLaunchKernelGGL(track_post_kernel, dim3((n + POST_EPB - 1) / POST_EPB), dim3(64 * (2 + (cfg.num_tar_steps > 0 ? cfg.num_tar_steps : 0))), 0,
+                       (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, n, what, ray_xy);
     PARC_CHECK_LAUNCH();
     return PARC_OK;
 }

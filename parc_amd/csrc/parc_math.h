@@ -71,11 +71,24 @@ PARC_DEV q4 axis_angle_to_quat(v3 axis, float angle) {
     return quat_unit(q);
 }
 
+// sin on [0, pi/2] without range reduction: odd Taylor polynomial through x^13 (truncation < 6e-8 at pi/2);
+// the slerp weights only ever need this interval (half angle in [0, pi/2], blend in [0, 1])
+PARC_DEV float sin_0_halfpi(float x) {
+    float x2 = x * x;
+    float p = fmaf(x2, 1.6059043836821613e-10f, -2.5052108385441720e-08f);
+    p = fmaf(x2, p, 2.7557319223985893e-06f);
+    p = fmaf(x2, p, -1.9841269841269841e-04f);
+    p = fmaf(x2, p, 8.3333333333333333e-03f);
+    p = fmaf(x2, p, -1.6666666666666666e-01f);
+    return fmaf(x * x2, p, x);
+}
+
 // util/torch_util.py:394-419
 PARC_DEV q4 exp_map_to_quat(v3 em) {
     float a = sqrtf(dot3(em, em));
     v3 ax = v3{em.x / a, em.y / a, em.z / a};
-    a = normalize_angle(a);
+    // normalize_angle(a) = atan2(sin a, cos a) is the identity (to 1 ulp) for 0 <= a < pi: skip three transcendentals
+    if (!(a < 3.1415925f)) a = normalize_angle(a);
     bool ok = fabsf(a) > 1e-5f;
     if (!ok) {
         ax = mk3(0.f, 0.f, 1.f);
@@ -122,8 +135,8 @@ PARC_DEV q4 slerp(q4 q0, q4 q1, float t) {
     c = fabsf(c);
     float ht = acosf(c);
     float s = sqrtf(1.0f - c * c);
-    float ra = sinf((1.f - t) * ht) / s;
-    float rb = sinf(t * ht) / s;
+    float ra = sin_0_halfpi((1.f - t) * ht) / s;
+    float rb = sin_0_halfpi(t * ht) / s;
     q4 o = q4{ra * q0.x + rb * q1.x, ra * q0.y + rb * q1.y, ra * q0.z + rb * q1.z, ra * q0.w + rb * q1.w};
     if (fabsf(s) < 0.001f) o = q4{0.5f * q0.x + 0.5f * q1.x, 0.5f * q0.y + 0.5f * q1.y, 0.5f * q0.z + 0.5f * q1.z, 0.5f * q0.w + 0.5f * q1.w};
     if (fabsf(c) >= 1.f) o = q0;
@@ -138,6 +151,26 @@ PARC_DEV float calc_heading(q4 q) {
 
 // util/torch_util.py:491-499
 PARC_DEV q4 calc_heading_quat_inv(q4 q) { return axis_angle_to_quat(mk3(0.f, 0.f, 1.f), -calc_heading(q)); }
+
+// Same rotation without atan2/sin/cos: the heading h has cos h = a/r, sin h = b/r for the rotated x axis (a, b, .);
+// the half-angle values follow from the numerically stable branch of the half-angle formulas.
+PARC_DEV q4 calc_heading_quat_inv_alg(q4 q) {
+    float a = 1.0f - 2.0f * (q.y * q.y + q.z * q.z);
+    float b = 2.0f * (q.w * q.z + q.x * q.y);
+    float r2 = a * a + b * b;
+    if (!(r2 > 0.f)) return mk4(0.f, 0.f, 0.f, 1.f);
+    float ir = rsqrtf(r2);
+    float ch = a * ir, sh = b * ir;
+    float c2, s2;
+    if (ch >= 0.f) {
+        c2 = sqrtf(0.5f * (1.0f + ch));
+        s2 = sh / (2.0f * c2);
+    } else {
+        s2 = (sh >= 0.f ? 1.f : -1.f) * sqrtf(0.5f * (1.0f - ch));
+        c2 = sh / (2.0f * s2);
+    }
+    return mk4(0.f, 0.f, -s2, c2);   // rotation by -h about z
+}
 
 // util/torch_util.py:361-373: 6 floats = R(q) e_x | R(q) e_z
 PARC_DEV void quat_to_tan_norm(q4 q, float *o) {
