@@ -76,8 +76,88 @@ class DeepMimicEnv:
 
     # ------------------------------------------------------------------ terrain (reference :118-126,188-356,493-507)
     def build_terrain(self, env_config, terrain_save_path, x_offset=0.0, y_offset=0.0):
+        if self._terrain_build_mode == "file":
+            return self.load_motion_terrain_file(env_config, terrain_save_path)
+        if self._terrain_build_mode == "wide":
+            return self.build_terrain_wide(env_config, terrain_save_path, x_offset, y_offset)
         if self._terrain_build_mode != "square":
-            raise NotImplementedError("terrain_build_mode '{}' (square tiling is the tracker default)".format(self._terrain_build_mode))
+            raise AssertionError("unsupported terrain build mode")
+        return self.build_terrain_square(env_config, terrain_save_path, x_offset, y_offset)
+
+    def _save_terrain_cache(self, terrain_save_path):
+        if not terrain_save_path:
+            return
+        os.makedirs(os.path.dirname(terrain_save_path) or ".", exist_ok=True)
+        cpu_t = self._terrain.torch_copy()
+        cpu_t.set_device("cpu")
+        with open(terrain_save_path, "wb") as f:
+            pickle.dump({"terrain": cpu_t.numpy_copy(), "terrains_per_motion": self._terrains_per_motion,
+                         "motion_offsets": self._dm_motion_offsets.cpu().numpy(), "all_terrain_verts": [], "all_terrain_tris": []}, f)
+
+    def load_motion_terrain_file(self, env_config, terrain_save_path):
+        """terrain_build_mode "file" (reference :128-186): ONE shared terrain named by the motion YAML's `terrain:` key,
+        per-clip offsets from the clips' optional `min_point_offset`."""
+        import yaml
+        from ...util import safe_pickle
+        with open(env_config["dm"]["motion_file"], "r") as f:
+            my = yaml.safe_load(f)
+        loader = (lambda p: pickle.load(open(p, "rb"))) if env_config["dm"].get("unsafe_pickle", False) else safe_pickle.load_motion_file_safe
+        t = loader(my["terrain"])["terrain"]
+        if isinstance(t, dict):
+            t = terrain_util.SubTerrain.from_arrays(t["hf"], t["min_point"], t["dxdy"], t.get("hf_mask"), t.get("hf_maxmin"), device=self._device)
+        else:
+            t.to_torch(self._device)
+        self._terrain = t
+        self._terrains_per_motion = 1
+        offs = []
+        for elem in my["motions"]:
+            d = loader(elem["file"])
+            mpo = d.get("min_point_offset") if hasattr(d, "get") else None
+            offs.append(np.zeros(2, np.float32) if mpo is None or isinstance(mpo, safe_pickle.Unresolved) else np.asarray(mpo, np.float32).reshape(2))
+        self._dm_motion_offsets = torch.tensor(np.stack(offs), dtype=torch.float32, device=self._device).unsqueeze(1)
+        self._save_terrain_cache(terrain_save_path)
+        return [], []
+
+    def build_terrain_wide(self, env_config, terrain_save_path, x_offset=0.0, y_offset=0.0):
+        """terrain_build_mode "wide" (reference :362-491): clips side by side along x, `terrains_per_motion` copies along y,
+        `padding` metres between neighbours."""
+        hm = env_config["dm"]["heightmap"]
+        dx = float(hm["horizontal_scale"])
+        padding = float(hm["padding"])
+        npad = int(round(padding / dx))
+        ters = self._motion_lib._terrains
+        M, R = self._motion_lib.num_motions(), self._terrains_per_motion
+        offsets = torch.zeros((M, R, 2), dtype=torch.float32, device=self._device)
+        gmin = np.zeros(2)
+        gmax = np.zeros(2)
+        xo = x_offset
+        for i in range(M):
+            t = ters[i]
+            yo = y_offset
+            for j in range(R):
+                offsets[i, j, 0] = xo - t.min_point[0]
+                offsets[i, j, 1] = yo - t.min_point[1]
+                gmin = np.minimum(gmin, [xo, yo])
+                gmax = np.maximum(gmax, [xo + t.dims[0].item() * dx, yo + t.dims[1].item() * dx])
+                yo += dx * t.dims[1].item() + padding * 2.0
+            xo += dx * t.dims[0].item() + padding * 2.0
+        dims = np.round((gmax - gmin) / dx).astype(int)
+        glob = terrain_util.SubTerrain("heightmap", int(dims[0]), int(dims[1]), dx, dx, float(gmin[0]), float(gmin[1]), device=self._device)
+        sx = 0
+        for i in range(M):
+            t = ters[i]
+            sy = 0
+            for j in range(R):
+                glob.hf[sx:sx + t.dims[0], sy:sy + t.dims[1]] = t.hf
+                glob.hf_mask[sx:sx + t.dims[0], sy:sy + t.dims[1]] = t.hf_mask
+                sy += int(t.dims[1].item()) + 2 * npad
+            sx += int(t.dims[0].item()) + 2 * npad
+        self._terrain = glob
+        self._dm_motion_offsets = offsets
+        self._save_terrain_cache(terrain_save_path)
+        return [], []
+
+    def build_terrain_square(self, env_config, terrain_save_path, x_offset=0.0, y_offset=0.0):
         hm = env_config["dm"]["heightmap"]
         dx = float(hm["horizontal_scale"])
         npad = hm["padding"] / dx
@@ -110,13 +190,7 @@ class DeepMimicEnv:
                 k += 1
         self._terrain = glob
         self._dm_motion_offsets = offsets
-        if terrain_save_path:
-            os.makedirs(os.path.dirname(terrain_save_path) or ".", exist_ok=True)
-            cpu_t = glob.torch_copy()
-            cpu_t.set_device("cpu")
-            with open(terrain_save_path, "wb") as f:
-                pickle.dump({"terrain": cpu_t.numpy_copy(), "terrains_per_motion": self._terrains_per_motion,
-                             "motion_offsets": offsets.cpu().numpy(), "all_terrain_verts": [], "all_terrain_tris": []}, f)
+        self._save_terrain_cache(terrain_save_path)
         return [], []
 
     def load_terrain(self, terrain_save_path):

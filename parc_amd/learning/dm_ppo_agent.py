@@ -22,6 +22,7 @@ from ..util import mp_util
 from ..util.logger import Logger
 from . import dm_ppo_model, experience_buffer, mp_optimizer, normalizer, rl_util
 from .dm_ppo_return_tracker import DMPPOReturnTracker
+from .tracking_error_tracker import TrackingErrorTracker
 
 
 class AgentMode(enum.Enum):
@@ -57,6 +58,8 @@ class DMPPOAgent(torch.nn.Module):
         self._curr_obs = None
         self._curr_info = None
         self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self._device)
+        if getattr(self._env, "_report_tracking_error", False):
+            self._test_tracking_error_tracker = TrackingErrorTracker(self.get_num_envs(), self._device)
 
     # ------------------------------------------------------------------ config (base_agent.py:170-182, ppo_agent.py:21-51)
     def _load_params(self, config):
@@ -233,6 +236,9 @@ class DMPPOAgent(torch.nn.Module):
 
     def _rollout_test(self, num_episodes):
         self._test_return_tracker.reset()
+        report_te = getattr(self._env, "_report_tracking_error", False)
+        if report_te:
+            self._test_tracking_error_tracker.reset()
         if num_episodes == 0:
             return {"mean_return": 0.0, "mean_ep_len": 0.0, "num_eps": 0}
         min_eps_per_env = int(np.ceil(num_episodes / self.get_num_envs()))
@@ -240,12 +246,24 @@ class DMPPOAgent(torch.nn.Module):
             action, _ = self._decide_action(self._curr_obs, self._curr_info)
             _, _, done, next_info = self._env.step(action)
             self._test_return_tracker.update(next_info, done)
+            if report_te and "tracking_error" in next_info:
+                self._test_tracking_error_tracker.update(next_info["tracking_error"], done)
             self._curr_obs, self._curr_info = self._reset_done_envs(done)
             if torch.all(self._test_return_tracker.get_eps_per_env() > min_eps_per_env - 1):
                 break
-        return {"mean_return": self._test_return_tracker.get_mean_return().item(),
-                "mean_ep_len": self._test_return_tracker.get_mean_ep_len().item(),
-                "num_eps": self._test_return_tracker.get_episodes()}
+        out = {"mean_return": self._test_return_tracker.get_mean_return().item(),
+               "mean_ep_len": self._test_return_tracker.get_mean_ep_len().item(),
+               "num_eps": self._test_return_tracker.get_episodes()}
+        if report_te:
+            t = self._test_tracking_error_tracker
+            out.update({"test_mean_root_pos_tracking_err": t.get_mean_root_pos_err().item(),
+                        "test_mean_root_rot_tracking_err": t.get_mean_root_rot_err().item(),
+                        "test_mean_body_pos_tracking_err": t.get_mean_body_pos_err().item(),
+                        "test_mean_body_rot_tracking_err": t.get_mean_body_rot_err().item(),
+                        "test_mean_dof_vel_tracking_err": t.get_mean_dof_vel_err().item(),
+                        "test_mean_root_vel_tracking_err": t.get_mean_root_vel_err().item(),
+                        "test_mean_root_ang_vel_tracking_err": t.get_mean_root_ang_vel_err().item()})
+        return out
 
     def hard_reset_envs(self):
         if self._is_terrain_runner:
@@ -437,8 +455,10 @@ class DMPPOAgent(torch.nn.Module):
 
     # ------------------------------------------------------------------ motion recording (dm_ppo_agent.py:414-533)
     def record_motions(self, max_steps=None):
-        """Deterministic rollout of every env on its own clip from t=0; clips tracked to the end are written to the env's
-        output_motion_dir.  Returns the list of per-env success flags."""
+        """Deterministic rollout of every env on its own clip (demo mode: clip id = env id mod M) from t=0; clips
+        tracked to their end are written to the env's output_motion_dir.  Clips that failed are retried from start
+        fractions 0.1 .. 0.5 (shorter than 2 s remaining: skipped), like the reference.  Returns the success flags
+        (the reference prints the statistics and calls exit())."""
         self.eval()
         self.set_mode(AgentMode.TEST)
         env = self._env
@@ -447,11 +467,38 @@ class DMPPOAgent(torch.nn.Module):
         env.set_rand_root_pos_offset_scale(0.0)
         env._episode_length = 1000.0
         env._cfg.struct.episode_length = 1000.0
-        env.build_agent_states_dict(name_suffix="_dm", record_obs=True)
-        self._curr_obs, self._curr_info = env.reset()
-        steps = 0
-        while env.is_writing_agent_states() and (max_steps is None or steps < max_steps):
-            action, _ = self._decide_action(self._curr_obs, self._curr_info)
-            self._curr_obs, _, _, self._curr_info = env.step(action)
-            steps += 1
-        return env.get_env_success_states()
+        N = self.get_num_envs()
+
+        def helper(prev_successful=None):
+            self._curr_obs, self._curr_info = env.reset()
+            env.build_agent_states_dict("_dm", record_obs=True)
+            env.write_agent_states()
+            if prev_successful is not None:
+                for e in range(N):
+                    env.set_writing_env_state(e, not prev_successful[e])
+            steps = 0
+            while env.is_writing_agent_states() and (max_steps is None or steps < max_steps):
+                action, _ = self._decide_action(self._curr_obs, self._curr_info)
+                _, _, done, _ = self._env.step(action)
+                self._curr_obs, self._curr_info = self._reset_done_envs(done)
+                steps += 1
+
+        helper()
+        successful = list(env.get_env_success_states())
+        counts = [sum(successful)]
+        dm = env.get_dm_env()
+        for frac in [0.1, 0.2, 0.3, 0.4, 0.5]:
+            if all(successful):
+                break
+            for e in range(N):
+                mid = e % dm._motion_lib.num_motions()
+                if (1.0 - frac) * dm._motion_lib._motion_lengths[mid].item() < 2.0:
+                    successful[e] = True
+            dm.set_motion_start_time_fraction(torch.full([N], frac, dtype=torch.float32, device=self._device))
+            helper(prev_successful=successful)
+            new = list(env.get_env_success_states())
+            counts.append(sum(new))
+            successful = [a or b for a, b in zip(successful, new)]
+        Logger.print("Successful motions at 0 percent start time: {} / {}".format(counts[0], N))
+        Logger.print("Total successful motions: {}".format(sum(counts)))
+        return successful

@@ -109,3 +109,65 @@ def test_safe_motion_reader_roundtrip(tmp_path):
     out = safe_pickle.load_motion_file_safe(str(q))
     assert isinstance(out["frames"], safe_pickle.Unresolved)
     assert not os.path.exists("/tmp/parc_pwned")
+
+
+def _dm_env_cpu(mode, tmp_path, n_clips=3, R=1):
+    """DeepMimicEnv on CPU with synthetic clips + terrains (terrain tiling is host logic, no kernels)."""
+    import types
+    from parc_amd.envs.ig_parkour import dm_env
+    from parc_amd.util import terrain_util
+    rng = np.random.default_rng(3)
+    ters = []
+    for k in range(n_clips):
+        nx, ny = 12 + 2 * k, 10 + k
+        ters.append(terrain_util.SubTerrain.from_arrays(rng.integers(0, 3, (nx, ny)).astype(np.float32) * 0.3,
+                                                         np.array([-1.0 - k, 0.5 * k], np.float32), np.array([0.4, 0.4], np.float32)))
+    e = dm_env.DeepMimicEnv.__new__(dm_env.DeepMimicEnv)
+    e._device = "cpu"
+    e._terrain_build_mode = mode
+    e._terrains_per_motion = R
+    e._motion_lib = types.SimpleNamespace(_terrains=ters, num_motions=lambda: n_clips)
+    return e, ters
+
+
+def test_terrain_build_wide_places_every_clip_terrain(tmp_path):
+    e, ters = _dm_env_cpu("wide", tmp_path, R=2)
+    cfg = {"dm": {"heightmap": {"horizontal_scale": 0.4, "padding": 0.8}}}
+    e.build_terrain(cfg, str(tmp_path / "t.pkl"))
+    g = e._terrain
+    assert e._dm_motion_offsets.shape == (3, 2, 2)
+    for k, t in enumerate(ters):
+        for j in range(2):
+            # a clip-frame point + the offset lands on the same height in the global field
+            p = t.min_point + e._dm_motion_offsets[k, j]
+            ij = torch.round((p - g.min_point) / g.dxdy).long()
+            sub = g.hf[ij[0]:ij[0] + t.hf.shape[0], ij[1]:ij[1] + t.hf.shape[1]]
+            assert torch.equal(sub, t.hf)
+    # the cache written next to it reloads through the non-executing reader
+    e2, _ = _dm_env_cpu("wide", tmp_path)
+    e2.load_terrain(str(tmp_path / "t.pkl"))
+    assert torch.equal(e2._terrain.hf, g.hf) and torch.equal(e2._dm_motion_offsets, e._dm_motion_offsets)
+    assert e2._terrains_per_motion == 2
+
+
+def test_terrain_build_file_mode(tmp_path):
+    import yaml
+    from parc_amd.util import terrain_util
+    e, ters = _dm_env_cpu("file", tmp_path, n_clips=2)
+    big = terrain_util.SubTerrain.from_arrays(np.arange(80, dtype=np.float32).reshape(8, 10), np.array([-2.0, -3.0], np.float32),
+                                              np.array([0.4, 0.4], np.float32))
+    with open(tmp_path / "ter.pkl", "wb") as f:
+        pickle.dump({"terrain": big.numpy_copy()}, f)
+    for k, off in enumerate([None, np.array([1.2, -0.4], np.float32)]):
+        d = {"fps": 30, "loop_mode": "CLAMP", "frames": np.zeros((4, 34), np.float32)}
+        if off is not None:
+            d["min_point_offset"] = off
+        with open(tmp_path / "m{}.pkl".format(k), "wb") as f:
+            pickle.dump(d, f)
+    with open(tmp_path / "motions.yaml", "w") as f:
+        yaml.safe_dump({"terrain": str(tmp_path / "ter.pkl"),
+                        "motions": [{"file": str(tmp_path / "m0.pkl"), "weight": 1.0}, {"file": str(tmp_path / "m1.pkl"), "weight": 1.0}]}, f)
+    e.build_terrain({"dm": {"motion_file": str(tmp_path / "motions.yaml")}}, None)
+    assert e._terrains_per_motion == 1
+    np.testing.assert_array_equal(e._terrain.hf.numpy(), big.hf.numpy())
+    np.testing.assert_allclose(e._dm_motion_offsets.numpy(), np.array([[[0, 0]], [[1.2, -0.4]]], np.float32))
