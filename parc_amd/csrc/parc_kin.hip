@@ -279,13 +279,17 @@ PARC_DEV int any16(int v) {
 }
 
 // anim/kin_char_model.py:57-77: one joint's dofs -> quaternion (lane b >= 1)
+template <bool LIB = false>
 PARC_DEV q4 joint_dof_to_rot(const parc_char_model_t &m, int b, const float *dof, int stride) {
     int jt = m.joint_type[b];
     if (jt == PARC_JOINT_HINGE) {
-        return axis_angle_to_quat(mk3(m.joint_axis[b][0], m.joint_axis[b][1], m.joint_axis[b][2]), dof[m.dof_idx[b] * stride]);
+        v3 ax = mk3(m.joint_axis[b][0], m.joint_axis[b][1], m.joint_axis[b][2]);
+        float an = dof[m.dof_idx[b] * stride];
+        return LIB ? axis_angle_to_quat_lib(ax, an) : axis_angle_to_quat(ax, an);
     } else if (jt == PARC_JOINT_SPHERICAL) {
         int d = m.dof_idx[b];
-        return exp_map_to_quat(mk3(dof[d * stride], dof[(d + 1) * stride], dof[(d + 2) * stride]));
+        v3 em = mk3(dof[d * stride], dof[(d + 1) * stride], dof[(d + 2) * stride]);
+        return LIB ? exp_map_to_quat_lib(em) : exp_map_to_quat(em);
     }
     return mk4(0.f, 0.f, 0.f, 1.f);
 }
@@ -432,10 +436,10 @@ __global__ __launch_bounds__(256) void motion_rows_kernel(parc_char_model_t m, p
     float *row = rows + (size_t)f * ml.row_stride;
     q4 q;
     if (b == 0) {
-        q = exp_map_to_quat(mk3(fr[3], fr[4], fr[5]));            // motion_lib.py:418
+        q = exp_map_to_quat_lib(mk3(fr[3], fr[4], fr[5]));        // motion_lib.py:418
         st3(row + ml.off_pos, ld3(fr));
     } else {
-        q = quat_pos(joint_dof_to_rot(m, b, fr + 6, 1));           // motion_lib.py:420-421
+        q = quat_pos(joint_dof_to_rot<true>(m, b, fr + 6, 1));     // motion_lib.py:420-421
     }
     st4(row + 4 * b, q);
     row[ml.off_contacts + b] = contacts ? contacts[(size_t)f * m.num_bodies + b] : 0.f;
@@ -629,6 +633,9 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
         r_root = shfl16(jq, 0);
     }
     // ---- phase B: K2 forward kinematics, level-synchronous inside the 16-lane group
+    // (kept in the reference's composition order root -> leaf: slerp between nearly identical frames returns slightly
+    // non-unit quaternions, for which the rotation formula is not associative, so a reassociated tree walk - e.g. pointer
+    // doubling in the root frame - drifts ~1e-4 from the reference's body positions)
     v3 pos;
     q4 rot;
     group_fk(m, b, p_root, r_root, jq, pos, rot);
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
             // char contacts  ig_parkour_env.py:841-848
             if (valid) {
                 v3 f = ld3(buf.contact_forces + ((size_t)e * B + b) * 3);
-                row[Wc + S * Wt + S * B + b] = sqrtf(dot3(f, f)) > cfg.contact_eps ? 1.f : 0.f;
+                row[Wc + S * Wt + S * B + b] = fsqrt(dot3(f, f)) > cfg.contact_eps ? 1.f : 0.f;
             }
         }
     } else if (is_ref) {
@@ -703,7 +710,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
                 if (valid) {
                     // compute_contact_reward  mgdm_dm_util.py:555-576
                     v3 f = ld3(buf.contact_forces + ((size_t)e * B + b) * 3);
-                    float fn = fminf(sqrtf(dot3(f, f)), 1.0f);
+                    float fn = fminf(fsqrt(dot3(f, f)), 1.0f);
                     float cr = -(1.0f - r_contact) * fn;
                     cr += r_contact * fn;
                     cpen = cfg.contact_w[b] * cr;
@@ -732,11 +739,11 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
                     float rre = quat_diff_angle(c_rot, r_rot);
                     float rre2 = rre * rre;
                     v3 dv = r_vel - ld3(rs + 7), dw = r_avel - ld3(rs + 10);
-                    float pose_r = expf(-0.25f * pose_e);
-                    float vel_r = expf(-0.01f * vel_e);
-                    float root_pose_r = expf(-5.0f * (root_pos_err + 0.1f * rre2));
-                    float root_vel_r = expf(-1.0f * (dot3(dv, dv) + 0.1f * dot3(dw, dw)));
-                    float key_r = expf(-10.0f * key_e);
+                    float pose_r = fexp(-0.25f * pose_e);
+                    float vel_r = fexp(-0.01f * vel_e);
+                    float root_pose_r = fexp(-5.0f * (root_pos_err + 0.1f * rre2));
+                    float root_vel_r = fexp(-1.0f * (dot3(dv, dv) + 0.1f * dot3(dw, dw)));
+                    float key_r = fexp(-10.0f * key_e);
                     float cp = cpen / (float)B;
                     // ig_parkour_env.py:1317-1339,1404
                     float dm = cfg.reward_w[0] * pose_r + cfg.reward_w[1] * vel_r + cfg.reward_w[2] * root_pose_r +
@@ -754,14 +761,19 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
                         // task terms  ig_parkour_env.py:1346-1393 (logged; they scale the reward only if rel_task_w > 0)
                         float tx = buf.target_xy[2 * e] - c_pos.x, ty = buf.target_xy[2 * e + 1] - c_pos.y;
                         float terr = tx * tx + ty * ty;
-                        float task_r1 = expf(-0.075f * terr);
-                        float tl = sqrtf(terr);
-                        float dxn = tl > 0.01f ? tx / tl : 0.f, dyn = tl > 0.01f ? ty / tl : 0.f;
+                        float task_r1 = fexp(-0.075f * terr);
+                        float tl = fsqrt(terr);
+                        float itl = frcp(tl);
+                        float dxn = tl > 0.01f ? tx * itl : 0.f, dyn = tl > 0.01f ? ty * itl : 0.f;
                         float mve = fmaxf(2.0f - (dxn * rs[7] + dyn * rs[8]), 0.f);
-                        float min_vel_r = expf(-(mve * mve));
-                        float hd = calc_heading(c_rot);
-                        float he = fmaxf(1.0f - (dxn * cosf(hd) + dyn * sinf(hd)), 0.f);
-                        float task2 = min_vel_r * expf(-(he * he));
+                        float min_vel_r = fexp(-(mve * mve));
+                        // heading direction (cos h, sin h) = normalised xy of the rotated x axis
+                        float ha = 1.0f - 2.0f * (c_rot.y * c_rot.y + c_rot.z * c_rot.z), hb = 2.0f * (c_rot.w * c_rot.z + c_rot.x * c_rot.y);
+                        float hn2 = ha * ha + hb * hb;
+                        float hir = __builtin_amdgcn_rsqf(hn2);
+                        float chd = hn2 > 0.f ? ha * hir : 1.0f, shd = hn2 > 0.f ? hb * hir : 0.0f;
+                        float he = fmaxf(1.0f - (dxn * chd + dyn * shd), 0.f);
+                        float task2 = min_vel_r * fexp(-(he * he));
                         float task_r = cfg.task1_w * task_r1 + cfg.task2_w * task2;
                         if (terr < cfg.target_radius * cfg.target_radius) task_r = 1.0f;
                         buf.reward_terms[6 * (size_t)N + e] = task_r1;
@@ -823,14 +835,15 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
             // same affine cell-unit form as hf_gather_kernel
             const int P = cfg.num_ray_points;
             const float max_i = (float)(ter.dim_x - 1), max_j = (float)(ter.dim_y - 1);
-            for (int idx = tid; idx < POST_EPB * P; idx += nthr) {
-                int l2 = idx / P, p = idx - l2 * P;
+            const int tpe = nthr / POST_EPB, l2 = tid / tpe;       // blockDim = 64*(2+S): a multiple of POST_EPB
+            const float h0 = hfp[l2][0], h1 = hfp[l2][1], h2 = hfp[l2][2], h3 = hfp[l2][3], h4 = hfp[l2][4], h5 = hfp[l2][5], h6 = hfp[l2][6];
+            for (int p = tid - l2 * tpe; p < P; p += tpe) {
                 float rx = ray_xy[2 * p], ry = ray_xy[2 * p + 1];
-                float ui = fmaf(rx, hfp[l2][0], fmaf(ry, hfp[l2][1], hfp[l2][2]));
-                float uj = fmaf(rx, hfp[l2][3], fmaf(ry, hfp[l2][4], hfp[l2][5]));
+                float ui = fmaf(rx, h0, fmaf(ry, h1, h2));
+                float uj = fmaf(rx, h3, fmaf(ry, h4, h5));
                 ui = __builtin_amdgcn_fmed3f(rintf(ui), 0.f, max_i);
                 uj = __builtin_amdgcn_fmed3f(rintf(uj), 0.f, max_j);
-                rows[l2][row_len + p] = __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - hfp[l2][6], cfg.min_obs_h, cfg.max_obs_h);
+                rows[l2][row_len + p] = __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - h6, cfg.min_obs_h, cfg.max_obs_h);
             }
             out_len = cfg.obs_dim;
             __syncthreads();

@@ -13,7 +13,13 @@ DEV = "cuda:0"
 
 def close(a, b, atol=2e-5, rtol=1e-5):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
-    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+    bad = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)) > atol + rtol * np.abs(np.asarray(b, np.float64))
+    if bad.any():
+        idx = np.argwhere(bad)
+        last = np.unique(idx[:, -1])
+        raise AssertionError("{} of {} differ (atol {}, rtol {}); max |d| {:.3e}; trailing indices {}; first {}".format(
+            int(bad.sum()), bad.size, atol, rtol, float(np.abs(np.asarray(a, np.float64) - b)[bad].max()), last[:40].tolist(),
+            [(tuple(i), float(np.asarray(a)[tuple(i)]), float(np.asarray(b)[tuple(i)])) for i in idx[:6]]))
 
 
 def T(x, dtype=torch.float32):

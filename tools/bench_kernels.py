@@ -125,7 +125,7 @@ def bench_post_step(n, iters):
     full = _hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF
     us_fused = time_loop(lambda: core.post_step(full), iters)
     us_nohf = time_loop(lambda: core.post_step(full & ~_hip.POST_HF), iters)
-    for name, bits in (("no_tar", 0x10000), ("no_ref", 0x20000), ("no_char", 0x40000), ("only_char", 0x30000), ("only_ref", 0x50000), ("only_tar", 0x60000), ("none", 0x70000)):
+    for name, bits in () if "--plain" in sys.argv else (("no_tar", 0x10000), ("no_ref", 0x20000), ("no_char", 0x40000), ("only_char", 0x30000), ("only_ref", 0x50000), ("only_tar", 0x60000), ("none", 0x70000)):
         print(json.dumps({"ablation": name, "us": time_loop(lambda: core.post_step(full | bits), iters)}))
     # algorithmic bytes per env: K5 3544 + K3 7*760 + state 456 + obs cols [0,871) 3484 + bodies 780 + 8 out
     alg = n * (3544 + 7 * 760 + 456 + 3484 + 780 + 8)
@@ -136,7 +136,6 @@ def bench_post_step(n, iters):
 
 if __name__ == "__main__":
     if "--post" in sys.argv:
-        sys.argv.remove("--post")
         bench_post_step(4096, 300)
         sys.exit(0)
     main()
