@@ -340,7 +340,7 @@ PARC_DEV void group_fk(const parc_char_model_t &m, int b, v3 root_pos, q4 root_r
 struct frame_query {
     const float *row0, *row1;
     float blend, loop_phase;
-    int wrap;
+    int wrap, idx0, idx1;     // idx = absolute frame row
 };
 
 // anim/motion_lib.py:443-456,527-538 (+ :458-475 loop offset)
@@ -358,8 +358,10 @@ PARC_DEV frame_query make_query(const parc_motion_lib_t &ml, int64_t id, float t
     int i1 = min(i0 + 1, nf - 1);
     fq.blend = fp - (float)i0;
     int st = ml.start_idx[id];
-    fq.row0 = ml.frames + (size_t)(st + i0) * ml.row_stride;
-    fq.row1 = ml.frames + (size_t)(st + i1) * ml.row_stride;
+    fq.idx0 = st + i0;
+    fq.idx1 = st + i1;
+    fq.row0 = ml.frames + (size_t)fq.idx0 * ml.row_stride;
+    fq.row1 = ml.frames + (size_t)fq.idx1 * ml.row_stride;
     return fq;
 }
 
@@ -565,6 +567,9 @@ extern "C" int parc_forward_kinematics(void *stream, parc_char_model_t model, in
 #define POST_EPB 4            // envs per workgroup
 #define POST_MAX_THREADS 512  // 64 * (2 + PARC_MAX_TAR_STEPS)
 #define POST_MAX_ROW 1408
+#ifndef POST_MIN_WAVES
+#define POST_MIN_WAVES 5   // register budget 102/lane; forcing 8 (64 VGPRs, one resident round for 4096 envs) spills 22 registers and measured 33 us vs 27 us
+#endif
 
 // Workgroup = POST_EPB envs, one ROLE per wave so no wave diverges:
 //   wave 0      the simulated character of the 4 envs   (4 x 16 body lanes)
@@ -572,48 +577,72 @@ extern "C" int parc_forward_kinematics(void *stream, parc_char_model_t model, in
 //   wave 2..    target poses: group k = (wave-2)*4 + g covers env k / S, step k % S
 // Phase 1 writes the pose-derived columns of the 4 observation rows into LDS, phase 2 (all threads) gathers the
 // 4 x 441 heightmap samples into the same rows, phase 3 streams the rows out as aligned float4.
-__global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_model_t m, parc_motion_lib_t ml, parc_terrain_t ter,
+__global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_kernel(parc_char_model_t m, parc_motion_lib_t ml, parc_terrain_t ter,
                                                                      parc_track_cfg_t cfg, parc_env_buffers_t buf,
                                                                      const int64_t *__restrict__ env_ids, int n_total, int what,
                                                                      const float *__restrict__ ray_xy) {
-    __shared__ __attribute__((aligned(16))) float rows[POST_EPB][POST_MAX_ROW];
+    __shared__ __attribute__((aligned(16))) float rows[POST_EPB * POST_MAX_ROW];   // 4 rows at stride obs_dim (contiguous, like the 4 output rows)
     __shared__ float hfp[POST_EPB][8];
+    __shared__ __attribute__((aligned(16))) float envd[POST_EPB][12];                            // root pos 3 | root rot 4 | heading^-1 4 | env id
+    __shared__ __attribute__((aligned(16))) float qryd[1 + PARC_MAX_TAR_STEPS][POST_EPB][8];    // frame idx0, idx1, blend, root xyz
     const int tid = threadIdx.x;
     const int wv = tid >> 6, gg = (tid & 63) >> 4, b = tid & 15;
     const int B = m.num_bodies, J = B - 1, D = m.dof_size, K = cfg.num_key_bodies, S = cfg.num_tar_steps;
     const bool is_char = wv == 0, is_ref = wv == 1, is_tar = wv >= 2;
-    int le = gg, s_idx = 0;
-    if (is_tar) {
-        int k = (wv - 2) * 4 + gg;
-        le = k / S;
-        s_idx = k - le * S;
-    }
+    const int le = gg, s_idx = is_tar ? wv - 2 : 0;     // a target wave = one target step of the 4 envs
     const int el = blockIdx.x * POST_EPB + le;
     const bool live = el < n_total;
-    const int elc = live ? el : n_total - 1;
-    const int e = env_ids ? (int)env_ids[elc] : elc;
-    float *row = rows[le];
+    const int RS = cfg.obs_dim;
+    float *row = rows + le * RS;
     const int Wc = 12 + 6 * J + D + 3 * K;   // char_obs width (136)
     const int Wt = 9 + 6 * J + 3 * K;        // one target step (105)
     const int row_len = cfg.obs_dim - cfg.num_ray_points;  // 871
     const bool valid = b < B;
+    const bool do_hf = (what & PARC_POST_HF) != 0;
 
-    const float *rs = buf.root_state + (size_t)e * 13;
-    const v3 c_pos = ld3(rs);
-    const q4 c_rot = ld4(rs + 3);
-    const q4 hinv = calc_heading_quat_inv_alg(c_rot);
-    const int64_t mid = buf.motion_ids[e];
-    const float mtime = buf.time_buf[e] + buf.motion_time_offsets[e];   // dm_env.py:597-602
-    const float offx = buf.motion_xy_offset[2 * e] - buf.env_offsets[3 * e];          // dm_env.py:604-615
-    const float offy = buf.motion_xy_offset[2 * e + 1] - buf.env_offsets[3 * e + 1];
-    const float *dofs = buf.dof_state + (size_t)e * D * 2;  // interleaved pos,vel
-
+    // ---- phase 0 (wave 0): the per-env and per-query scalars, ONE lane each instead of once per 16-lane group in
+    // every wave: lane l -> env l & 3, query l >> 2 (0 = reference at t, s + 1 = target step s)
+    if (wv == 0 && tid < POST_EPB * (1 + S)) {
+        const int ple = tid & (POST_EPB - 1), pq = tid >> 2;
+        const int pel = min((int)blockIdx.x * POST_EPB + ple, n_total - 1);
+        const int pe = env_ids ? (int)env_ids[pel] : pel;
+        const int64_t mid = buf.motion_ids[pe];
+        const float mtime = buf.time_buf[pe] + buf.motion_time_offsets[pe];   // dm_env.py:597-602
+        if (pq == 0) {
+            const float *prs = buf.root_state + (size_t)pe * 13;
+            const q4 cr = ld4(prs + 3);
+            const q4 hi = calc_heading_quat_inv_alg(cr);
+            float4 *ed = reinterpret_cast<float4 *>(envd[ple]);
+            ed[0] = make_float4(prs[0], prs[1], prs[2], cr.x);
+            ed[1] = make_float4(cr.y, cr.z, cr.w, hi.x);
+            ed[2] = make_float4(hi.y, hi.z, hi.w, __int_as_float(pe));
+        }
+        // K3 index part: MotionLib.calc_motion_frame at t (ref) or t + dt_s (targets); dm_env.py:570-582, mgdm_dm_util.py:279-302
+        const float t = mtime + (pq > 0 ? cfg.tar_dt[pq - 1] : 0.f);
+        const frame_query fq = make_query(ml, mid, t);
+        v3 pr = query_root_pos(ml, fq, mid);
+        pr.x += buf.motion_xy_offset[2 * pe] - buf.env_offsets[3 * pe];              // _move_to_motion_terrain dm_env.py:604-615
+        pr.y += buf.motion_xy_offset[2 * pe + 1] - buf.env_offsets[3 * pe + 1];
+        float4 *qd = reinterpret_cast<float4 *>(qryd[pq][ple]);
+        qd[0] = make_float4(__int_as_float(fq.idx0), __int_as_float(fq.idx1), fq.blend, pr.x);
+        qd[1] = make_float4(pr.y, pr.z, 0.f, 0.f);
+    }
+    // loads that do not depend on phase 0
     int key_slot = -1;
     for (int k = 0; k < K; ++k)
         if (cfg.key_body_ids[k] == b) key_slot = k;
-    const bool do_hf = (what & PARC_POST_HF) != 0;
+    __syncthreads();
     // diagnostic role ablations (timing only): bits 16/17/18 drop the target / reference / character waves
     if (((what & 0x10000) && is_tar) || ((what & 0x20000) && is_ref) || ((what & 0x40000) && is_char)) return;
+
+    const float4 e0 = reinterpret_cast<const float4 *>(envd[le])[0], e1 = reinterpret_cast<const float4 *>(envd[le])[1],
+                 e2 = reinterpret_cast<const float4 *>(envd[le])[2];
+    const v3 c_pos = mk3(e0.x, e0.y, e0.z);
+    const q4 c_rot = mk4(e0.w, e1.x, e1.y, e1.z);
+    const q4 hinv = mk4(e1.w, e2.x, e2.y, e2.z);
+    const int e = __float_as_int(e2.w);
+    const float *rs = buf.root_state + (size_t)e * 13;
+    const float *dofs = buf.dof_state + (size_t)e * D * 2;  // interleaved pos,vel
 
     // ---- phase A: every group gets its pose (root transform + one joint rotation per lane)
     frame_query fq;
@@ -623,13 +652,15 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
     if (is_char) {
         if (valid && b > 0) jq = joint_dof_to_rot(m, b, dofs, 2);      // K1 (kin_char_model.py:478-491)
     } else {
-        // K3: MotionLib.calc_motion_frame at t (ref) or t + dt_s (targets); dm_env.py:570-582, mgdm_dm_util.py:279-302
-        const float t = mtime + (is_tar ? cfg.tar_dt[s_idx] : 0.f);
-        fq = make_query(ml, mid, t);
+        const float4 q0 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[0];
+        const float4 q1 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[1];
+        fq.idx0 = __float_as_int(q0.x);
+        fq.idx1 = __float_as_int(q0.y);
+        fq.blend = q0.z;
+        fq.row0 = ml.frames + (size_t)fq.idx0 * ml.row_stride;
+        fq.row1 = ml.frames + (size_t)fq.idx1 * ml.row_stride;
         if (valid) jq = query_quat(fq, b);
-        p_root = query_root_pos(ml, fq, mid);
-        p_root.x += offx;                                              // _move_to_motion_terrain dm_env.py:604-615
-        p_root.y += offy;
+        p_root = mk3(q0.w, q1.x, q1.y);
         r_root = shfl16(jq, 0);
     }
     // ---- phase B: K2 forward kinematics, level-synchronous inside the 16-lane group
@@ -651,6 +682,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
             } else if (valid) {
                 quat_to_tan_norm(jq, row + 12 + 6 * (b - 1));
             }
+            #pragma unroll 1
             for (int d = b; d < D; d += GRP) row[12 + 6 * J + d] = dofs[2 * d + 1];
             if (key_slot >= 0) st3(row + 12 + 6 * J + D + 3 * key_slot, quat_rotate(hinv, pos - c_pos));
             if (b == 0 && do_hf) {
@@ -663,7 +695,26 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
                 row[Wc + S * Wt + S * B + b] = fsqrt(dot3(f, f)) > cfg.contact_eps ? 1.f : 0.f;
             }
         }
-    } else if (is_ref) {
+    } else if (is_tar) {
+        if (what & PARC_POST_OBS) {
+            // DeepMimicEnv.compute_tar_obs + compute_tar_obs  dm_env.py:686-718, mgdm_dm_util.py:462-519
+            const int s = s_idx;
+            float *o = row + Wc + s * Wt;
+            v3 rpo = quat_rotate(hinv, p_root - c_pos);
+            if (b == 0) st3(o, rpo);
+            // lane 0: heading-relative root rotation at o+3; lane b: joint b-1 at o + 9 + 6 (b-1) = o + 3 + 6 b
+            const q4 hr = quat_mul(hinv, r_root);
+            if (valid) quat_to_tan_norm(b == 0 ? hr : jq, o + 3 + 6 * b);
+            if (key_slot >= 0) st3(o + 9 + 6 * J + 3 * key_slot, quat_rotate(hinv, pos - p_root) + rpo);
+            if (valid)
+                row[Wc + S * Wt + s * B + b] = lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend);
+        }
+    }
+    // The reference wave writes no observation columns: it passes both barriers right away and does its epilogue
+    // (reference state, reward, termination) while the other waves gather the heightmap and stream the rows out.
+    if (what & PARC_POST_OBS) __syncthreads();          // B1: pose-derived columns are in LDS
+    if (is_ref) {
+        if ((what & PARC_POST_OBS) && do_hf) __syncthreads();   // B2, early
         if (what & (PARC_POST_REF | PARC_POST_REWARD_DONE)) {
             // DeepMimicEnv._update_ref_motion  dm_env.py:570-595
             const v3 r_pos = p_root;
@@ -685,6 +736,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
                     buf.ref_contacts[(size_t)e * B + b] = r_contact;
                     st3(buf.ref_body_pos + ((size_t)e * B + b) * 3, pos);
                 }
+                #pragma unroll 1
                 for (int d = b; d < D; d += GRP) buf.ref_dof_vel[(size_t)e * D + d] = fq.row0[ml.off_dof_vel + d];
             }
             if (what & PARC_POST_REWARD_DONE) {
@@ -699,6 +751,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
                     float da = quat_diff_angle(cj, rq);
                     pose_e = cfg.joint_err_w[b - 1] * da * da;
                 }
+                #pragma unroll 1
                 for (int d = b; d < D; d += GRP) {
                     float dv = fq.row0[ml.off_dof_vel + d] - dofs[2 * d + 1];
                     vel_e += cfg.dof_err_w[d] * dv * dv;
@@ -800,6 +853,8 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
                         if (failed) done = PARC_DONE_FAIL;
                     }
                     // DeepMimicEnv.update_done  dm_env.py:746-783
+                    const int64_t mid = buf.motion_ids[e];
+                    const float mtime = tm + buf.motion_time_offsets[e];                          // dm_env.py:597-602
                     int motion_end = (mtime >= ml.length[mid]) && (ml.loop_mode[mid] != 1);
                     int kind = 0;
                     if (done != PARC_DONE_NULL || motion_end) kind = (done == PARC_DONE_FAIL) ? 1 : 2;
@@ -809,26 +864,11 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
                 }
             }
         }
-    } else if (is_tar) {
-        if (what & PARC_POST_OBS) {
-            // DeepMimicEnv.compute_tar_obs + compute_tar_obs  dm_env.py:686-718, mgdm_dm_util.py:462-519
-            const int s = s_idx;
-            float *o = row + Wc + s * Wt;
-            v3 rpo = quat_rotate(hinv, p_root - c_pos);
-            if (b == 0) {
-                st3(o, rpo);
-                quat_to_tan_norm(quat_mul(hinv, r_root), o + 3);
-            } else if (valid) {
-                quat_to_tan_norm(jq, o + 9 + 6 * (b - 1));
-            }
-            if (key_slot >= 0) st3(o + 9 + 6 * J + 3 * key_slot, quat_rotate(hinv, pos - p_root) + rpo);
-            if (valid)
-                row[Wc + S * Wt + s * B + b] = lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend);
-        }
+        return;
     }
     if (what & PARC_POST_OBS) {
-        __syncthreads();
-        const int nthr = blockDim.x;
+        const int nthr = blockDim.x - 64;               // all waves but the reference wave
+        const int tid = is_char ? (int)threadIdx.x : (int)threadIdx.x - 64;
         int out_len = row_len;
         if (do_hf) {
             // K5 fused: RefCharEnv._refresh_ray_obs_hfs (mgdm_dm_util.py:158-179) for the 4 envs of this workgroup,
@@ -843,19 +883,49 @@ __global__ __launch_bounds__(POST_MAX_THREADS) void track_post_kernel(parc_char_
                 float uj = fmaf(rx, h3, fmaf(ry, h4, h5));
                 ui = __builtin_amdgcn_fmed3f(rintf(ui), 0.f, max_i);
                 uj = __builtin_amdgcn_fmed3f(rintf(uj), 0.f, max_j);
-                rows[l2][row_len + p] = __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - h6, cfg.min_obs_h, cfg.max_obs_h);
+                rows[l2 * RS + row_len + p] = __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - h6, cfg.min_obs_h, cfg.max_obs_h);
             }
             out_len = cfg.obs_dim;
             __syncthreads();
         }
-        const int n4 = out_len >> 2;
-        for (int l2 = 0; l2 < POST_EPB; ++l2) {
-            int el2 = blockIdx.x * POST_EPB + l2;
-            if (el2 >= n_total) break;
-            int e2 = env_ids ? (int)env_ids[el2] : el2;
-            float *dst = buf.obs + (size_t)e2 * cfg.obs_dim;
-            for (int i = tid; i < n4; i += nthr) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(rows[l2])[i];
-            for (int i = 4 * n4 + tid; i < out_len; i += nthr) dst[i] = rows[l2][i];
+        const int nlive = min(POST_EPB, n_total - (int)blockIdx.x * POST_EPB);
+        if (!env_ids && out_len == RS) {
+            // consecutive envs, whole rows: the LDS image IS the output image
+            float4 *dst = reinterpret_cast<float4 *>(buf.obs + (size_t)blockIdx.x * POST_EPB * RS);
+            const float4 *src = reinterpret_cast<const float4 *>(rows);
+            const int tot4 = nlive * (RS >> 2);
+#pragma unroll 1
+            for (int i = tid; i < tot4; i += nthr) dst[i] = src[i];
+        } else {
+            // subset of envs and/or rows without the heightmap columns: walk the (env, float4) pairs
+            const int n4 = out_len >> 2;
+            size_t rowoff[POST_EPB];
+#pragma unroll
+            for (int l2 = 0; l2 < POST_EPB; ++l2) {
+                int el2 = min((int)blockIdx.x * POST_EPB + l2, n_total - 1);
+                rowoff[l2] = (size_t)(env_ids ? (int)env_ids[el2] : el2) * RS;
+            }
+            int l2 = 0, i = tid;
+#pragma unroll 1
+            for (;;) {
+#pragma unroll 1
+                while (i >= n4) {
+                    i -= n4;
+                    ++l2;
+                }
+                if (l2 >= nlive) break;
+                size_t ro = rowoff[0];
+#pragma unroll
+                for (int k = 1; k < POST_EPB; ++k) ro = l2 == k ? rowoff[k] : ro;
+                reinterpret_cast<float4 *>(buf.obs + ro)[i] = reinterpret_cast<const float4 *>(rows + l2 * RS)[i];
+                i += nthr;
+            }
+            const int tl = out_len & 3;     // only without the fused heightmap columns
+            if (tid < tl) {
+#pragma unroll
+                for (int k = 0; k < POST_EPB; ++k)
+                    if (k < nlive) buf.obs[rowoff[k] + 4 * n4 + tid] = rows[k * RS + 4 * n4 + tid];
+            }
         }
     }
 }

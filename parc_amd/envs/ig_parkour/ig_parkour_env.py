@@ -166,6 +166,7 @@ class IGParkourEnv(base_env.BaseEnv):
         self._all_env_ids = torch.arange(N, device=self._device, dtype=torch.long)
         names = ["pose_r", "vel_r", "root_pos_r", "root_vel_r", "key_pos_r", "contact_penalty", "task_r1", "task_r2", "total_task_r"]
         self._reward_term_views = OrderedDict((n, c.reward_terms[i]) for i, n in enumerate(names))
+        self._reward_all_names = ["total_r"] + names      # row order of c.reward_all
 
     # ------------------------------------------------------------------ env API (envs/base_env.py, envs/ig_env.py:51-98)
     def get_num_envs(self):
@@ -296,8 +297,9 @@ class IGParkourEnv(base_env.BaseEnv):
         info["char_contact_forces"] = self._char_contact_forces.clone()
         if step:
             r = dict(self._reward_term_views)
-            r["total_r"] = self._reward_buf.clone()
+            r["total_r"] = self._reward_buf.clone()        # snapshots, as the reference hands out (ig_parkour_env.py:1428,1543-1547)
             info["rewards"] = r
+            info["rewards_all"] = (self._reward_all_names, self._core.reward_all)     # same data as one [10, N] block
             if self._report_tracking_error:
                 info["tracking_error"] = self._compute_tracking_error()
 

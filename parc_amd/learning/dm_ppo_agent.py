@@ -58,6 +58,14 @@ class DMPPOAgent(torch.nn.Module):
         self._curr_obs = None
         self._curr_info = None
         self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self._device)
+        # hipGraph rollout: the fixed-shape part of one env step (policy forward, record, simulator, post-step kernel,
+        # return tracker, record) is captured once and replayed; only the data-dependent reset of finished envs stays eager
+        self._use_hip_graph = bool(config.get("hip_graph_rollout", True)) and str(self._device).startswith("cuda")
+        self._graphs = dict()
+        self._graph_pool = None
+        self._graph_warm = 0
+        self._exp_prob_t = torch.ones([1, 1], dtype=torch.float32, device=self._device)
+        self._head_t = torch.zeros([1], dtype=torch.int64, device=self._device)
         if getattr(self._env, "_report_tracking_error", False):
             self._test_tracking_error_tracker = TrackingErrorTracker(self.get_num_envs(), self._device)
 
@@ -181,7 +189,8 @@ class DMPPOAgent(torch.nn.Module):
                 norm_a = dist.sample()
                 mask = torch.ones_like(norm_a[..., 0])
             else:
-                mask = torch.bernoulli(torch.full([obs.shape[0], 1], exp_prob, device=self._device))
+                self._exp_prob_t.fill_(exp_prob)                       # device scalar: value changes do not stale a captured graph
+                mask = torch.bernoulli(self._exp_prob_t.expand(obs.shape[0], 1))
                 norm_a = torch.where(mask == 1.0, dist.sample(), dist.mode)
                 mask = mask.squeeze(-1)
         else:
@@ -204,7 +213,10 @@ class DMPPOAgent(torch.nn.Module):
             self._obs_norm.record(obs)
         eb.record("a_logp", action_info["a_logp"])
         eb.record("rand_action_mask", action_info["rand_action_mask"])
-        eb.record("prev_char_contact_forces", info["char_contact_forces"])
+        # (inside a captured step the info snapshot of the previous eager reset is not a stable address: read the env's
+        # own buffer, which holds the same values until the simulator runs)
+        eb.record("prev_char_contact_forces", self._env._char_contact_forces if getattr(self, "_in_graph_step", False)
+                  else info["char_contact_forces"])
 
     def _record_data_post_step(self, next_obs, r, done, next_info):
         eb = self._exp_buffer
@@ -213,7 +225,8 @@ class DMPPOAgent(torch.nn.Module):
         eb.record("done", done)
         eb.record("timestep", next_info["timestep"])
         eb.record("ep_num", next_info["ep_num"])
-        eb.get_data("compute_time")[eb._buffer_head].fill_(float(next_info["compute_time"]))
+        if not getattr(self, "_in_graph_step", False):
+            eb.get_data("compute_time")[eb._buffer_head].fill_(float(next_info["compute_time"]))
         eb.record("next_char_contact_forces", next_info["char_contact_forces"])
         eb.record("env_id", self._env_ids)
         if self._is_terrain_runner:
@@ -224,13 +237,57 @@ class DMPPOAgent(torch.nn.Module):
         done_indices = (done != base_env.DoneFlags.NULL.value).nonzero(as_tuple=False).flatten()
         return self._env.reset(done_indices)
 
+    def _train_step_body(self):
+        action, action_info = self._decide_action(self._curr_obs, self._curr_info)
+        self._record_data_pre_step(self._curr_obs, self._curr_info, action, action_info)
+        next_obs, r, done, next_info = self._env.step(action)
+        self._train_return_tracker.update(next_info, done)
+        self._record_data_post_step(next_obs, r, done, next_info)
+        return done
+
+    def _graph_ok(self):
+        env = self._env
+        return (self._use_hip_graph and self._mode == AgentMode.TRAIN and not getattr(env, "_write_agent_states_flag", False)
+                and hasattr(env, "_char_contact_forces") and getattr(getattr(env, "_core", None), "timing_events", None) is None)
+
+    def _train_step_graph(self):
+        """One rollout step through a captured hipGraph (torch.cuda.CUDAGraph = hipGraph on ROCm).  Graphs are keyed by
+        the host-side branches inside the step; step inputs are the env's persistent buffers, the write row of the
+        experience buffer is the device scalar ``_head_t``."""
+        eb = self._exp_buffer
+        exp_prob = self._get_exp_prob()
+        key = (self._need_normalizer_update(), exp_prob >= 1.0)
+        self._head_t.fill_(eb._buffer_head)
+        g = self._graphs.get(key)
+        if g is None:
+            if self._graph_warm < 2:                 # library handles / workspaces are created by eager steps first
+                self._graph_warm += 1
+                return self._train_step_body()
+            eb.set_device_head(self._head_t)
+            self._in_graph_step = True
+            count0 = self._obs_norm._new_count
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self._graph_pool):
+                    done = self._train_step_body()
+                if self._graph_pool is None:
+                    self._graph_pool = g.pool()
+            finally:
+                eb.set_device_head(None)
+                self._in_graph_step = False
+            self._obs_norm._new_count = count0       # capture enqueues nothing; the replay below is this step
+            self._graphs[key] = (g, done)
+        g, done = self._graphs[key]
+        g.replay()
+        if key[0]:
+            self._obs_norm._new_count += self.get_num_envs()
+        eb.get_data("compute_time")[eb._buffer_head].fill_(time.time() - self._env._start_compute_time)
+        return done
+
     def _rollout_train(self, num_steps):
         for _ in range(num_steps):
-            action, action_info = self._decide_action(self._curr_obs, self._curr_info)
-            self._record_data_pre_step(self._curr_obs, self._curr_info, action, action_info)
-            next_obs, r, done, next_info = self._env.step(action)
-            self._train_return_tracker.update(next_info, done)
-            self._record_data_post_step(next_obs, r, done, next_info)
+            done = self._train_step_graph() if self._graph_ok() else self._train_step_body()
             self._curr_obs, self._curr_info = self._reset_done_envs(done)
             self._exp_buffer.inc()
 
@@ -375,11 +432,7 @@ class DMPPOAgent(torch.nn.Module):
             self._obs_norm.update()
         info = {**train_info, **data_info}
         tr = self._train_return_tracker
-        info["mean_return"] = tr.get_mean_return().item()
-        info["mean_ep_len"] = tr.get_mean_ep_len().item()
-        info["num_eps"] = tr.get_episodes()
-        for key in tr._mean_returns:
-            info[key] = tr.get_specific_mean_return(key).item()
+        info.update(tr.summary())           # one device->host copy for all tracked means
         return info
 
     def _init_train(self):

@@ -15,6 +15,7 @@ class ExperienceBuffer:
         self._flat_buffers = dict()
         self._sample_buf = torch.randperm(buffer_length * batch_size, device=device, dtype=torch.long)
         self._sample_buf_head = 0
+        self._device_head = None
 
     def add_buffer(self, name, buffer):
         assert len(buffer.shape) >= 2 and buffer.shape[0] == self._buffer_length and buffer.shape[1] == self._batch_size
@@ -42,7 +43,16 @@ class ExperienceBuffer:
 
     def record(self, name, data):
         assert data.shape[0] == self._batch_size
-        self._buffers[name][self._buffer_head] = data
+        if self._device_head is not None:
+            # hipGraph rollout: the write position is a device scalar, so one captured graph serves every step
+            buf = self._buffers[name]
+            buf.index_copy_(0, self._device_head, data.to(buf.dtype).unsqueeze(0))
+        else:
+            self._buffers[name][self._buffer_head] = data
+
+    def set_device_head(self, head_t):
+        """head_t: int64 device tensor [1] mirroring ``_buffer_head`` (None switches back to host indexing)."""
+        self._device_head = head_t
 
     def get_data(self, name):
         return self._buffers[name]

@@ -141,8 +141,10 @@ class TrackerCore:
         self.ref_contacts = z((N, B), **f32)
         self.ref_body_pos = z((N, B, 3), **f32)
         self.obs = z((N, cfg.obs_dim), **f32)
-        self.reward = z((N,), **f32)
-        self.reward_terms = z((9, N), **f32)
+        # row 0 = total reward, rows 1..9 = the logged terms: one [10, N] block so the return tracker adds it in one op
+        self.reward_all = z((10, N), **f32)
+        self.reward = self.reward_all[0]
+        self.reward_terms = self.reward_all[1:10]
         self.target_xy = z((N, 2), **f32)
         self.next_target_xy_time = z((N,), **f32)
         self.done = z((N,), dtype=torch.int, device=device)

@@ -125,3 +125,41 @@ def test_agent_checkpoint_keys_and_training_iteration(env, tmp_path):
     agent.load(str(p))
     res = agent.test_model(2)
     assert np.isfinite(res["mean_return"]) and res["num_eps"] >= 96
+
+
+def test_graph_rollout_matches_eager_bookkeeping(env):
+    """The captured rollout step (hipGraph) must leave the same bookkeeping as the eager step: contiguous transitions in
+    the experience buffer, timestep/episode counters, normaliser sample counts and return-tracker episode counts."""
+    from parc_amd import workloads
+    T = 12
+    agent = workloads.build_agent(env, DEV, steps_per_iter=T, update_epochs=1, batch_size=2)
+    assert agent._use_hip_graph
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    agent._rollout_train(T)
+    torch.cuda.synchronize()
+    assert len(agent._graphs) == 1                     # 2 eager warm-up steps, then capture + replays
+    eb = agent._exp_buffer
+    obs, nobs, done = eb.get_data("obs"), eb.get_data("next_obs"), eb.get_data("done")
+    ts, epn, r = eb.get_data("timestep"), eb.get_data("ep_num"), eb.get_data("reward")
+    assert torch.isfinite(obs).all() and torch.isfinite(nobs).all() and torch.isfinite(r).all()
+    for t in range(T - 1):
+        cont = done[t] == 0
+        assert torch.equal(nobs[t][cont], obs[t + 1][cont])                 # graph steps included (t >= 2)
+        assert torch.equal(ts[t + 1][cont], ts[t][cont] + 1)
+        assert torch.all(ts[t + 1][~cont] == 1)                             # reset -> first step of the new episode
+        assert torch.equal(epn[t + 1][~cont], epn[t][~cont] + 1)
+    assert torch.all(eb.get_data("env_id") == torch.arange(96, device=DEV))
+    assert torch.all(eb.get_data("compute_time")[T - 1] > 0)
+    n_done = int((done != 0).sum().item())
+    assert agent._train_return_tracker.get_episodes() == n_done
+    assert agent._obs_norm._new_count == T * 96
+    assert torch.allclose(agent._obs_norm._new_sum, obs.sum(dim=(0, 1)), rtol=1e-4, atol=1e-2)
+    # prev/next contact forces chain like the observations
+    pcf, ncf = eb.get_data("prev_char_contact_forces"), eb.get_data("next_char_contact_forces")
+    for t in range(2, T - 1):
+        cont = done[t] == 0
+        assert torch.equal(ncf[t][cont], pcf[t + 1][cont])
+    # the captured graph survives a full training iteration (update changes the weights in place)
+    info = agent._train_iter()
+    assert np.isfinite(info["mean_return"]) and len(agent._graphs) == 1
