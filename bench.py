@@ -190,7 +190,8 @@ def main():
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": kern_b2b_us,
                          "us_per_launch_event_pairs_in_rollout_loop": kern_us, "launches_event_timed": len(evs)},
-            "rollout": "hipGraph replay per env step + eager reset of finished envs" if agent._graphs else "eager",
+            "rollout": ("one hipGraph replay per env step" + (", finished envs reset on the device inside the graph" if any(k[2] for k in agent._graphs)
+                                                               else " + eager reset of finished envs")) if agent._graphs else "eager",
             "rollout_env_steps_per_s": world * N * T * args.steps / max(rollout_s[0], 1e-9),
             "rollout_fraction_of_time": rollout_s[0] / elapsed,
             "mean_episode_return": info["mean_return"] if info else None,

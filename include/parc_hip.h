@@ -132,6 +132,9 @@ typedef struct {
     float *reward_terms;            /* [9,N]: pose_r vel_r root_pos_r root_vel_r key_pos_r contact_penalty task_r1 task_r2 total_task_r */
     int32_t *done;                  /* [N]  DoneFlags after the motion-end override (dm_env.py:782) */
     int32_t *done_kind;             /* [N]  0 none, 1 failed, 2 ended without failing (feeds parc_update_fail_rates) */
+    /* device-side reset (no host round trip): see PARC_POST_MASKED / PARC_POST_INIT_CHAR; both may be NULL otherwise */
+    const int32_t *env_mask;        /* [N]  nonzero = env takes part in a PARC_POST_MASKED launch */
+    const float *init_noise_xy;     /* [N,2] or NULL: added to the root xy written by PARC_POST_INIT_CHAR (already scaled) */
 } parc_env_buffers_t;
 
 /* ---- K5: local heightmap ---------------------------------------------------------------------
@@ -183,9 +186,25 @@ int parc_motion_lib_build(void *stream, parc_char_model_t model, parc_motion_lib
 #define PARC_POST_OBS 2
 #define PARC_POST_REWARD_DONE 4
 #define PARC_POST_HF 8
+/* bit4: only envs with buf.env_mask[e] != 0 are processed (all N are scanned; env_ids must be NULL): the reset of
+ * finished envs without the nonzero()/index round trip of ig_env.py:100-121.
+ * bit5 (with bit0): RefCharEnv._char_state_init_from_ref + add_noise_to_char_state (mgdm_dm_util.py:119-136): the
+ * reference state at the env's clip time is ALSO written into root_state / dof_state rows of the env (the buffers are
+ * written through their const pointers in this mode only). */
+#define PARC_POST_MASKED 16
+#define PARC_POST_INIT_CHAR 32
 int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
                          parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
                          const float *ray_xy);
+
+/* Reset bookkeeping of DeepMimicEnv._reset_envs / IGEnv._reset_envs (dm_env.py:517-568, ig_env.py:100-121,693-721) for the
+ * envs whose mask is set, from per-env candidate samples new_*[N] (drawn for every env, used where masked):
+ * motion_ids/terrain ids/time offsets/tile offset are replaced, timestep/time/done/next-target-time cleared, ep_num += 1.
+ * motion_offsets is the [M, terrains_per_motion, 2] tile table. */
+int parc_reset_apply(void *stream, int n_envs, const int32_t *mask, const int64_t *new_motion_ids, const int64_t *new_terrain_ids,
+                     const float *new_time_offsets, const float *motion_offsets, int terrains_per_motion, int64_t *motion_ids,
+                     int64_t *motion_terrain_ids, float *motion_time_offsets, float *motion_xy_offset, int32_t *timestep_buf,
+                     float *time_buf, int32_t *done, float *next_target_time, int64_t *ep_num);
 
 /* DeepMimicEnv.update_done's per-done-env Python loop (dm_env.py:758-772): EMA of per-clip failure rates,
  * applied in increasing env order exactly as the reference's loop does. */

@@ -59,6 +59,10 @@ int parc_sim_step(void *stream, const parc_sim_model_t *model, parc_terrain_t te
 int parc_sim_refresh_bodies(void *stream, const parc_sim_model_t *model, int n_envs, const int64_t *env_ids, int n_sel,
                             const float *root_state, const float *dof_state, float *rigid_body_state, float *contact_forces);
 
+/* Same for every env whose mask[e] != 0 (device-side reset, no index list). */
+int parc_sim_refresh_bodies_masked(void *stream, const parc_sim_model_t *model, int n_envs, const int32_t *mask,
+                                   const float *root_state, const float *dof_state, float *rigid_body_state, float *contact_forces);
+
 int parc_sim_abi(void);
 
 #ifdef __cplusplus

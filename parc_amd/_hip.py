@@ -25,6 +25,8 @@ POST_REF = 1
 POST_OBS = 2
 POST_REWARD_DONE = 4
 POST_HF = 8
+POST_MASKED = 16
+POST_INIT_CHAR = 32
 
 c_int = ctypes.c_int
 c_i32 = ctypes.c_int32
@@ -75,7 +77,8 @@ class EnvBuffersS(ctypes.Structure):
                 ("ref_root_pos", c_vp), ("ref_root_rot", c_vp), ("ref_root_vel", c_vp), ("ref_root_ang_vel", c_vp),
                 ("ref_joint_rot", c_vp), ("ref_dof_vel", c_vp), ("ref_dof_pos", c_vp),
                 ("ref_contacts", c_vp), ("ref_body_pos", c_vp),
-                ("obs", c_vp), ("reward", c_vp), ("reward_terms", c_vp), ("done", c_vp), ("done_kind", c_vp)]
+                ("obs", c_vp), ("reward", c_vp), ("reward_terms", c_vp), ("done", c_vp), ("done_kind", c_vp),
+                ("env_mask", c_vp), ("init_noise_xy", c_vp)]
 
 
 _lib = None
@@ -137,8 +140,10 @@ def _declare(L):
     L.parc_update_fail_rates.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_vp]
     L.parc_td_lambda_return.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_f, c_f, c_vp]
     L.parc_adv_normalize.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp]
+    L.parc_reset_apply.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int] + [c_vp] * 9
+    L.parc_reset_apply.restype = c_int
     for name in ("parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
-                 "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step",
+                 "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step", "parc_reset_apply",
                  "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize"):
         getattr(L, name).restype = c_int
     if hasattr(L, "parc_sim_abi"):
@@ -148,7 +153,7 @@ def _declare(L):
 
 EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
             "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step",
-            "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize"]
+            "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize", "parc_reset_apply"]
 
 
 def check(rc, what):

@@ -295,7 +295,8 @@ PARC_DEV q4 joint_dof_to_rot(const parc_char_model_t &m, int b, const float *dof
 }
 
 // anim/kin_char_model.py:79-100: one joint's quaternion -> dofs
-PARC_DEV void joint_rot_to_dof(const parc_char_model_t &m, int b, q4 q, float *dof) {
+// (dof2, when given, receives the same values at stride 2: the position slots of an interleaved dof_state row)
+PARC_DEV void joint_rot_to_dof(const parc_char_model_t &m, int b, q4 q, float *dof, float *dof2 = nullptr) {
     int jt = m.joint_type[b];
     if (jt == PARC_JOINT_HINGE) {
         v3 ax;
@@ -304,12 +305,18 @@ PARC_DEV void joint_rot_to_dof(const parc_char_model_t &m, int b, q4 q, float *d
         float d = m.joint_axis[b][0] * ax.x + m.joint_axis[b][1] * ax.y + m.joint_axis[b][2] * ax.z;
         if (d < 0.f) an *= -1.f;
         dof[m.dof_idx[b]] = an;
+        if (dof2) dof2[2 * m.dof_idx[b]] = an;
     } else if (jt == PARC_JOINT_SPHERICAL) {
         v3 e = quat_to_exp_map(q);
         int d = m.dof_idx[b];
         dof[d] = e.x;
         dof[d + 1] = e.y;
         dof[d + 2] = e.z;
+        if (dof2) {
+            dof2[2 * d] = e.x;
+            dof2[2 * d + 2] = e.y;
+            dof2[2 * d + 4] = e.z;
+        }
     }
 }
 
@@ -591,7 +598,18 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     const bool is_char = wv == 0, is_ref = wv == 1, is_tar = wv >= 2;
     const int le = gg, s_idx = is_tar ? wv - 2 : 0;     // a target wave = one target step of the 4 envs
     const int el = blockIdx.x * POST_EPB + le;
-    const bool live = el < n_total;
+    const bool masked = (what & PARC_POST_MASKED) != 0;
+    if (masked) {
+        // device-side reset: nothing to do for a workgroup whose envs all kept running (uniform: every wave leaves)
+        int any = 0;
+#pragma unroll
+        for (int k = 0; k < POST_EPB; ++k) {
+            int ek = blockIdx.x * POST_EPB + k;
+            if (ek < n_total) any |= buf.env_mask[ek];
+        }
+        if (!any) return;
+    }
+    const bool live = el < n_total && (!masked || buf.env_mask[el] != 0);
     const int RS = cfg.obs_dim;
     float *row = rows + le * RS;
     const int Wc = 12 + 6 * J + D + 3 * K;   // char_obs width (136)
@@ -738,6 +756,26 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 }
                 #pragma unroll 1
                 for (int d = b; d < D; d += GRP) buf.ref_dof_vel[(size_t)e * D + d] = fq.row0[ml.off_dof_vel + d];
+                if (what & PARC_POST_INIT_CHAR) {
+                    // RefCharEnv._char_state_init_from_ref + add_noise_to_char_state  mgdm_dm_util.py:119-136
+                    float *wrs = const_cast<float *>(buf.root_state) + (size_t)e * 13;
+                    float *wds = const_cast<float *>(buf.dof_state) + (size_t)e * D * 2;
+                    if (b == 0) {
+                        v3 ip = r_pos;
+                        if (buf.init_noise_xy) {
+                            ip.x += buf.init_noise_xy[2 * e];
+                            ip.y += buf.init_noise_xy[2 * e + 1];
+                        }
+                        st3(wrs, ip);
+                        st4(wrs + 3, r_rot);
+                        st3(wrs + 7, r_vel);
+                        st3(wrs + 10, r_avel);
+                    } else if (valid) {
+                        joint_rot_to_dof(m, b, rq, buf.ref_dof_pos + (size_t)e * D, wds);
+                    }
+#pragma unroll 1
+                    for (int d = b; d < D; d += GRP) wds[2 * d + 1] = fq.row0[ml.off_dof_vel + d];
+                }
             }
             if (what & PARC_POST_REWARD_DONE) {
                 // compute_deepmimic_reward  mgdm_dm_util.py:327-390 (track_root, track_root_h)
@@ -889,7 +927,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             __syncthreads();
         }
         const int nlive = min(POST_EPB, n_total - (int)blockIdx.x * POST_EPB);
-        if (!env_ids && out_len == RS) {
+        if (!env_ids && !masked && out_len == RS) {
             // consecutive envs, whole rows: the LDS image IS the output image
             float4 *dst = reinterpret_cast<float4 *>(buf.obs + (size_t)blockIdx.x * POST_EPB * RS);
             const float4 *src = reinterpret_cast<const float4 *>(rows);
@@ -900,10 +938,12 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             // subset of envs and/or rows without the heightmap columns: walk the (env, float4) pairs
             const int n4 = out_len >> 2;
             size_t rowoff[POST_EPB];
+            bool rowlive[POST_EPB];
 #pragma unroll
             for (int l2 = 0; l2 < POST_EPB; ++l2) {
                 int el2 = min((int)blockIdx.x * POST_EPB + l2, n_total - 1);
                 rowoff[l2] = (size_t)(env_ids ? (int)env_ids[el2] : el2) * RS;
+                rowlive[l2] = !masked || buf.env_mask[el2] != 0;
             }
             int l2 = 0, i = tid;
 #pragma unroll 1
@@ -915,16 +955,21 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 }
                 if (l2 >= nlive) break;
                 size_t ro = rowoff[0];
+                bool rl = rowlive[0];
 #pragma unroll
-                for (int k = 1; k < POST_EPB; ++k) ro = l2 == k ? rowoff[k] : ro;
-                reinterpret_cast<float4 *>(buf.obs + ro)[i] = reinterpret_cast<const float4 *>(rows + l2 * RS)[i];
+                for (int k = 1; k < POST_EPB; ++k) {
+                    ro = l2 == k ? rowoff[k] : ro;
+                    rl = l2 == k ? rowlive[k] : rl;
+                }
+                if (rl)
+                    reinterpret_cast<float4 *>(buf.obs + ro)[i] = reinterpret_cast<const float4 *>(rows + l2 * RS)[i];
                 i += nthr;
             }
             const int tl = out_len & 3;     // only without the fused heightmap columns
             if (tid < tl) {
 #pragma unroll
                 for (int k = 0; k < POST_EPB; ++k)
-                    if (k < nlive) buf.obs[rowoff[k] + 4 * n4 + tid] = rows[k * RS + 4 * n4 + tid];
+                    if (k < nlive && rowlive[k]) buf.obs[rowoff[k] + 4 * n4 + tid] = rows[k * RS + 4 * n4 + tid];
             }
         }
     }
@@ -942,11 +987,49 @@ extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_
         if (!(what & PARC_POST_OBS) || !ray_xy || !terrain.hf) return PARC_EINVAL;
     }
     if (((uintptr_t)buf.obs & 15) || ((uintptr_t)mlib.frames & 15) || (mlib.row_stride & 3)) return PARC_EINVAL;
+    if ((what & PARC_POST_MASKED) && (env_ids || !buf.env_mask)) return PARC_EINVAL;
+    if ((what & PARC_POST_INIT_CHAR) && !(what & PARC_POST_REF)) return PARC_EINVAL;
     int n = env_ids ? n_sel : buf.num_envs;
     if (n < 0) return PARC_EINVAL;
     if (n == 0) return PARC_OK;
     hipLaunchKernelGGL(track_post_kernel, dim3((n + POST_EPB - 1) / POST_EPB), dim3(64 * (2 + (cfg.num_tar_steps > 0 ? cfg.num_tar_steps : 0))), 0,
                        (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, n, what, ray_xy);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+// =============================================================================================
+// Device-side reset bookkeeping (dm_env.py:517-568, ig_env.py:100-121,693-721), one thread per env
+// =============================================================================================
+__global__ __launch_bounds__(256) void reset_apply_kernel(int n, const int32_t *__restrict__ mask, const int64_t *__restrict__ new_mid,
+                                                          const int64_t *__restrict__ new_tid, const float *__restrict__ new_t,
+                                                          const float *__restrict__ offs, int R, int64_t *mid, int64_t *tid, float *toff,
+                                                          float *xyoff, int32_t *timestep, float *time_buf, int32_t *done,
+                                                          float *next_target_time, int64_t *ep_num) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || mask[e] == 0) return;
+    int64_t mi = new_mid[e], ti = new_tid[e];
+    mid[e] = mi;
+    tid[e] = ti;
+    toff[e] = new_t[e];
+    xyoff[2 * e] = offs[(mi * R + ti) * 2];
+    xyoff[2 * e + 1] = offs[(mi * R + ti) * 2 + 1];
+    timestep[e] = 0;
+    time_buf[e] = 0.f;
+    done[e] = PARC_DONE_NULL;
+    next_target_time[e] = 0.f;
+    ep_num[e] += 1;
+}
+
+extern "C" int parc_reset_apply(void *stream, int n_envs, const int32_t *mask, const int64_t *new_motion_ids, const int64_t *new_terrain_ids,
+                                const float *new_time_offsets, const float *motion_offsets, int terrains_per_motion, int64_t *motion_ids,
+                                int64_t *motion_terrain_ids, float *motion_time_offsets, float *motion_xy_offset, int32_t *timestep_buf,
+                                float *time_buf, int32_t *done, float *next_target_time, int64_t *ep_num) {
+    if (n_envs < 0 || terrains_per_motion < 1 || !mask) return PARC_EINVAL;
+    if (n_envs == 0) return PARC_OK;
+    hipLaunchKernelGGL(reset_apply_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_envs, mask, new_motion_ids,
+                       new_terrain_ids, new_time_offsets, motion_offsets, terrains_per_motion, motion_ids, motion_terrain_ids,
+                       motion_time_offsets, motion_xy_offset, timestep_buf, time_buf, done, next_target_time, ep_num);
     PARC_CHECK_LAUNCH();
     return PARC_OK;
 }

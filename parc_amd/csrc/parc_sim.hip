@@ -21,10 +21,12 @@ __global__ __launch_bounds__(SIM_THREADS) void sim_step_kernel(const parc_sim_mo
 }
 
 __global__ __launch_bounds__(SIM_THREADS) void sim_refresh_kernel(const parc_sim_model_t *__restrict__ model, int n, const int64_t *__restrict__ env_ids,
+                                                                  const int32_t *__restrict__ mask,
                                                                   const float *__restrict__ root_state, const float *__restrict__ dof_state,
                                                                   float *rigid_body_state, float *contact_forces) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
+    if (mask && mask[k] == 0) return;
     const int e = env_ids ? (int)env_ids[k] : k;
     const parc_sim_model_t &m = *model;
     const int B = m.num_bodies, D = m.dof_size;
@@ -39,12 +41,22 @@ __global__ __launch_bounds__(SIM_THREADS) void sim_refresh_kernel(const parc_sim
     parc_sim::publish_bodies(m, x, rigid_body_state + 13 * (size_t)B * e, contact_forces + 3 * (size_t)B * e);
 }
 
+// envs (= lanes) per workgroup of the step kernel: 4096 envs are only 64 full waves on a 1024-SIMD chip, so partially
+// filled waves on more CUs can win; tuning knob, not part of the stable ABI
+static int g_sim_threads = SIM_THREADS;
+extern "C" int parc_tune_sim_threads(int t) {
+    if (t != 8 && t != 16 && t != 32 && t != 64) return PARC_EINVAL;
+    g_sim_threads = t;
+    return PARC_OK;
+}
+
 extern "C" int parc_sim_step(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,
                              float *dof_state, float *rigid_body_state, float *contact_forces, const float *env_offsets,
                              const float *action, const float *action_low, const float *action_high, int n_substeps, float h) {
     if (!model || n_envs < 0 || n_substeps <= 0 || !(h > 0.f) || !terrain.hf) return PARC_EINVAL;
     if (n_envs == 0) return PARC_OK;
-    hipLaunchKernelGGL(sim_step_kernel, dim3((n_envs + SIM_THREADS - 1) / SIM_THREADS), dim3(SIM_THREADS), 0, (hipStream_t)stream, model,
+    const int th = g_sim_threads;
+    hipLaunchKernelGGL(sim_step_kernel, dim3((n_envs + th - 1) / th), dim3(th), 0, (hipStream_t)stream, model,
                        terrain, n_envs, root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low,
                        action_high, n_substeps, h);
     hipError_t e = hipGetLastError();
@@ -57,7 +69,19 @@ extern "C" int parc_sim_refresh_bodies(void *stream, const parc_sim_model_t *mod
     int n = env_ids ? n_sel : n_envs;
     if (n <= 0) return n == 0 ? PARC_OK : PARC_EINVAL;
     hipLaunchKernelGGL(sim_refresh_kernel, dim3((n + SIM_THREADS - 1) / SIM_THREADS), dim3(SIM_THREADS), 0, (hipStream_t)stream, model, n,
-                       env_ids, root_state, dof_state, rigid_body_state, contact_forces);
+                       env_ids, (const int32_t *)nullptr, root_state, dof_state, rigid_body_state, contact_forces);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}
+
+extern "C" int parc_sim_refresh_bodies_masked(void *stream, const parc_sim_model_t *model, int n_envs, const int32_t *mask,
+                                              const float *root_state, const float *dof_state, float *rigid_body_state,
+                                              float *contact_forces) {
+    if (!model || n_envs < 0 || !mask) return PARC_EINVAL;
+    if (n_envs == 0) return PARC_OK;
+    // few envs are masked per call: 16 lanes per workgroup spread the flagged ones over more CUs
+    hipLaunchKernelGGL(sim_refresh_kernel, dim3((n_envs + 15) / 16), dim3(16), 0, (hipStream_t)stream, model, n_envs,
+                       (const int64_t *)nullptr, mask, root_state, dof_state, rigid_body_state, contact_forces);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }

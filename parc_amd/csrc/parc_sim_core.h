@@ -34,6 +34,51 @@
 
 namespace parc_sim {
 
+// Scalar primitives.  Device: the hardware's 1-ulp sqrt / reciprocal and short polynomials (the kernel is one long
+// dependent instruction stream per wave; the library versions are 10-200 instructions each).  Host build: libm.
+#if defined(__HIP_DEVICE_COMPILE__)
+PARC_HD float p_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+PARC_HD float p_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+PARC_HD void p_sincos(float x, float &s, float &c) {
+    float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(k, -1.5707963705062866f, x);
+    r = fmaf(k, 4.3711388286737929e-08f, r);
+    float z = r * r;
+    float ps = fmaf(z, fmaf(z, -0.0001947956479853019f, 0.0083318455144763f), -0.16666647791862488f);
+    float pc = fmaf(z, fmaf(z, 2.4421184207312763e-05f, -0.001388721400871873f), 0.04166664183139801f);
+    float sr = fmaf(r * z, ps, r);
+    float cr = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    int q = (int)k;
+    float so = (q & 1) ? cr : sr, co = (q & 1) ? sr : cr;
+    s = (q & 2) ? -so : so;
+    c = ((q + 1) & 2) ? -co : co;
+}
+// atan2(y, x) for y >= 0, x >= 0
+PARC_HD float p_atan2_q1(float y, float x) {
+    float mn = fminf(x, y), mx = fmaxf(x, y);
+    float t = mx > 0.f ? mn * p_rcp(mx) : 0.f;
+    float z = t * t;
+    float p = fmaf(z, -0.0025300427805632353f, 0.014093323610723019f);
+    p = fmaf(z, p, -0.036850083619356155f);
+    p = fmaf(z, p, 0.06335900723934174f);
+    p = fmaf(z, p, -0.08698903024196625f);
+    p = fmaf(z, p, 0.11045123636722565f);
+    p = fmaf(z, p, -0.1428011804819107f);
+    p = fmaf(z, p, 0.19999824464321136f);
+    p = fmaf(z, p, -0.3333333134651184f);
+    float a = fmaf(t * z, p, t);
+    return y > x ? 1.5707963267948966f - a : a;
+}
+#else
+PARC_HD float p_sqrt(float x) { return sqrtf(x); }
+PARC_HD float p_rcp(float x) { return 1.0f / x; }
+PARC_HD void p_sincos(float x, float &s, float &c) {
+    s = sinf(x);
+    c = cosf(x);
+}
+PARC_HD float p_atan2_q1(float y, float x) { return atan2f(y, x); }
+#endif
+
 struct V3 {
     float x, y, z;
 };
@@ -110,7 +155,7 @@ PARC_HD M3 inv_sym(const M3 &a) {
     float a00 = a.m[0], a01 = a.m[1], a02 = a.m[2], a11 = a.m[4], a12 = a.m[5], a22 = a.m[8];
     float c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
     float det = a00 * c00 + a01 * c01 + a02 * c02;
-    float id = 1.0f / det;
+    float id = p_rcp(det);
     M3 r;
     r.m[0] = c00 * id;
     r.m[1] = r.m[3] = c01 * id;
@@ -130,8 +175,8 @@ PARC_HD Q4 qmul(Q4 a, Q4 b) {
 }
 PARC_HD Q4 qconj(Q4 q) { return Q4{-q.x, -q.y, -q.z, q.w}; }
 PARC_HD Q4 qnormalize(Q4 q) {
-    float n = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-    float i = n > 1e-12f ? 1.0f / n : 1.0f;
+    float n = p_sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    float i = n > 1e-12f ? p_rcp(n) : 1.0f;
     return Q4{q.x * i, q.y * i, q.z * i, q.w * i};
 }
 PARC_HD M3 qmat(Q4 q) {
@@ -144,16 +189,18 @@ PARC_HD M3 qmat(Q4 q) {
 }
 // exponential map (rotation vector) <-> quaternion; same conventions as util/torch_util.py:346-351,414-419
 PARC_HD Q4 exp_to_q(V3 e) {
-    float a = sqrtf(dot(e, e));
+    float a = p_sqrt(dot(e, e));
     if (a < 1e-6f) return qnormalize(Q4{0.5f * e.x, 0.5f * e.y, 0.5f * e.z, 1.f});
-    float s = sinf(0.5f * a) / a;
-    return Q4{e.x * s, e.y * s, e.z * s, cosf(0.5f * a)};
+    float s, c;
+    p_sincos(0.5f * a, s, c);
+    s *= p_rcp(a);
+    return Q4{e.x * s, e.y * s, e.z * s, c};
 }
 PARC_HD V3 q_to_exp(Q4 q) {
     if (q.w < 0.f) q = Q4{-q.x, -q.y, -q.z, -q.w};
-    float l = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z);
+    float l = p_sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
     if (l < 1e-6f) return V3{2.f * q.x, 2.f * q.y, 2.f * q.z};
-    float a = 2.0f * atan2f(l, q.w) / l;
+    float a = 2.0f * p_atan2_q1(l, q.w) * p_rcp(l);
     return V3{a * q.x, a * q.y, a * q.z};
 }
 
@@ -205,7 +252,7 @@ PARC_HD float terrain_h(const parc_terrain_t &t, int i, int j) {
 // One sample sphere (centre p in GLOBAL xy / env z, radius rho) against the column field.  Returns the deepest
 // contact: penetration depth (>0), unit normal n.
 PARC_HD bool sphere_vs_columns(const parc_terrain_t &t, V3 p, float rho, float &depth, V3 &n) {
-    float u = (p.x - t.min_x) / t.dx, w = (p.y - t.min_y) / t.dy;
+    float u = (p.x - t.min_x) * p_rcp(t.dx), w = (p.y - t.min_y) * p_rcp(t.dy);
     int ci = (int)floorf(u + 0.5f), cj = (int)floorf(w + 0.5f);
     float h0 = terrain_h(t, ci, cj);
     bool hit = false;
@@ -242,13 +289,14 @@ PARC_HD bool sphere_vs_columns(const parc_terrain_t &t, V3 p, float rho, float &
             float gz = p.z > hn ? p.z - hn : 0.f;
             float d2 = gx * gx + gy * gy + gz * gz;
             if (d2 >= rho * rho) continue;
-            float d = sqrtf(d2);
+            float d = p_sqrt(d2);
             float pen = rho - d;
             if (pen > depth) {
-                V3 nn = d > 1e-6f ? v3(-(float)di * gx / d, -(float)dj * gy / d, gz / d) : v3(-(float)di, -(float)dj, 0.f);
-                float nl = sqrtf(dot(nn, nn));
+                float id = p_rcp(d);
+                V3 nn = d > 1e-6f ? v3(-(float)di * gx * id, -(float)dj * gy * id, gz * id) : v3(-(float)di, -(float)dj, 0.f);
+                float nl = p_sqrt(dot(nn, nn));
                 if (nl > 1e-6f) {
-                    n = (1.0f / nl) * nn;
+                    n = p_rcp(nl) * nn;
                     depth = pen;
                     hit = true;
                 }
@@ -323,9 +371,9 @@ PARC_HD void pass1(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_
         float fn0 = m.contact_kn * d_eff - cn * vn;
         if (fn0 <= 0.f) continue;
         V3 vt = vpb - vn * nb;
-        float vtn = sqrtf(dot(vt, vt));
+        float vtn = p_sqrt(dot(vt, vt));
         float ct = m.contact_ct;
-        float ct_cone = m.friction_mu * fn0 / (vtn > 1e-4f ? vtn : 1e-4f);
+        float ct_cone = m.friction_mu * fn0 * p_rcp(vtn > 1e-4f ? vtn : 1e-4f);
         if (ct_cone < ct) ct = ct_cone;
         V3 F0 = fn0 * nb - ct * vt;
         // Z = (cn + h kn) n n^T + ct (1 - n n^T), body coordinates
@@ -362,9 +410,9 @@ PARC_HD void report_contacts(const parc_sim_model_t &m, const parc_terrain_t &te
         float fn0 = m.contact_kn * d_eff - cn * vn;
         if (fn0 <= 0.f) continue;
         V3 vt = vpb - vn * nb;
-        float vtn = sqrtf(dot(vt, vt));
+        float vtn = p_sqrt(dot(vt, vt));
         float ct = m.contact_ct;
-        float ct_cone = m.friction_mu * fn0 / (vtn > 1e-4f ? vtn : 1e-4f);
+        float ct_cone = m.friction_mu * fn0 * p_rcp(vtn > 1e-4f ? vtn : 1e-4f);
         if (ct_cone < ct) ct = ct_cone;
         V3 F0 = fn0 * nb - ct * vt;
         V3 dv = h * (s.a[b].l + cross(s.a[b].a, rc));
@@ -400,7 +448,7 @@ PARC_HD void substep(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 en
                 float kp = m.kp[d0 + k], kd = m.kd[d0 + k];
                 float t = kp * ev[k] - kd * wv[k];
                 float lim = m.effort[d0 + k];
-                float sc = (lim > 0.f && fabsf(t) > lim) ? lim / fabsf(t) : 1.0f;
+                float sc = (lim > 0.f && fabsf(t) > lim) ? lim * p_rcp(fabsf(t)) : 1.0f;
                 tau[k] = sc * t;
                 aug[k] = m.armature[d0 + k] + sc * (h * kd + h * h * kp);
                 float over = ee[k] > m.limit_hi[d0 + k] ? ee[k] - m.limit_hi[d0 + k] : (ee[k] < m.limit_lo[d0 + k] ? ee[k] - m.limit_lo[d0 + k] : 0.f);
@@ -431,7 +479,7 @@ PARC_HD void substep(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 en
             float kp = m.kp[d0], kd = m.kd[d0];
             float t = kp * (x.tang[i] - x.jang[i] - h * w) - kd * w;
             float lim = m.effort[d0];
-            float sc = (lim > 0.f && fabsf(t) > lim) ? lim / fabsf(t) : 1.0f;
+            float sc = (lim > 0.f && fabsf(t) > lim) ? lim * p_rcp(fabsf(t)) : 1.0f;
             float tau = sc * t;
             float aug = m.armature[d0] + sc * (h * kd + h * h * kp);
             float ang = x.jang[i];
@@ -442,7 +490,7 @@ PARC_HD void substep(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 en
             }
             V3 ua = mul(Ia.A, ax), ul = mulT(Ia.B, ax);
             float D = dot(ax, ua) + aug;
-            float Di = 1.0f / D;
+            float Di = p_rcp(D);
             float u = tau - dot(ax, pa.a);
             s.Ua[i].m[0] = ua.x; s.Ua[i].m[1] = ua.y; s.Ua[i].m[2] = ua.z;
             s.Ul[i].m[0] = ul.x; s.Ul[i].m[1] = ul.y; s.Ul[i].m[2] = ul.z;
@@ -517,16 +565,16 @@ PARC_HD void substep(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 en
     x.root_vel.l = x.root_vel.l + h * s.a[0].l;
     const float wmax = m.max_angular_velocity;
     {
-        float wn = sqrtf(dot(x.root_vel.a, x.root_vel.a));
-        if (wn > wmax) x.root_vel.a = (wmax / wn) * x.root_vel.a;
+        float wn = p_sqrt(dot(x.root_vel.a, x.root_vel.a));
+        if (wn > wmax) x.root_vel.a = (wmax * p_rcp(wn)) * x.root_vel.a;
     }
     x.root_pos = x.root_pos + h * mul(s.R[0], x.root_vel.l);
     x.root_rot = qnormalize(qmul(x.root_rot, exp_to_q(h * x.root_vel.a)));
     for (int i = 1; i < B; ++i) {
         const int jt = m.joint_type[i];
         if (jt == PARC_JOINT_SPHERICAL) {
-            float wn = sqrtf(dot(x.jw[i], x.jw[i]));
-            if (wn > wmax) x.jw[i] = (wmax / wn) * x.jw[i];
+            float wn = p_sqrt(dot(x.jw[i], x.jw[i]));
+            if (wn > wmax) x.jw[i] = (wmax * p_rcp(wn)) * x.jw[i];
             x.jq[i] = qnormalize(qmul(x.jq[i], exp_to_q(h * x.jw[i])));
         } else if (jt == PARC_JOINT_HINGE) {
             x.jw[i].x = clampf(x.jw[i].x, -wmax, wmax);

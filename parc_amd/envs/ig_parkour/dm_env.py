@@ -73,6 +73,7 @@ class DeepMimicEnv:
         self._done_buf = core.done
         self._ray_hfs = core.ray_hfs
         self._ray_xy_points = core.ray_xy_points
+        self._all_ids = torch.arange(self._num_envs, device=self._device, dtype=torch.int64)
 
     # ------------------------------------------------------------------ terrain (reference :118-126,188-356,493-507)
     def build_terrain(self, env_config, terrain_save_path, x_offset=0.0, y_offset=0.0):
@@ -243,6 +244,30 @@ class DeepMimicEnv:
         self._timestep_buf[env_ids] = 0
         self._time_buf[env_ids] = 0.0
         self._done_buf[env_ids] = base_env.DoneFlags.NULL.value
+
+    def sample_reset_all(self):
+        """Candidate (clip, tile, start time) for EVERY env, with fixed shapes and no host round trip (device-side reset:
+        parc_reset_apply keeps them only where an episode ended).  Same distributions as sample_reset."""
+        n = self._num_envs
+        ml = self._motion_lib
+        M = ml.num_motions()
+        if self._demo_mode:
+            motion_ids = self._all_ids % M
+        elif self._one_motion_mode:
+            motion_ids = torch.full_like(self._all_ids, self._selected_motion_id)
+        else:
+            w = ml._motion_weights
+            if not self._ignore_fail_rates:
+                w = torch.clamp(self._motion_id_fail_rates, min=self._min_motion_weight) * w
+            cdf = torch.cumsum(w, dim=0)
+            u = torch.rand(n, device=self._device, dtype=cdf.dtype) * cdf[-1]
+            motion_ids = torch.searchsorted(cdf, u, right=True).clamp_(max=M - 1)      # multinomial with replacement
+        terrain_ids = torch.randint(high=self._terrains_per_motion, size=(n,), dtype=torch.int64, device=self._device)
+        if self._rand_reset:
+            motion_times = ml.sample_time(motion_ids)
+        else:
+            motion_times = ml.get_motion_length(motion_ids) * self._motion_start_time_fraction
+        return motion_ids, terrain_ids, motion_times
 
     # ------------------------------------------------------------------ accessors used by agent / recorder
     def set_rand_root_pos_offset_scale(self, val):

@@ -250,6 +250,42 @@ class IGParkourEnv(base_env.BaseEnv):
         self._update_info()
         return self._obs_buf, self._info
 
+    # ------------------------------------------------------------------ device-side reset of finished envs
+    def supports_device_reset(self):
+        dm = self._dm_env
+        return dm._root_pos_offset is None and dm._root_rot_offset is None and dm._dm_motion_offsets is not None
+
+    def reset_done(self, done=None):
+        """reset(nonzero(done)) without the nonzero: the same state changes as ``reset(env_ids)`` for every env whose
+        done flag is set, as fixed-shape device work (no host sync, capturable in the rollout hipGraph).  Candidates are
+        drawn for all envs and applied where the flag is set (parc_reset_apply), the reference pose / character state /
+        observations of those envs come from masked launches of the post-step kernel."""
+        c, dm, N = self._core, self._dm_env, self._num_envs
+        L = _hip.lib()
+        done = self._done_buf if done is None else done
+        c.reset_mask.copy_(done != base_env.DoneFlags.NULL.value)
+        new_mid, new_tid, new_t = dm.sample_reset_all()
+        offs = dm._dm_motion_offsets
+        assert offs.is_contiguous() and offs.dim() == 3
+        _hip.check(L.parc_reset_apply(_hip.stream(), N, _hip.ptr(c.reset_mask), _hip.ptr(new_mid), _hip.ptr(new_tid),
+                                      _hip.ptr(new_t.contiguous()), _hip.ptr(offs), int(offs.shape[1]), _hip.ptr(c.motion_ids),
+                                      _hip.ptr(c.motion_terrain_ids), _hip.ptr(c.motion_time_offsets), _hip.ptr(c.motion_xy_offset),
+                                      _hip.ptr(c.timestep_buf), _hip.ptr(c.time_buf), _hip.ptr(c.done), _hip.ptr(c.next_target_xy_time),
+                                      _hip.ptr(self._ep_num_buf)), "parc_reset_apply")
+        sc = dm._rand_root_pos_offset_scale
+        if sc != 0.0:
+            c.init_noise_xy.uniform_(-sc, sc)
+        else:
+            c.init_noise_xy.zero_()
+        c.post_step(_hip.POST_REF | _hip.POST_INIT_CHAR | _hip.POST_MASKED)
+        _hip.check(L.parc_sim_refresh_bodies_masked(_hip.stream(), self._sim_model.device_ptr(self._device), N, _hip.ptr(c.reset_mask),
+                                                    _hip.ptr(c.root_state), _hip.ptr(c.dof_state), _hip.ptr(c.rigid_body_state),
+                                                    _hip.ptr(c.contact_forces)), "parc_sim_refresh_bodies_masked")
+        self._update_motion_targets()
+        c.post_step(_hip.POST_OBS | _hip.POST_HF | _hip.POST_MASKED)
+        self._update_info()
+        return self._obs_buf, self._info
+
     # ------------------------------------------------------------------ step (ig_env.py:68-86,839-848)
     def step(self, action):
         c = self._core

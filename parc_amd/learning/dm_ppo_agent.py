@@ -237,32 +237,39 @@ class DMPPOAgent(torch.nn.Module):
         done_indices = (done != base_env.DoneFlags.NULL.value).nonzero(as_tuple=False).flatten()
         return self._env.reset(done_indices)
 
-    def _train_step_body(self):
+    def _train_step_body(self, device_reset=False):
         action, action_info = self._decide_action(self._curr_obs, self._curr_info)
         self._record_data_pre_step(self._curr_obs, self._curr_info, action, action_info)
         next_obs, r, done, next_info = self._env.step(action)
         self._train_return_tracker.update(next_info, done)
         self._record_data_post_step(next_obs, r, done, next_info)
+        if device_reset:
+            # finished envs restart on the device (masked kernels): no nonzero(), the step stays sync-free
+            self._curr_obs, self._curr_info = self._env.reset_done(done)
         return done
+
+    def _device_reset_ok(self):
+        env = self._env
+        return self._graph_ok() and hasattr(env, "reset_done") and env.supports_device_reset()
 
     def _graph_ok(self):
         env = self._env
         return (self._use_hip_graph and self._mode == AgentMode.TRAIN and not getattr(env, "_write_agent_states_flag", False)
                 and hasattr(env, "_char_contact_forces") and getattr(getattr(env, "_core", None), "timing_events", None) is None)
 
-    def _train_step_graph(self):
+    def _train_step_graph(self, device_reset=False):
         """One rollout step through a captured hipGraph (torch.cuda.CUDAGraph = hipGraph on ROCm).  Graphs are keyed by
         the host-side branches inside the step; step inputs are the env's persistent buffers, the write row of the
         experience buffer is the device scalar ``_head_t``."""
         eb = self._exp_buffer
         exp_prob = self._get_exp_prob()
-        key = (self._need_normalizer_update(), exp_prob >= 1.0)
+        key = (self._need_normalizer_update(), exp_prob >= 1.0, device_reset)
         self._head_t.fill_(eb._buffer_head)
         g = self._graphs.get(key)
         if g is None:
             if self._graph_warm < 2:                 # library handles / workspaces are created by eager steps first
                 self._graph_warm += 1
-                return self._train_step_body()
+                return self._train_step_body(device_reset)
             eb.set_device_head(self._head_t)
             self._in_graph_step = True
             count0 = self._obs_norm._new_count
@@ -270,7 +277,7 @@ class DMPPOAgent(torch.nn.Module):
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=self._graph_pool):
-                    done = self._train_step_body()
+                    done = self._train_step_body(device_reset)
                 if self._graph_pool is None:
                     self._graph_pool = g.pool()
             finally:
@@ -287,8 +294,14 @@ class DMPPOAgent(torch.nn.Module):
 
     def _rollout_train(self, num_steps):
         for _ in range(num_steps):
-            done = self._train_step_graph() if self._graph_ok() else self._train_step_body()
-            self._curr_obs, self._curr_info = self._reset_done_envs(done)
+            if self._graph_ok():
+                dev_reset = self._device_reset_ok()
+                done = self._train_step_graph(dev_reset)
+            else:
+                dev_reset = False
+                done = self._train_step_body()
+            if not dev_reset:
+                self._curr_obs, self._curr_info = self._reset_done_envs(done)
             self._exp_buffer.inc()
 
     def _rollout_test(self, num_episodes):

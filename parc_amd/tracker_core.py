@@ -149,6 +149,9 @@ class TrackerCore:
         self.next_target_xy_time = z((N,), **f32)
         self.done = z((N,), dtype=torch.int, device=device)
         self.done_kind = z((N,), dtype=torch.int, device=device)
+        # device-side reset (PARC_POST_MASKED / PARC_POST_INIT_CHAR)
+        self.reset_mask = z((N,), dtype=torch.int, device=device)
+        self.init_noise_xy = z((N, 2), **f32)
         self.ray_xy_points = ray_xy_points.to(device=device, dtype=torch.float32).contiguous()
         P = self.ray_xy_points.shape[0]
         assert P == cfg.struct.num_ray_points
@@ -174,7 +177,8 @@ class TrackerCore:
                 p(self.target_xy),
                 p(self.ref_root_pos), p(self.ref_root_rot), p(self.ref_root_vel), p(self.ref_root_ang_vel),
                 p(self.ref_joint_rot), p(self.ref_dof_vel), p(self.ref_dof_pos), p(self.ref_contacts), p(self.ref_body_pos),
-                p(self.obs), p(self.reward), p(self.reward_terms), p(self.done), p(self.done_kind))
+                p(self.obs), p(self.reward), p(self.reward_terms), p(self.done), p(self.done_kind),
+                p(self.reset_mask), p(self.init_noise_xy))
         return self._buf_struct
 
     # ---- K5 (IGParkourEnv._refresh_obs_hfs)

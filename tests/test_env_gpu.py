@@ -163,3 +163,57 @@ def test_graph_rollout_matches_eager_bookkeeping(env):
     # the captured graph survives a full training iteration (update changes the weights in place)
     info = agent._train_iter()
     assert np.isfinite(info["mean_return"]) and len(agent._graphs) == 1
+
+
+def _snapshot(env):
+    c = env._core
+    names = ["root_state", "dof_state", "rigid_body_state", "contact_forces", "motion_ids", "motion_terrain_ids", "motion_time_offsets",
+             "motion_xy_offset", "time_buf", "timestep_buf", "done", "obs", "ref_root_pos", "ref_root_rot", "ref_joint_rot", "ref_dof_pos",
+             "ref_dof_vel", "ref_body_pos", "ref_contacts", "next_target_xy_time", "target_xy"]
+    d = {n: getattr(c, n).clone() for n in names}
+    d["ep_num"] = env._ep_num_buf.clone()
+    return d
+
+
+def _restore(env, snap):
+    c = env._core
+    for n, v in snap.items():
+        (env._ep_num_buf if n == "ep_num" else getattr(c, n)).copy_(v)
+
+
+def test_device_reset_equals_indexed_reset(env):
+    """reset_done(done) (masked kernels, no host sync) must leave exactly the state reset(nonzero(done)) leaves when both
+    draw the same clip / start time: demo mode + fixed start fraction + no root noise make the draw deterministic."""
+    dm = env._dm_env
+    env.reset()
+    act = torch.zeros((96, 28), device=DEV)
+    for _ in range(3):
+        env.step(act)
+    old = (dm._demo_mode, dm._rand_reset, dm._rand_root_pos_offset_scale)
+    dm._demo_mode, dm._rand_reset, dm._rand_root_pos_offset_scale = True, False, 0.0
+    dm._motion_start_time_fraction[:] = torch.linspace(0.05, 0.6, 96, device=DEV)
+    try:
+        done = torch.zeros(96, dtype=torch.int32, device=DEV)
+        done[[0, 3, 4, 5, 6, 7, 31, 64, 95]] = torch.tensor([1, 1, 3, 1, 1, 2, 1, 3, 1], dtype=torch.int32, device=DEV)
+        env._done_buf.copy_(done)
+        snap = _snapshot(env)
+        torch.manual_seed(5)
+        env.reset(done.nonzero().flatten())
+        a = _snapshot(env)
+        _restore(env, snap)
+        torch.manual_seed(5)
+        assert env.supports_device_reset()
+        env.reset_done(env._done_buf)
+        b = _snapshot(env)
+    finally:
+        dm._demo_mode, dm._rand_reset, dm._rand_root_pos_offset_scale = old
+        dm._motion_start_time_fraction.zero_()
+    ids = done.nonzero().flatten()
+    assert torch.all(b["timestep_buf"][ids] == 0) and torch.all(b["done"][ids] == 0) and torch.equal(b["ep_num"][ids], snap["ep_num"][ids] + 1)
+    for n in a:
+        if n in ("target_xy", "next_target_xy_time"):       # drawn from the RNG in a different order
+            continue
+        assert torch.equal(a[n], b[n]), n
+    keep = done == 0
+    for n in ("root_state", "dof_state", "obs", "motion_ids", "time_buf", "ref_root_pos"):
+        assert torch.equal(b[n].reshape(96, -1)[keep], snap[n].reshape(96, -1)[keep]), n

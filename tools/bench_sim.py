@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Simulator step kernel timing vs lanes per workgroup (run on the GPU box)."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from parc_amd import _hip, workloads
+
+dev = "cuda:0"
+env, clips, tiled = workloads.build_env("boxes_64clips", 4096, dev, seed=0)
+env.reset()
+a = torch.zeros((4096, 28), device=dev)
+L = _hip.lib()
+for th in (64, 32, 16, 8):
+    L.parc_tune_sim_threads(th)
+    for _ in range(3):
+        env.step(a)
+    torch.cuda.synchronize()
+    c = env._core
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(20):
+        L.parc_sim_step(_hip.stream(), env._sim_model.device_ptr(dev), c._terrain_struct, 4096, _hip.ptr(c.root_state), _hip.ptr(c.dof_state),
+                        _hip.ptr(c.rigid_body_state), _hip.ptr(c.contact_forces), _hip.ptr(c.env_offsets), _hip.ptr(a),
+                        _hip.ptr(env._action_bound_low), _hip.ptr(env._action_bound_high), env._sim_steps * env._substeps, env._sim_h)
+    e.record()
+    torch.cuda.synchronize()
+    print(json.dumps({"sim_threads": th, "us_per_step": s.elapsed_time(e) * 1e3 / 20}))
+    env.reset()
