@@ -82,6 +82,50 @@ class DistributionGaussianDiagBuilder(torch.nn.Module):
 _NETS = {"fc_3layers_2048units": [2048, 1024, 512], "fc_3layers_1024units": [1024, 1024, 512], "fc_2layers_1024units": [1024, 512]}
 
 
+class _LinearReLU(torch.autograd.Function):
+    """relu(x W^T + b) with the bias + ReLU applied in the GEMM epilogue (hipBLASLt RELU_BIAS through
+    torch._addmm_activation), so the forward pass writes the activation once instead of GEMM output + clamp.  The op
+    has no registered derivative in torch 2.10, hence the explicit backward (the same three kernels autograd uses)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = torch._addmm_activation(bias, x, weight.t(), use_gelu=False)
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        g = torch.ops.aten.threshold_backward(gy, y, 0.0)
+        gx = g.mm(weight) if ctx.needs_input_grad[0] else None
+        gw = g.t().mm(x) if ctx.needs_input_grad[1] else None
+        gb = g.sum(dim=0) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+class FusedMLP(torch.nn.Sequential):
+    """Sequential(Linear, ReLU, Linear, ReLU, ...) with the reference's parameter names (``0.weight``, ``2.weight`` ...);
+    on the GPU every Linear+ReLU pair runs as one fused GEMM."""
+
+    def forward(self, x):
+        mods = list(self)
+        if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
+            return super().forward(x)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, torch.nn.Linear) and i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.ReLU):
+                if torch.is_grad_enabled() and (x.requires_grad or m.weight.requires_grad):
+                    x = _LinearReLU.apply(x, m.weight, m.bias)
+                else:
+                    x = torch._addmm_activation(m.bias, x, m.weight.t(), use_gelu=False)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
 def build_net(name, in_size, activation):
     if name not in _NETS:
         raise NotImplementedError("net '{}' (the tracker default is fc_3layers_2048units)".format(name))
@@ -91,7 +135,7 @@ def build_net(name, in_size, activation):
         torch.nn.init.zeros_(lin.bias)
         layers += [lin, activation()]
         in_size = out_size
-    return torch.nn.Sequential(*layers), in_size
+    return FusedMLP(*layers), in_size
 
 
 class DMPPOModel(torch.nn.Module):
