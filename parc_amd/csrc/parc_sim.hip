@@ -1,6 +1,7 @@
 // Device entry points of the articulated-body simulator: one env per lane, 64 envs per workgroup.
 #include <hip/hip_runtime.h>
 
+#include "parc_sim_bpl.h"
 #include "parc_sim_core.h"
 
 #define SIM_THREADS 64
@@ -18,6 +19,31 @@ __global__ __launch_bounds__(SIM_THREADS) void sim_step_kernel(const parc_sim_mo
     parc_sim::env_step(m, ter, env_offsets + 3 * (size_t)e, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e,
                        rigid_body_state + 13 * (size_t)B * e, contact_forces + 3 * (size_t)B * e, action + (size_t)D * e, act_lo, act_hi,
                        n_sub, h, s);
+}
+
+// body-per-lane step: 16 lanes per env, 4 envs per 64-thread workgroup (parc_sim_bpl.h)
+__global__ __launch_bounds__(64) void sim_step_bpl_kernel(const parc_sim_model_t *__restrict__ model, parc_terrain_t ter, int n_envs,
+                                                          float *root_state, float *dof_state, float *rigid_body_state,
+                                                          float *contact_forces, const float *__restrict__ env_offsets,
+                                                          const float *__restrict__ action, const float *__restrict__ act_lo,
+                                                          const float *__restrict__ act_hi, int n_sub, float h) {
+    using namespace parc_sim_bpl;
+    __shared__ float lds[BPL_EPB][BPL_G * BPL_CONTRIB];
+    const int g = threadIdx.x / BPL_G, b = threadIdx.x % BPL_G;
+    const int e = min((int)blockIdx.x * BPL_EPB + g, n_envs - 1);      // tail groups recompute the last env (same values)
+    const parc_sim_model_t &m = *model;
+    const int B = m.num_bodies, D = m.dof_size;
+    const Lane L = load_lane(m, b);
+    int maxd = L.depth;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) maxd = max(maxd, __shfl_xor(maxd, o, BPL_G));
+    LState x;
+    load_lane_state(m, L, b, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e, action + (size_t)D * e, act_lo, act_hi, x);
+    const parc_sim::V3 off = parc_sim::ld(env_offsets + 3 * (size_t)e);
+    const float w = 1.0f / (float)n_sub;
+    for (int s = 0; s < n_sub; ++s) substep(m, ter, off, L, b, maxd, x, h, w, lds[g]);
+    store_lane_state(L, b, maxd, x, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e, rigid_body_state + 13 * (size_t)B * e,
+                     contact_forces + 3 * (size_t)B * e);
 }
 
 __global__ __launch_bounds__(SIM_THREADS) void sim_refresh_kernel(const parc_sim_model_t *__restrict__ model, int n, const int64_t *__restrict__ env_ids,
@@ -44,6 +70,14 @@ __global__ __launch_bounds__(SIM_THREADS) void sim_refresh_kernel(const parc_sim
 // envs (= lanes) per workgroup of the step kernel: 4096 envs are only 64 full waves on a 1024-SIMD chip, so partially
 // filled waves on more CUs can win; tuning knob, not part of the stable ABI
 static int g_sim_threads = SIM_THREADS;
+// 1 = body-per-lane kernel (default), 0 = one env per lane (the single-source reference core)
+static int g_sim_variant = 1;
+static const int model_bodies_hint = PARC_SIM_MAX_BODIES;      // PARC_SIM_MAX_BODIES == lanes per env
+extern "C" int parc_tune_sim_variant(int v) {
+    if (v != 0 && v != 1) return PARC_EINVAL;
+    g_sim_variant = v;
+    return PARC_OK;
+}
 extern "C" int parc_tune_sim_threads(int t) {
     if (t != 8 && t != 16 && t != 32 && t != 64) return PARC_EINVAL;
     g_sim_threads = t;
@@ -55,6 +89,12 @@ extern "C" int parc_sim_step(void *stream, const parc_sim_model_t *model, parc_t
                              const float *action, const float *action_low, const float *action_high, int n_substeps, float h) {
     if (!model || n_envs < 0 || n_substeps <= 0 || !(h > 0.f) || !terrain.hf) return PARC_EINVAL;
     if (n_envs == 0) return PARC_OK;
+    if (g_sim_variant == 1 && model_bodies_hint <= BPL_G) {
+        hipLaunchKernelGGL(sim_step_bpl_kernel, dim3((n_envs + BPL_EPB - 1) / BPL_EPB), dim3(64), 0, (hipStream_t)stream, model, terrain, n_envs,
+                           root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low, action_high, n_substeps, h);
+        hipError_t e1 = hipGetLastError();
+        return e1 == hipSuccess ? PARC_OK : (int)e1;
+    }
     const int th = g_sim_threads;
     hipLaunchKernelGGL(sim_step_kernel, dim3((n_envs + th - 1) / th), dim3(th), 0, (hipStream_t)stream, model,
                        terrain, n_envs, root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low,

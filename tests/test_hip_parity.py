@@ -310,16 +310,18 @@ def test_full_size_properties(km, mlib):
     assert torch.allclose(ret1, r + 0.99 * v, atol=1e-5)
 
 
-def test_sim_device_matches_host_build(km):
-    """The simulator kernel against the HOST build of the same source (oracle/sim_host.cpp): a few env steps of
-    random actions on a bumpy terrain, 64 envs.  fp32 with different libm / contraction: tolerance 1e-3 after
-    3 steps (contacts make the dynamics locally stiff)."""
+@pytest.mark.parametrize("variant,n", [(1, 64), (1, 61), (0, 64)])
+def test_sim_device_matches_host_build(km, variant, n):
+    """Both simulator kernels -- body per lane (variant 1, the default: parc_sim_bpl.h) and one env per lane (variant 0, the
+    single-source core) -- against the HOST build of that core (oracle/sim_host.cpp): a few env steps of random actions
+    on a bumpy terrain; n = 61 leaves a partially filled last workgroup.  fp32 with different libm / contraction /
+    summation order: tolerance 1e-3 after 3 steps (contacts make the dynamics locally stiff)."""
     from parc_amd import _hip
     from parc_amd.sim_model import SimModel
     from oracle.sim_host import HostSim
     rng = np.random.default_rng(2)
     sm = SimModel(km)
-    n = 64
+    assert _hip.lib().parc_tune_sim_variant(variant) == 0
     hf = (rng.random((40, 40)) * 0.3).astype(np.float32)
     host = HostSim(sm.struct, n, hf, [-4.0, -4.0], [0.4, 0.4])
     host.root_state[:, 0:2] = rng.random((n, 2)) * 6.0
@@ -341,7 +343,11 @@ def test_sim_device_matches_host_build(km):
         _hip.check(L.parc_sim_step(_hip.stream(), sm.device_ptr(DEV), ter, n, _hip.ptr(rs), _hip.ptr(ds), _hip.ptr(rb), _hip.ptr(cf),
                                    _hip.ptr(eo), _hip.ptr(a), _hip.ptr(lo), _hip.ptr(hi), 4, 1.0 / 120.0), "parc_sim_step")
         torch.cuda.synchronize()
+    L.parc_tune_sim_variant(1)
     assert torch.isfinite(rs).all() and torch.isfinite(ds).all()
+    assert float(np.abs(host.contact_forces).max()) > 10.0           # the scene does have contacts
+    close(cf, host.contact_forces, atol=2.0, rtol=2e-2)                # N; forces are stiff in the penetration depth
+    close(rb[..., 3:7], host.rigid_body_state[..., 3:7], atol=2e-3)
     close(rs[:, 0:7], host.root_state[:, 0:7], atol=1e-3)
     close(rs[:, 7:13], host.root_state[:, 7:13], atol=2e-2)
     close(ds[..., 0], host.dof_state[..., 0], atol=2e-3)

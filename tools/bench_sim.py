@@ -10,8 +10,10 @@ env, clips, tiled = workloads.build_env("boxes_64clips", 4096, dev, seed=0)
 env.reset()
 a = torch.zeros((4096, 28), device=dev)
 L = _hip.lib()
-for th in (64, 32, 16, 8):
-    L.parc_tune_sim_threads(th)
+for th in (64, 32, 0):
+    L.parc_tune_sim_variant(0 if th else 1)      # 0 -> body-per-lane kernel
+    if th:
+        L.parc_tune_sim_threads(th)
     for _ in range(3):
         env.step(a)
     torch.cuda.synchronize()
@@ -24,5 +26,6 @@ for th in (64, 32, 16, 8):
                         _hip.ptr(env._action_bound_low), _hip.ptr(env._action_bound_high), env._sim_steps * env._substeps, env._sim_h)
     e.record()
     torch.cuda.synchronize()
-    print(json.dumps({"sim_threads": th, "us_per_step": s.elapsed_time(e) * 1e3 / 20}))
+    print(json.dumps({"kernel": "one env per lane, %d lanes/workgroup" % th if th else "body per lane (16 lanes/env)",
+                      "us_per_step": s.elapsed_time(e) * 1e3 / 20}))
     env.reset()
