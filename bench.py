@@ -165,6 +165,56 @@ def main():
     kern_b2b_us = s.elapsed_time(e) * 1e3 / 200
     alg_bytes = N * POST_STEP_BYTES_PER_ENV
     achieved = alg_bytes / (kern_b2b_us * 1e-6) / 1e9
+    # HBM traffic per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE, gfx950-corrected), valid
+    # for exactly this workload and env count; null otherwise (counters cannot be read from inside this process)
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "r01_post_step_pmc_traffic.json")
+    if args.workload == "boxes_64clips" and os.path.exists(tp):
+        with open(tp) as f:
+            tj = json.load(f)
+        if tj.get("envs") == N:
+            traffic = tj["traffic_bytes_corrected"]
+
+    def time_launches(fn, iters):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e3 / iters
+
+    extra = []
+    if rank == 0:
+        # the other hand-written kernels of the step, same HIP-event timing (context for the roofline object)
+        c, L = env._core, _hip.lib()
+        P = c.ray_xy_points.shape[0]
+        for nn in (N, 65536):
+            obs_big = c.obs if nn == N else torch.zeros((nn, c.cfg.obs_dim), device=dev)
+            rs_big = c.root_state if nn == N else c.root_state.repeat((nn + N - 1) // N, 1)[:nn].contiguous()
+            eo_big = c.env_offsets if nn == N else c.env_offsets.repeat((nn + N - 1) // N, 1)[:nn].contiguous()
+            dst = _hip.c_vp(obs_big.data_ptr() + 4 * (c.cfg.obs_dim - P))
+            us = time_launches(lambda: L.parc_refresh_obs_hfs(_hip.stream(), nn, _hip.ptr(c.ray_xy_points), P, _hip.ptr(rs_big), _hip.ptr(eo_big),
+                                                               c._terrain_struct, c.cfg.struct.min_obs_h, c.cfg.struct.max_obs_h, dst,
+                                                               c.cfg.obs_dim), 200 if nn == N else 50)
+            byts = nn * 3544
+            extra.append({"kernel": "hf_gather_kernel (K5 alone)", "envs": nn, "us_per_launch": us, "bound": "hbm", "algorithmic_bytes": byts,
+                          "achieved_GBps": byts / us / 1e3, "frac_of_peak": byts / us / 1e3 / HBM_PEAK_GBPS})
+            del obs_big, rs_big, eo_big
+        act = torch.zeros((N, env._sim_model.struct.dof_size), device=dev)
+        state = (c.root_state.clone(), c.dof_state.clone())
+        us = time_launches(lambda: L.parc_sim_step(_hip.stream(), env._sim_model.device_ptr(dev), c._terrain_struct, N, _hip.ptr(c.root_state),
+                                                   _hip.ptr(c.dof_state), _hip.ptr(c.rigid_body_state), _hip.ptr(c.contact_forces),
+                                                   _hip.ptr(c.env_offsets), _hip.ptr(act), _hip.ptr(env._action_bound_low),
+                                                   _hip.ptr(env._action_bound_high), env._sim_steps * env._substeps, env._sim_h), 20)
+        c.root_state.copy_(state[0])
+        c.dof_state.copy_(state[1])
+        extra.append({"kernel": "sim_step_bpl_kernel (articulated-body step, {} substeps)".format(env._sim_steps * env._substeps), "envs": N,
+                      "us_per_launch": us, "bound": "instruction latency (serial tree sweeps); state traffic 1624 B/env",
+                      "achieved_GBps": N * 1624 / us / 1e3})
 
     if rank == 0:
         total_env_steps = world * N * T * args.steps
@@ -187,11 +237,12 @@ def main():
                        "minibatch": agent._batch_size * N, "sim_substeps": env._sim_steps * env._substeps, "parallelism": "dp{}".format(world),
                        "grad_allreduce": "per minibatch (reference cadence)"},
             "roofline": {"kernel": "track_post_kernel (fused K5 heightmap gather + K3 K2 K4 K6-K10)", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": kern_b2b_us,
                          "us_per_launch_event_pairs_in_rollout_loop": kern_us, "launches_event_timed": len(evs)},
             "rollout": ("one hipGraph replay per env step" + (", finished envs reset on the device inside the graph" if any(k[2] for k in agent._graphs)
                                                                else " + eager reset of finished envs")) if agent._graphs else "eager",
+            "kernels": extra,
             "rollout_env_steps_per_s": world * N * T * args.steps / max(rollout_s[0], 1e-9),
             "rollout_fraction_of_time": rollout_s[0] / elapsed,
             "mean_episode_return": info["mean_return"] if info else None,

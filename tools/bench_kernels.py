@@ -136,6 +136,8 @@ def bench_post_step(n, iters):
 
 if __name__ == "__main__":
     if "--post" in sys.argv:
-        bench_post_step(4096, 300)
+        ns = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--envs=")] or [4096]
+        for nn in ns:
+            bench_post_step(nn, 300 if nn <= 8192 else 60)
         sys.exit(0)
     main()
