@@ -219,6 +219,22 @@ int parc_td_lambda_return(void *stream, int T, int N, const float *reward, const
 int parc_adv_normalize(void *stream, int n, const float *ret, const float *vals, const float *rand_action_mask,
                        float clip, float *norm_adv, float *mean_std_out /* [2] */, double *workspace);
 
+/* ---- PPO loss + gradient in one pass: PPOAgent._compute_loss  learning/ppo_agent.py:186-330 (diagonal Gaussian policy with a
+ * state-independent log-std; masked means over rand_action_mask == 1; clip / action-bound / entropy / mean-regulariser terms;
+ * L2 or L1 critic loss; the "large critic loss" guard that stops the actor gradient).
+ * mean, norm_a [B,A]; logstd [A]; old_logp, adv, mask, pred, tar_val [B].
+ * Outputs: g_mean [B,A] = dloss/dmean, g_logstd [A], g_pred [B];
+ * out[11] = loss, critic_loss, actor_loss, clip_frac, imp_ratio, action_bound_loss, entropy, reg_loss, cnt, (2 scale factors).
+ * workspace: parc_ppo_workspace_floats(B) floats. */
+typedef struct {
+    float clip_ratio, bound_w, entropy_w, reg_w, critic_w, large_critic_loss;
+    int32_t critic_l1;
+} parc_ppo_cfg_t;
+int parc_ppo_loss(void *stream, int B, int A, const float *mean, const float *logstd, const float *norm_a, const float *old_logp,
+                  const float *adv, const float *mask, const float *pred, const float *tar_val, parc_ppo_cfg_t cfg, float *g_mean,
+                  float *g_logstd, float *g_pred, float *out, float *workspace);
+int parc_ppo_workspace_floats(int B);
+
 int parc_abi_version(void);
 
 #ifdef __cplusplus

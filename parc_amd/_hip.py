@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libparc_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["parc_kin.hip", "parc_sim.hip"]
+SOURCES = ["parc_kin.hip", "parc_sim.hip", "parc_ppo.hip"]
 
 MAX_BODIES = 16
 MAX_DOFS = 64
@@ -81,6 +81,11 @@ class EnvBuffersS(ctypes.Structure):
                 ("env_mask", c_vp), ("init_noise_xy", c_vp)]
 
 
+class PPOCfgS(ctypes.Structure):
+    _fields_ = [("clip_ratio", c_f), ("bound_w", c_f), ("entropy_w", c_f), ("reg_w", c_f), ("critic_w", c_f),
+                ("large_critic_loss", c_f), ("critic_l1", c_i32)]
+
+
 _lib = None
 
 
@@ -140,6 +145,10 @@ def _declare(L):
     L.parc_update_fail_rates.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_vp]
     L.parc_td_lambda_return.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_f, c_f, c_vp]
     L.parc_adv_normalize.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp]
+    L.parc_ppo_loss.argtypes = [c_vp, c_int, c_int] + [c_vp] * 8 + [PPOCfgS] + [c_vp] * 5
+    L.parc_ppo_loss.restype = c_int
+    L.parc_ppo_workspace_floats.argtypes = [c_int]
+    L.parc_ppo_workspace_floats.restype = c_int
     L.parc_reset_apply.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int] + [c_vp] * 9
     L.parc_reset_apply.restype = c_int
     for name in ("parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
@@ -153,7 +162,7 @@ def _declare(L):
 
 EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
             "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step",
-            "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize", "parc_reset_apply"]
+            "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize", "parc_reset_apply", "parc_ppo_loss", "parc_ppo_workspace_floats"]
 
 
 def check(rc, what):

@@ -1,0 +1,161 @@
+// PPO surrogate + critic loss of the tracker agent with its gradient in one pass (gfx950).
+// Restates PPOAgent._compute_loss / DMPPOAgent (learning/ppo_agent.py:186-330, learning/dm_ppo_agent.py) for a diagonal
+// Gaussian policy with state-independent log-std: the ~120 small elementwise / reduction launches of the autograd
+// graph between the two MLP outputs and the scalar loss become three launches with a deterministic reduction order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/parc_hip.h"
+
+#define PPO_THREADS 256
+#define PPO_MAX_A 64
+#define PPO_NSCAL 8      // cnt_raw, critic_sum, surr_sum, clip_sum, ratio_sum, viol_sum, reg_sum, (spare)
+#define PPO_W (PPO_NSCAL + PPO_MAX_A)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// pass 1: one thread per sample.  Unscaled gradients (the 1/cnt and gate factors are only known after the reduction).
+__global__ __launch_bounds__(PPO_THREADS) void ppo_sample_kernel(int B, int A, const float *__restrict__ mean, const float *__restrict__ logstd,
+                                                                 const float *__restrict__ norm_a, const float *__restrict__ old_logp,
+                                                                 const float *__restrict__ adv, const float *__restrict__ mask,
+                                                                 const float *__restrict__ pred, const float *__restrict__ tar_val,
+                                                                 parc_ppo_cfg_t cfg, float *g_mean, float *g_pred, float *ws) {
+    __shared__ float s_istd[PPO_MAX_A];
+    __shared__ float s_part[PPO_THREADS / 64][PPO_W];
+    const int tid = threadIdx.x, i = blockIdx.x * PPO_THREADS + tid;
+    float sum_logstd = 0.f;
+    if (tid < A) s_istd[tid] = __expf(-logstd[tid]);       // std^-1 = exp(-logstd)
+    __syncthreads();
+    for (int j = 0; j < A; ++j) sum_logstd += logstd[j];
+    const bool live = i < B;
+    const int ii = live ? i : 0;
+    const float m = live ? (mask[ii] == 1.0f ? 1.f : 0.f) : 0.f;
+    const float *mu = mean + (size_t)ii * A, *ac = norm_a + (size_t)ii * A;
+    float zz = 0.f, viol = 0.f, reg = 0.f;
+    for (int j = 0; j < A; ++j) {
+        float mj = mu[j];
+        float z = (ac[j] - mj) * s_istd[j];
+        zz = fmaf(z, z, zz);
+        float vmin = fminf(mj + 1.0f, 0.f), vmax = fmaxf(mj - 1.0f, 0.f);
+        viol += vmin * vmin + vmax * vmax;
+        reg = fmaf(mj, mj, reg);
+    }
+    const float logp = -0.5f * zz + (-0.5f * (float)A * 1.8378770664093453f - sum_logstd);     // log(2 pi)
+    const float ratio = __expf(logp - old_logp[ii]);
+    const float ad = adv[ii];
+    const float lo = 1.0f - cfg.clip_ratio, hi = 1.0f + cfg.clip_ratio;
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const float l0 = ad * ratio, l1 = ad * rc;
+    const float surr = fminf(l0, l1);
+    // d surr / d ratio: torch.minimum sends the gradient to l0 when l0 <= l1, else to l1, whose clamp passes it inside [lo, hi]
+    const float dsurr = (l0 <= l1) ? ad : ((ratio >= lo && ratio <= hi) ? ad : 0.f);
+    const float c = -m * dsurr * ratio;                       // d(-sum m surr)/d logp_i   (x 1/cnt later)
+    const float diff = tar_val[ii] - pred[ii];
+    if (live) {
+        g_pred[i] = cfg.critic_l1 ? (diff > 0.f ? -1.f : (diff < 0.f ? 1.f : 0.f)) : -2.0f * diff;
+        float *gm = g_mean + (size_t)i * A;
+        for (int j = 0; j < A; ++j) {
+            float mj = mu[j];
+            float z = (ac[j] - mj) * s_istd[j];
+            float vmin = fminf(mj + 1.0f, 0.f), vmax = fmaxf(mj - 1.0f, 0.f);
+            gm[j] = c * z * s_istd[j] + m * (cfg.bound_w * 2.0f * (vmin + vmax) + cfg.reg_w * 2.0f * mj);
+        }
+    }
+    // block partials, fixed order: lanes -> waves -> block
+    float sc[PPO_NSCAL];
+    sc[0] = m;
+    sc[1] = live ? (cfg.critic_l1 ? fabsf(diff) : diff * diff) : 0.f;
+    sc[2] = m * surr;
+    sc[3] = m * (fabsf(ratio - 1.0f) > cfg.clip_ratio ? 1.f : 0.f);
+    sc[4] = m * ratio;
+    sc[5] = m * viol;
+    sc[6] = m * reg;
+    sc[7] = 0.f;
+    const int wv = tid >> 6, ln = tid & 63;
+#pragma unroll
+    for (int k = 0; k < PPO_NSCAL; ++k) {
+        float v = wave_sum(sc[k]);
+        if (ln == 0) s_part[wv][k] = v;
+    }
+    for (int j = 0; j < A; ++j) {
+        float z = live ? (ac[j] - mu[j]) * s_istd[j] : 0.f;
+        float v = wave_sum(c * (z * z - 1.0f));               // d logp / d logstd_j = z^2 - 1
+        if (ln == 0) s_part[wv][PPO_NSCAL + j] = v;
+    }
+    __syncthreads();
+    if (tid < PPO_NSCAL + A) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < PPO_THREADS / 64; ++w) v += s_part[w][tid];
+        ws[(size_t)blockIdx.x * PPO_W + tid] = v;
+    }
+}
+
+// pass 2: one small block reduces the block partials in order and produces the scalars, the log-std gradient and the scale factors
+__global__ __launch_bounds__(128) void ppo_reduce_kernel(int B, int A, int nblk, const float *__restrict__ logstd, parc_ppo_cfg_t cfg,
+                                                         const float *__restrict__ ws, float *g_logstd, float *out) {
+    __shared__ float s[PPO_W];
+    const int tid = threadIdx.x;
+    if (tid < PPO_NSCAL + A) {
+        double v = 0.0;
+        for (int b = 0; b < nblk; ++b) v += (double)ws[(size_t)b * PPO_W + tid];
+        s[tid] = (float)v;
+    }
+    __syncthreads();
+    const float msum = s[0];
+    const float cnt = fmaxf(msum, 1.0f);
+    const float critic_loss = s[1] / (float)B;
+    float sum_logstd = 0.f;
+    for (int j = 0; j < A; ++j) sum_logstd += logstd[j];
+    const float ent = (sum_logstd + 0.5f * (float)A * 2.8378770664093453f) * (msum / cnt);     // log(2 pi e)
+    const float abl = s[5] / cnt, regl = s[6] / cnt;
+    float actor_loss = -s[2] / cnt;
+    if (cfg.bound_w != 0.f) actor_loss += cfg.bound_w * abl;
+    if (cfg.entropy_w != 0.f) actor_loss -= cfg.entropy_w * ent;
+    if (cfg.reg_w != 0.f) actor_loss += cfg.reg_w * regl;
+    // "LARGE CRITIC LOSS" guard (ppo_agent.py:225-238): the actor term gives no gradient while the critic is off
+    const float gate = critic_loss > cfg.large_critic_loss ? 0.f : 1.f;
+    if (tid < A) g_logstd[tid] = gate * (s[PPO_NSCAL + tid] / cnt - cfg.entropy_w * (msum / cnt));
+    if (tid == 0) {
+        out[0] = actor_loss + cfg.critic_w * critic_loss;
+        out[1] = critic_loss;
+        out[2] = actor_loss;
+        out[3] = s[3] / cnt;
+        out[4] = s[4] / cnt;
+        out[5] = abl;
+        out[6] = ent;
+        out[7] = regl;
+        out[8] = cnt;
+        out[9] = gate / cnt;                         // scale of g_mean
+        out[10] = cfg.critic_w / (float)B;           // scale of g_pred
+    }
+}
+
+// pass 3: apply the scale factors
+__global__ __launch_bounds__(256) void ppo_scale_kernel(int n_mean, int n_pred, const float *__restrict__ out, float *g_mean, float *g_pred) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float sa = out[9], sp = out[10];
+    if (i < n_mean) g_mean[i] *= sa;
+    if (i < n_pred) g_pred[i] *= sp;
+}
+
+extern "C" int parc_ppo_loss(void *stream, int B, int A, const float *mean, const float *logstd, const float *norm_a, const float *old_logp,
+                             const float *adv, const float *mask, const float *pred, const float *tar_val, parc_ppo_cfg_t cfg, float *g_mean,
+                             float *g_logstd, float *g_pred, float *out, float *workspace) {
+    if (B <= 0 || A <= 0 || A > PPO_MAX_A) return PARC_EINVAL;
+    const int nblk = (B + PPO_THREADS - 1) / PPO_THREADS;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ppo_sample_kernel, dim3(nblk), dim3(PPO_THREADS), 0, st, B, A, mean, logstd, norm_a, old_logp, adv, mask, pred, tar_val, cfg,
+                       g_mean, g_pred, workspace);
+    hipLaunchKernelGGL(ppo_reduce_kernel, dim3(1), dim3(128), 0, st, B, A, nblk, logstd, cfg, workspace, g_logstd, out);
+    const int n = B * A;
+    hipLaunchKernelGGL(ppo_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, B, out, g_mean, g_pred);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}
+
+extern "C" int parc_ppo_workspace_floats(int B) { return ((B + PPO_THREADS - 1) / PPO_THREADS) * PPO_W; }

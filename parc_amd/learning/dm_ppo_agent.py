@@ -30,7 +30,9 @@ class AgentMode(enum.Enum):
     TEST = 1
 
 
-_LOSS_KEYS = ["obs", "action", "a_logp", "tar_val", "adv", "rand_action_mask"]
+# "norm_obs" = the normalised observations, written once per iteration by _build_train_data (the normaliser statistics do not
+# change during the update), so a minibatch is one gather instead of gather + subtract + divide + clamp
+_LOSS_KEYS = ["norm_obs", "action", "a_logp", "tar_val", "adv", "rand_action_mask"]
 
 
 class DMPPOAgent(torch.nn.Module):
@@ -141,6 +143,7 @@ class DMPPOAgent(torch.nn.Module):
         add("prev_char_contact_forces", [B, 3])
         add("next_char_contact_forces", [B, 3])
         add("env_id", [], torch.int64)
+        add("norm_obs", obs_dim)          # not in the reference's buffer set: update-phase cache, see _LOSS_KEYS
         self._env_ids = torch.arange(0, N, 1, device=dev, dtype=torch.int64)
         if self._is_terrain_runner:
             add("replan_timer", [])
@@ -347,6 +350,27 @@ class DMPPOAgent(torch.nn.Module):
         P = mp_util.get_num_procs()
         return self._rollout_test(int(np.ceil(num_episodes / P)))
 
+    @torch.no_grad()
+    def _critic_values(self):
+        """(V(obs), V(next_obs)) over the whole rollout buffer, [T, N] each; also fills the "norm_obs" cache."""
+        eb = self._exp_buffer
+        obs, next_obs, done = eb.get_data("obs"), eb.get_data("next_obs"), eb.get_data("done")
+        norm_obs = eb.get_data("norm_obs")
+        torch.sub(obs, self._obs_norm.get_mean(), out=norm_obs)
+        norm_obs.div_(self._obs_norm.get_std()).clamp_(-self._obs_norm._clip, self._obs_norm._clip)    # == Normalizer.normalize
+        vals = self._model.eval_critic(norm_obs).squeeze(-1)
+        # V(next_obs[t]) == V(obs[t+1]) wherever env did not finish at t (the two rows hold the same observation), so the
+        # second critic pass of the reference (ppo_agent.py:146-150) only has to run on the last step and on finished envs
+        T = obs.shape[0]
+        need = done != base_env.DoneFlags.NULL.value
+        need[T - 1] = True
+        next_vals = torch.empty_like(vals)
+        next_vals[:T - 1] = vals[1:]
+        idx = need.flatten().nonzero().flatten()                      # one host sync per iteration
+        sel = next_obs.flatten(0, 1)[idx]
+        next_vals.flatten()[idx] = self._model.eval_critic(self._obs_norm.normalize(sel)).squeeze(-1)
+        return vals, next_vals
+
     # ------------------------------------------------------------------ train data (dm_ppo_agent.py:343-411)
     @torch.no_grad()
     def _build_train_data(self):
@@ -355,7 +379,7 @@ class DMPPOAgent(torch.nn.Module):
         obs, next_obs = eb.get_data("obs"), eb.get_data("next_obs")
         r, done = eb.get_data("reward"), eb.get_data("done")
         mask = eb.get_data("rand_action_mask")
-        next_vals = self._model.eval_critic(self._obs_norm.normalize(next_obs)).squeeze(-1)
+        vals, next_vals = self._critic_values()
         r_min, r_max = self._env.get_reward_bounds()
         next_vals = torch.clamp(next_vals, r_min / (1.0 - self._discount), r_max / (1.0 - self._discount))
         succ_val = self._env.get_reward_succ() / (1.0 - self._discount)
@@ -363,7 +387,6 @@ class DMPPOAgent(torch.nn.Module):
         next_vals = torch.where(done == base_env.DoneFlags.SUCC.value, torch.full_like(next_vals, succ_val), next_vals)
         next_vals = torch.where(done == base_env.DoneFlags.FAIL.value, torch.full_like(next_vals, fail_val), next_vals)
         new_vals = rl_util.compute_td_lambda_return(r, next_vals, done, self._discount, self._td_lambda)      # K16 (HIP)
-        vals = self._model.eval_critic(self._obs_norm.normalize(obs)).squeeze(-1)
         norm_adv, mean_std = rl_util.normalize_advantage(new_vals, vals, mask, self._norm_adv_clip)            # K17 (HIP)
         eb.set_data("tar_val", new_vals)
         eb.set_data("adv", norm_adv)
@@ -371,9 +394,13 @@ class DMPPOAgent(torch.nn.Module):
 
     # ------------------------------------------------------------------ update (ppo_agent.py:186-330)
     def _compute_loss(self, batch):
-        norm_obs = self._obs_norm.normalize(batch["obs"])
+        norm_obs = batch["norm_obs"] if "norm_obs" in batch else self._obs_norm.normalize(batch["obs"])
         norm_a = self._a_norm.normalize(batch["action"])
         pred = self._model.eval_critic(norm_obs).squeeze(-1)
+        if norm_obs.is_cuda and self._config.get("fused_ppo_loss", True):
+            fused = self._compute_loss_fused(batch, norm_obs, norm_a, pred)
+            if fused is not None:
+                return fused
         diff = batch["tar_val"] - pred
         critic_loss = torch.mean(torch.square(diff)) if self._critic_loss_type == "L2" else torch.mean(torch.abs(diff))
         m = (batch["rand_action_mask"] == 1.0).to(torch.float32)
@@ -408,6 +435,27 @@ class DMPPOAgent(torch.nn.Module):
         actor_term = torch.where(critic_loss.detach() > 20.0, actor_loss.detach(), actor_loss)
         loss = actor_term + self._critic_loss_weight * critic_loss
         self._nan_flag |= torch.isnan(loss.detach()).to(torch.int32)      # NaN trap, checked once per iteration
+        info["loss"] = loss
+        return info
+
+    def _compute_loss_fused(self, batch, norm_obs, norm_a, pred):
+        """Same loss through parc_ppo_loss (one pass for value + gradient); None when the policy's log-std depends on the
+        state (StdType.VARIABLE), which the kernel does not cover."""
+        a_dist = self._model.eval_actor(norm_obs)
+        logstd = a_dist.logstd
+        if logstd.dim() != 2 or logstd.stride(0) != 0:
+            return None
+        loss, out = rl_util.ppo_loss(a_dist.mean, logstd[0], pred, norm_a, batch["a_logp"], batch["adv"], batch["rand_action_mask"],
+                                     batch["tar_val"], self._ppo_clip_ratio, self._action_bound_weight, self._action_entropy_weight,
+                                     self._action_reg_weight, self._critic_loss_weight, 20.0, self._critic_loss_type != "L2")
+        info = {"critic_loss": out[1], "clip_frac": out[3], "imp_ratio": out[4], "actor_loss": out[2]}
+        if self._action_bound_weight != 0:
+            info["action_bound_loss"] = out[5]
+        if self._action_entropy_weight != 0:
+            info["action_entropy"] = out[6]
+        if self._action_reg_weight != 0:
+            info["action_reg_loss"] = out[7]
+        self._nan_flag |= torch.isnan(out[0]).to(torch.int32)      # NaN trap, checked once per iteration
         info["loss"] = loss
         return info
 

@@ -160,6 +160,13 @@ def test_graph_rollout_matches_eager_bookkeeping(env):
     for t in range(2, T - 1):
         cont = done[t] == 0
         assert torch.equal(ncf[t][cont], pcf[t + 1][cont])
+    # V(next_obs) assembled from V(obs[t+1]) + a critic pass on finished envs / the last step == the direct second pass
+    with torch.no_grad():
+        vals, nv = agent._critic_values()
+        direct = agent._model.eval_critic(agent._obs_norm.normalize(nobs)).squeeze(-1)
+        direct_v = agent._model.eval_critic(agent._obs_norm.normalize(obs)).squeeze(-1)
+    assert torch.allclose(nv, direct, rtol=1e-4, atol=1e-4) and torch.allclose(vals, direct_v, rtol=1e-4, atol=1e-4)
+    assert torch.equal(eb.get_data("norm_obs"), agent._obs_norm.normalize(obs))
     # the captured graph survives a full training iteration (update changes the weights in place)
     info = agent._train_iter()
     assert np.isfinite(info["mean_return"]) and len(agent._graphs) == 1

@@ -359,3 +359,63 @@ def test_sim_device_matches_host_build(km, variant, n):
                                          _hip.ptr(rb2), _hip.ptr(cf2)), "refresh")
     close(rb2[0::2, :, 0:7], rb[0::2, :, 0:7].cpu().numpy(), atol=1e-4)
     assert torch.all(rb2[1::2] == 1.0) and torch.all(cf2[0::2] == 0.0)
+
+
+@pytest.mark.parametrize("case", ["default", "all_terms_l1", "critic_off_gate", "no_random_actions"])
+def test_fused_ppo_loss_matches_autograd(case):
+    """parc_ppo_loss (value + gradient in one pass) against the composite torch expression of the reference's
+    PPOAgent._compute_loss (learning/ppo_agent.py:186-330), gradients through torch.autograd."""
+    from parc_amd.learning import rl_util
+    g = torch.Generator().manual_seed(11)
+    B, A = 3000, 28            # not a multiple of the 256-thread block
+    mean = (torch.randn(B, A, generator=g) * 0.7).to(DEV).requires_grad_(True)
+    logstd = (torch.randn(A, generator=g) * 0.2 - 1.5).to(DEV).requires_grad_(True)
+    pred = torch.randn(B, generator=g).to(DEV).requires_grad_(True)
+    norm_a = (mean.detach() + torch.exp(logstd.detach()) * torch.randn(B, A, generator=g).to(DEV)).contiguous()
+    adv = torch.randn(B, generator=g).to(DEV)
+    mask = (torch.rand(B, generator=g) < 0.8).float().to(DEV)
+    tar = torch.randn(B, generator=g).to(DEV)
+    clip, bw, ew, rw, cw, l1 = 0.2, 10.0, 0.0, 0.0, 0.5, False
+    if case == "all_terms_l1":
+        ew, rw, l1 = 0.01, 0.003, True
+    if case == "critic_off_gate":
+        tar = tar + 9.0                      # critic loss > 20: the actor term must give no gradient
+    if case == "no_random_actions":
+        mask.zero_()
+
+    def logp_of(mu, ls):
+        z = (norm_a - mu) / torch.exp(ls)
+        return -0.5 * torch.sum(z * z, dim=-1) + (-0.5 * A * np.log(2.0 * np.pi) - torch.sum(ls))
+    old_logp = (logp_of(mean.detach(), logstd.detach()) + 0.3 * torch.randn(B, generator=g).to(DEV)).contiguous()
+
+    # composite (reference formulation)
+    diff = tar - pred
+    critic_loss = diff.abs().mean() if l1 else diff.square().mean()
+    m = (mask == 1.0).float()
+    cnt = m.sum().clamp_min(1.0)
+    ratio = torch.exp(logp_of(mean, logstd) - old_logp)
+    l0, l1_ = adv * ratio, adv * torch.clamp(ratio, 1 - clip, 1 + clip)
+    actor = -(torch.minimum(l0, l1_) * m).sum() / cnt
+    viol = torch.clamp_max(mean + 1.0, 0.0).square().sum(-1) + torch.clamp_min(mean - 1.0, 0.0).square().sum(-1)
+    actor = actor + bw * (viol * m).sum() / cnt
+    ent = ((logstd.sum() + 0.5 * A * np.log(2.0 * np.pi * np.e)) * m).sum() / cnt
+    actor = actor - ew * ent
+    actor = actor + rw * (mean.square().sum(-1) * m).sum() / cnt
+    term = torch.where(critic_loss.detach() > 20.0, actor.detach(), actor)
+    loss_ref = term + cw * critic_loss
+    g_ref = torch.autograd.grad(loss_ref, [mean, logstd, pred], allow_unused=True)
+
+    loss, out = rl_util.ppo_loss(mean, logstd, pred, norm_a, old_logp, adv, mask, tar, clip, bw, ew, rw, cw, 20.0, l1)
+    g_f = torch.autograd.grad(loss, [mean, logstd, pred])
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5 * max(1.0, abs(loss_ref.item()))
+    ref_info = [loss_ref, critic_loss, actor, ((torch.abs(ratio - 1.0) > clip).float() * m).sum() / cnt, (ratio * m).sum() / cnt,
+                (viol * m).sum() / cnt, ent, (mean.square().sum(-1) * m).sum() / cnt, cnt]
+    for k, r in enumerate(ref_info):
+        assert abs(out[k].item() - r.item()) <= 2e-5 * max(1.0, abs(r.item())), (k, out[k].item(), r.item())
+    for a, b, name in zip(g_f, g_ref, ("mean", "logstd", "pred")):
+        b = torch.zeros_like(a) if b is None else b
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (name, float((a - b).abs().max()), scale)
+    if case == "critic_off_gate":
+        assert float(g_f[0].abs().max()) == 0.0 and float(g_f[1].abs().max()) == 0.0 and float(g_f[2].abs().max()) > 0.0
