@@ -43,6 +43,8 @@ class DeepMimicEnv:
         self._one_motion_mode = False
         self._selected_motion_id = 0
         self._terrain_build_mode = dm.get("terrain_build_mode", "square")
+        self._build_tile_meshes = bool(dm.get("build_tile_meshes", True))     # the reference always builds them (for PhysX)
+        self._all_terrain_verts, self._all_terrain_tris = [], []
         self._motion_classes = dm.get("motion_classes", [])
         self._has_motion_classes = False
 
@@ -85,7 +87,23 @@ class DeepMimicEnv:
             raise AssertionError("unsupported terrain build mode")
         return self.build_terrain_square(env_config, terrain_save_path, x_offset, y_offset)
 
-    def _save_terrain_cache(self, terrain_save_path):
+    @staticmethod
+    def _tile_mesh(hf, min_x, min_y, dx, padding=0):
+        """Collision mesh of one terrain tile as the reference builds it for the simulator (dm_env.py:257-286): two triangles
+        for a flat tile, the voxelised column mesh otherwise.  The MI355X simulator collides with the heightfield columns
+        directly; the meshes are produced for the return value / cache file of the reference's API."""
+        hf = np.asarray(hf, np.float32)
+        if abs(float(hf.max()) - float(hf.min())) < 1e-5:
+            max_x, max_y = min_x + dx * (hf.shape[0] - 1), min_y + dx * (hf.shape[1] - 1)
+            z = hf[0, 0]
+            verts = np.array([[min_x - dx / 2, min_y - dx / 2, z], [max_x + dx / 2, min_y - dx / 2, z], [min_x - dx / 2, max_y + dx / 2, z],
+                              [max_x + dx / 2, max_y + dx / 2, z]], dtype=np.float32)
+            return verts, np.array([[0, 1, 2], [1, 3, 2]], dtype=np.uint32)
+        return terrain_util.convert_heightfield_to_voxelized_trimesh(hf, min_x, min_y, dx, padding=padding)
+
+    def _save_terrain_cache(self, terrain_save_path, all_verts=None, all_tris=None):
+        self._all_terrain_verts = all_verts if all_verts is not None else []
+        self._all_terrain_tris = all_tris if all_tris is not None else []
         if not terrain_save_path:
             return
         os.makedirs(os.path.dirname(terrain_save_path) or ".", exist_ok=True)
@@ -93,7 +111,8 @@ class DeepMimicEnv:
         cpu_t.set_device("cpu")
         with open(terrain_save_path, "wb") as f:
             pickle.dump({"terrain": cpu_t.numpy_copy(), "terrains_per_motion": self._terrains_per_motion,
-                         "motion_offsets": self._dm_motion_offsets.cpu().numpy(), "all_terrain_verts": [], "all_terrain_tris": []}, f)
+                         "motion_offsets": self._dm_motion_offsets.cpu().numpy(), "all_terrain_verts": self._all_terrain_verts,
+                         "all_terrain_tris": self._all_terrain_tris}, f)
 
     def load_motion_terrain_file(self, env_config, terrain_save_path):
         """terrain_build_mode "file" (reference :128-186): ONE shared terrain named by the motion YAML's `terrain:` key,
@@ -116,8 +135,11 @@ class DeepMimicEnv:
             mpo = d.get("min_point_offset") if hasattr(d, "get") else None
             offs.append(np.zeros(2, np.float32) if mpo is None or isinstance(mpo, safe_pickle.Unresolved) else np.asarray(mpo, np.float32).reshape(2))
         self._dm_motion_offsets = torch.tensor(np.stack(offs), dtype=torch.float32, device=self._device).unsqueeze(1)
-        self._save_terrain_cache(terrain_save_path)
-        return [], []
+        # reference :141-156: one voxelised mesh of the shared terrain, min point / cell size as float32 .item() values
+        verts, tris = terrain_util.convert_heightfield_to_voxelized_trimesh(t.hf, t.min_point[0].item(), t.min_point[1].item(),
+                                                                            t.dxdy[0].item(), padding=0)
+        self._save_terrain_cache(terrain_save_path, [[verts]], [[tris]])
+        return self._all_terrain_verts, self._all_terrain_tris
 
     def build_terrain_wide(self, env_config, terrain_save_path, x_offset=0.0, y_offset=0.0):
         """terrain_build_mode "wide" (reference :362-491): clips side by side along x, `terrains_per_motion` copies along y,
@@ -176,6 +198,7 @@ class DeepMimicEnv:
         glob = terrain_util.SubTerrain("heightmap", dim_x * n_side, dim_y * n_side, dx, dx, first_x, first_y, device=self._device)
         offsets = torch.zeros((M, self._terrains_per_motion, 2), dtype=torch.float32, device=self._device)
         k = 0
+        all_verts, all_tris = [], []
         for i in range(n_side):
             for j in range(n_side):
                 if k >= M:
@@ -183,6 +206,10 @@ class DeepMimicEnv:
                 t = ters[k]
                 t.pad(npad, torch.min(t.hf).item())                 # :245-249 pads with the clip terrain's minimum
                 xo, yo = first_x + i * dim_x * dx, first_y + j * dim_y * dx
+                if self._build_tile_meshes:
+                    v, tr = self._tile_mesh(t.hf.cpu().numpy(), xo, yo, dx)
+                    all_verts.append([v])
+                    all_tris.append([tr])
                 offsets[k, 0, 0] = xo - t.min_point[0]
                 offsets[k, 0, 1] = yo - t.min_point[1]
                 sx, sy = i * dim_x, j * dim_y
@@ -191,8 +218,8 @@ class DeepMimicEnv:
                 k += 1
         self._terrain = glob
         self._dm_motion_offsets = offsets
-        self._save_terrain_cache(terrain_save_path)
-        return [], []
+        self._save_terrain_cache(terrain_save_path, all_verts, all_tris)
+        return self._all_terrain_verts, self._all_terrain_tris
 
     def load_terrain(self, terrain_save_path):
         from ...util import safe_pickle

@@ -142,3 +142,66 @@ def slice_terrain_around_motion(motion_frames, terrain, padding=1.0):
     frames[:, 2] -= z0
     out.hf = out.hf - z0
     return out, frames
+
+
+def convert_heightfield_to_voxelized_trimesh(hf, min_x, min_y, dx=0.1, padding=None):
+    """Heightfield -> the flat-topped-column triangle mesh the reference hands to the simulator
+    (util/terrain_util.py:1099-1251): 4 vertices + 2 triangles per cell top, 2 triangles per shared cell edge along x and
+    along y (degenerate where neighbours are level), optionally an 8-vertex / 8-triangle skirt ``padding`` metres wide
+    at the lowest height.  Same vertex / triangle order and the same float64 -> float32 arithmetic as the reference's
+    per-cell Python loops, as whole-array numpy (O(cells) array ops instead of O(cells) interpreter iterations).
+    Returns (vertices float32 [V,3], tris uint32 [T,3])."""
+    if isinstance(hf, torch.Tensor):
+        hf = hf.detach().cpu().numpy()
+    hf = np.asarray(hf)
+    nx, ny = hf.shape
+    pad = padding is not None and padding > 0.0
+    n_cells = nx * ny
+    n_flat, n_x, n_y = 2 * n_cells, 2 * (nx - 1) * ny, 2 * nx * (ny - 1)
+    vertices = np.zeros((4 * n_cells + (8 if pad else 0), 3), dtype=np.float32)
+    tris = np.zeros((n_flat + n_x + n_y + (8 if pad else 0), 3), dtype=np.uint32)
+    x = dx * np.arange(nx, dtype=np.float64) + min_x           # cell centres, float64 like the reference's Python floats
+    y = dx * np.arange(ny, dtype=np.float64) + min_y
+    xm, xp, ym, yp = x - dx / 2, x + dx / 2, y - dx / 2, y + dx / 2
+    V = vertices[:4 * n_cells].reshape(nx, ny, 4, 3)
+    V[:, :, 0, 0] = xm[:, None]; V[:, :, 0, 1] = ym[None, :]
+    V[:, :, 1, 0] = xm[:, None]; V[:, :, 1, 1] = yp[None, :]
+    V[:, :, 2, 0] = xp[:, None]; V[:, :, 2, 1] = yp[None, :]
+    V[:, :, 3, 0] = xp[:, None]; V[:, :, 3, 1] = ym[None, :]
+    V[:, :, :, 2] = hf[:, :, None]
+    cell = (np.arange(nx, dtype=np.int64)[:, None] * ny + np.arange(ny, dtype=np.int64)[None, :])
+    c4 = (cell * 4).reshape(-1)
+    F = tris[:n_flat].reshape(n_cells, 2, 3)
+    F[:, 0] = np.stack([c4 + 0, c4 + 2, c4 + 1], axis=-1)
+    F[:, 1] = np.stack([c4 + 0, c4 + 3, c4 + 2], axis=-1)
+    if nx > 1:
+        a = (cell[:-1] * 4).reshape(-1)                          # cell (i, j) and its +x neighbour (i+1, j)
+        b = (cell[1:] * 4).reshape(-1)
+        v1, v2, v3, v4 = a + 3, a + 2, b + 1, b + 0
+        X = tris[n_flat:n_flat + n_x].reshape(-1, 2, 3)
+        X[:, 0] = np.stack([v1, v3, v2], axis=-1)
+        X[:, 1] = np.stack([v1, v4, v3], axis=-1)
+    if ny > 1:
+        a = (cell[:, :-1] * 4).reshape(-1)                       # cell (i, j) and its +y neighbour (i, j+1)
+        b = (cell[:, 1:] * 4).reshape(-1)
+        v1, v2, v3, v4 = a + 1, a + 2, b + 3, b + 0
+        Y = tris[n_flat + n_x:n_flat + n_x + n_y].reshape(-1, 2, 3)
+        Y[:, 0] = np.stack([v1, v2, v3], axis=-1)
+        Y[:, 1] = np.stack([v1, v3, v4], axis=-1)
+    if pad:
+        max_x = min_x + dx * (nx - 1)
+        max_y = min_y + dx * (ny - 1)
+        z = np.min(hf)
+        p0 = np.array([min_x - dx / 2, min_y - dx / 2, z])
+        p1 = np.array([max_x + dx / 2, min_y - dx / 2, z])
+        p2 = np.array([min_x - dx / 2, max_y + dx / 2, z])
+        p3 = np.array([max_x + dx / 2, max_y + dx / 2, z])
+        vertices[-8], vertices[-7], vertices[-6], vertices[-5] = p0, p1, p2, p3
+        vertices[-4] = p0 + np.array([-padding, -padding, 0.0])
+        vertices[-3] = p1 + np.array([+padding, -padding, 0.0])
+        vertices[-2] = p2 + np.array([-padding, +padding, 0.0])
+        vertices[-1] = p3 + np.array([+padding, +padding, 0.0])
+        n = vertices.shape[0]
+        v0, v1, v2, v3, v4, v5, v6, v7 = (n - 8 + k for k in range(8))
+        tris[-8:] = [[v0, v4, v5], [v0, v5, v1], [v1, v5, v7], [v1, v7, v3], [v3, v7, v6], [v3, v6, v2], [v2, v6, v4], [v2, v4, v0]]
+    return vertices, tris

@@ -475,7 +475,33 @@ def gen_td_lambda(rng):
          params=np.array([0.99, 0.95, 4.0], np.float64))
 
 
+def gen_voxel_mesh(rng):
+    """G10: heightfield -> voxelised triangle mesh (util/terrain_util.py:1099-1251).  Case A is the authors' own output:
+    data/terrains/civilization_ig.pkl holds the terrain together with the verts / tris their build produced from it
+    (dm_env.py:143-148, padding 0).  Case B runs the reference function on a small random field with padding 0.8."""
+    ig = load_motion_file_safe(os.path.join(REF, "data/terrains/civilization_ig.pkl"))
+    # the terrain inside the _ig file is stored as torch tensors (not materialised by the non-executing reader); it was built
+    # from civilization.pkl (data/terrains/civilization_motions.yaml, terrain_build_mode "file"), whose arrays are numpy
+    ter = load_motion_file_safe(os.path.join(REF, "data/terrains/civilization.pkl"))["terrain"]
+    hf = np.asarray(ter["hf"], np.float32)
+    a_v = np.asarray(ig["all_terrain_verts"][0]).reshape(-1, 3)
+    a_t = np.asarray(ig["all_terrain_tris"][0]).reshape(-1, 3)
+    # the reference function reproduces the shipped arrays (checked here so the fixture is known to be that function's output)
+    # (the reference passes min_point / dxdy as .item() of float32 tensors: dx is the double value of float32(0.4))
+    mn = np.asarray(ter["min_point"], np.float32).astype(np.float64)
+    dx = float(np.float32(ter["dxdy"][0]))
+    v, tr = terrain_util.convert_heightfield_to_voxelized_trimesh(torch.tensor(hf), float(mn[0]), float(mn[1]), dx, padding=0)
+    assert np.array_equal(v, a_v) and np.array_equal(tr, a_t)
+    hf_b = (rng.integers(-2, 4, size=(7, 5)) * 0.3).astype(np.float32)
+    b_v, b_t = terrain_util.convert_heightfield_to_voxelized_trimesh(torch.tensor(hf_b), -1.3, 0.7, 0.4, padding=0.8)
+    save("g10_voxel_mesh", a_hf=hf, a_min_point=mn, a_dx=np.float64(dx), a_verts=a_v,
+         a_tris=a_t, b_hf=hf_b, b_min_point=np.array([-1.3, 0.7]), b_dx=np.float64(0.4), b_padding=np.float64(0.8), b_verts=b_v, b_tris=b_t)
+
+
 def main():
+    if "--only-voxel-mesh" in sys.argv:
+        gen_voxel_mesh(np.random.default_rng(10))
+        return
     rng = np.random.default_rng(0)
     torch.manual_seed(0)
     civ = load_motion_file_safe(os.path.join(REF, "data/terrains/civilization.pkl"))
@@ -489,6 +515,7 @@ def main():
     gen_heightmap(rng, civ, teaser, rays)
     gen_obs_reward_done(rng, km, mlib, civ, rays)
     gen_td_lambda(rng)
+    gen_voxel_mesh(np.random.default_rng(10))
 
 
 if __name__ == "__main__":

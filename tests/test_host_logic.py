@@ -126,6 +126,7 @@ def _dm_env_cpu(mode, tmp_path, n_clips=3, R=1):
     e._device = "cpu"
     e._terrain_build_mode = mode
     e._terrains_per_motion = R
+    e._build_tile_meshes = True
     e._motion_lib = types.SimpleNamespace(_terrains=ters, num_motions=lambda: n_clips)
     return e, ters
 
@@ -171,3 +172,26 @@ def test_terrain_build_file_mode(tmp_path):
     assert e._terrains_per_motion == 1
     np.testing.assert_array_equal(e._terrain.hf.numpy(), big.hf.numpy())
     np.testing.assert_allclose(e._dm_motion_offsets.numpy(), np.array([[[0, 0]], [[1.2, -0.4]]], np.float32))
+    # the shared terrain's voxel mesh is returned like the reference does (one entry, 4 verts per cell)
+    assert len(e._all_terrain_verts) == 1 and e._all_terrain_verts[0][0].shape == (8 * 10 * 4, 3)
+    assert e._all_terrain_tris[0][0].shape == (2 * 80 + 2 * 7 * 10 + 2 * 8 * 9, 3)
+
+
+def test_voxel_mesh_matches_reference_and_shipped_arrays():
+    """G10: the whole-array mesh builder against (A) the vertex / triangle arrays the reference's authors shipped in
+    data/terrains/civilization_ig.pkl for the 50x50 civilization terrain and (B) the reference function run on a small
+    field with a skirt: bit-exact, vertices and indices."""
+    from parc_amd.util import terrain_util
+    z = golden("g10_voxel_mesh")
+    v, t = terrain_util.convert_heightfield_to_voxelized_trimesh(torch.tensor(z["a_hf"]), float(z["a_min_point"][0]), float(z["a_min_point"][1]),
+                                                                 float(z["a_dx"]), padding=0)
+    assert v.dtype == np.float32 and t.dtype == np.uint32 and v.shape == (10000, 3) and t.shape == (14800, 3)
+    np.testing.assert_array_equal(v, z["a_verts"])
+    np.testing.assert_array_equal(t, z["a_tris"])
+    v, t = terrain_util.convert_heightfield_to_voxelized_trimesh(z["b_hf"], float(z["b_min_point"][0]), float(z["b_min_point"][1]),
+                                                                 float(z["b_dx"]), padding=float(z["b_padding"]))
+    np.testing.assert_array_equal(v, z["b_verts"])
+    np.testing.assert_array_equal(t, z["b_tris"])
+    # 1 x n and n x 1 fields have no edges along the collapsed axis
+    v, t = terrain_util.convert_heightfield_to_voxelized_trimesh(np.zeros((1, 3), np.float32), 0.0, 0.0, 0.5)
+    assert v.shape == (12, 3) and t.shape == (6 + 0 + 4, 3)

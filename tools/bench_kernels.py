@@ -123,6 +123,9 @@ def bench_post_step(n, iters):
     core.dof_state.view(n, 28, 2)[..., 0] = core.ref_dof_pos
     core.rigid_body_state.view(n, 15, 13)[..., 0:3] = core.ref_body_pos
     full = _hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF
+    abl = [int(a.split("=")[1], 0) for a in sys.argv if a.startswith("--ablate=")]
+    if abl:                      # PMC runs of one role ablation: every launch of the process uses it
+        full |= abl[0]
     us_fused = time_loop(lambda: core.post_step(full), iters)
     us_nohf = time_loop(lambda: core.post_step(full & ~_hip.POST_HF), iters)
     for name, bits in () if "--plain" in sys.argv else (("no_tar", 0x10000), ("no_ref", 0x20000), ("no_char", 0x40000), ("only_char", 0x30000), ("only_ref", 0x50000), ("only_tar", 0x60000), ("none", 0x70000)):
