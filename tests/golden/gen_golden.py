@@ -498,7 +498,38 @@ def gen_voxel_mesh(rng):
          a_tris=a_t, b_hf=hf_b, b_min_point=np.array([-1.3, 0.7]), b_dx=np.float64(0.4), b_padding=np.float64(0.8), b_verts=b_v, b_tris=b_t)
 
 
+def gen_dataset_yaml():
+    """G11: PARC/util/create_dataset.py on the folder tree of tests/golden/dataset_tree.py (class-balanced weights, class
+    halving, large-terrain and bad-loss exclusion, ignore folders)."""
+    import json
+    import yaml
+    from pathlib import Path
+    sys.path.insert(0, HERE)
+    import dataset_tree
+    import PARC.util.create_dataset as ref_cd
+    # the function samples character surface points through trimesh (not installed) before it knows whether the
+    # preprocessing step is requested; with compute_preprocessing_data=False the points are never used
+    ref_cd.geom_util.get_char_point_samples = lambda char_model: None
+
+    def make_terrain(hf):
+        t = terrain_util.SubTerrain("t", hf.shape[0], hf.shape[1], 0.4, 0.4, 0.0, 0.0, device="cpu")
+        return t.numpy_copy()
+    root = tempfile.mkdtemp(prefix="parc_ds_")
+    folders = dataset_tree.build(root, make_terrain)
+    out = os.path.join(root, "out.yaml")
+    ref_cd.create_dataset_yaml([Path(f) for f in folders], Path(out), os.path.join(REF, "data/assets/humanoid.xml"), False, True, ["running"], 45, 45)
+    with open(out) as f:
+        y = yaml.safe_load(f)
+    entries = [{"file": os.path.relpath(m["file"], root), "weight": float(m["weight"])} for m in y["motions"]]
+    with open(os.path.join(OUT, "g11_dataset_yaml.json"), "w") as f:
+        json.dump({"cut_classes": ["running"], "max_dim": [45, 45], "motions": entries}, f, indent=1)
+    print("wrote g11_dataset_yaml.json", len(entries), "entries")
+
+
 def main():
+    if "--only-dataset-yaml" in sys.argv:
+        gen_dataset_yaml()
+        return
     if "--only-voxel-mesh" in sys.argv:
         gen_voxel_mesh(np.random.default_rng(10))
         return
@@ -516,6 +547,7 @@ def main():
     gen_obs_reward_done(rng, km, mlib, civ, rays)
     gen_td_lambda(rng)
     gen_voxel_mesh(np.random.default_rng(10))
+    gen_dataset_yaml()
 
 
 if __name__ == "__main__":

@@ -195,3 +195,36 @@ def test_voxel_mesh_matches_reference_and_shipped_arrays():
     # 1 x n and n x 1 fields have no edges along the collapsed axis
     v, t = terrain_util.convert_heightfield_to_voxelized_trimesh(np.zeros((1, 3), np.float32), 0.0, 0.0, 0.5)
     assert v.shape == (12, 3) and t.shape == (6 + 0 + 4, 3)
+
+
+def test_create_dataset_yaml_matches_reference(tmp_path):
+    """G11: class-balanced dataset YAML (PARC/util/create_dataset.py) on the tree of tests/golden/dataset_tree.py: same entries,
+    same order, same weights as the reference produced (tests/golden/g11_dataset_yaml.json)."""
+    import json
+    import sys
+    import yaml
+    sys.path.insert(0, os.path.join(REPO, "tests", "golden"))
+    import dataset_tree
+    from parc_amd.util import create_dataset, terrain_util
+    with open(os.path.join(REPO, "tests", "golden", "g11_dataset_yaml.json")) as f:
+        gold = json.load(f)
+
+    def make_terrain(hf):
+        return terrain_util.SubTerrain.from_arrays(hf, np.zeros(2, np.float32), np.array([0.4, 0.4], np.float32)).numpy_copy()
+    folders = dataset_tree.build(str(tmp_path), make_terrain, dataset_tree.FILES + [dataset_tree.BAD_LOSS_FILE])
+    out = tmp_path / "out.yaml"
+    create_dataset.create_dataset_yaml(folders, out, None, False, True, gold["cut_classes"], *gold["max_dim"])
+    got = yaml.safe_load(out.read_text())["motions"]
+    assert [os.path.relpath(m["file"], str(tmp_path)) for m in got] == [m["file"] for m in gold["motions"]]
+    np.testing.assert_allclose([m["weight"] for m in got], [m["weight"] for m in gold["motions"]], rtol=1e-12)
+    # every class ends up with the same total weight
+    tot = {}
+    for m in got:
+        c = m["file"].split(os.sep)[-2] if "sub" not in m["file"] else "running"
+        tot[c] = tot.get(c, 0.0) + m["weight"]
+    assert max(tot.values()) - min(tot.values()) < 1e-9
+    try:
+        create_dataset.create_dataset_yaml(folders, out, None, True)
+        assert False
+    except NotImplementedError:
+        pass
