@@ -46,25 +46,36 @@ __global__ __launch_bounds__(64) void sim_step_bpl_kernel(const parc_sim_model_t
                      contact_forces + 3 * (size_t)B * e);
 }
 
-__global__ __launch_bounds__(SIM_THREADS) void sim_refresh_kernel(const parc_sim_model_t *__restrict__ model, int n, const int64_t *__restrict__ env_ids,
-                                                                  const int32_t *__restrict__ mask,
-                                                                  const float *__restrict__ root_state, const float *__restrict__ dof_state,
-                                                                  float *rigid_body_state, float *contact_forces) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    if (mask && mask[k] == 0) return;
+// body-per-lane refresh: body poses / velocities from the state rows, for a list of envs (env_ids, n = list length), for
+// the envs whose mask is set (device-side reset, n = env count), or for all (both null)
+__global__ __launch_bounds__(64) void sim_refresh_bpl_kernel(const parc_sim_model_t *__restrict__ model, int n, const int64_t *__restrict__ env_ids,
+                                                             const int32_t *__restrict__ mask, const float *__restrict__ root_state,
+                                                             const float *__restrict__ dof_state, float *rigid_body_state, float *contact_forces) {
+    using namespace parc_sim_bpl;
+    const int g = threadIdx.x / BPL_G, b = threadIdx.x % BPL_G;
+    const int k0 = (int)blockIdx.x * BPL_EPB;
+    if (mask) {
+        int any = 0;
+#pragma unroll
+        for (int k = 0; k < BPL_EPB; ++k)
+            if (k0 + k < n) any |= mask[k0 + k];
+        if (!any) return;                               // uniform: nothing flagged in this workgroup
+    }
+    const int k = min(k0 + g, n - 1);
     const int e = env_ids ? (int)env_ids[k] : k;
+    const bool live = k0 + g < n && (!mask || mask[e] != 0);
     const parc_sim_model_t &m = *model;
     const int B = m.num_bodies, D = m.dof_size;
-    parc_sim::State x;
-    float zero_act[PARC_SIM_MAX_DOFS], lo[PARC_SIM_MAX_DOFS], hi[PARC_SIM_MAX_DOFS];
-    for (int d = 0; d < D; ++d) {
-        zero_act[d] = 0.f;
-        lo[d] = -1.f;
-        hi[d] = 1.f;
-    }
-    parc_sim::load_state(m, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e, zero_act, lo, hi, x);
-    parc_sim::publish_bodies(m, x, rigid_body_state + 13 * (size_t)B * e, contact_forces + 3 * (size_t)B * e);
+    const Lane L = load_lane(m, b);
+    int maxd = L.depth;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) maxd = max(maxd, __shfl_xor(maxd, o, BPL_G));
+    LState x;
+    // (PD targets are irrelevant here: the action / bound pointers are only read, point them at the dof row)
+    const float *drow = dof_state + 2 * (size_t)D * e;
+    load_lane_state(m, L, b, root_state + 13 * (size_t)e, drow, drow, drow, drow, x);
+    if (!live) return;        // whole 16-lane groups leave together; the sweeps below only shuffle inside a group
+    store_lane_state<false>(L, b, maxd, x, nullptr, nullptr, rigid_body_state + 13 * (size_t)B * e, contact_forces + 3 * (size_t)B * e);
 }
 
 // envs (= lanes) per workgroup of the step kernel: 4096 envs are only 64 full waves on a 1024-SIMD chip, so partially
@@ -108,8 +119,8 @@ extern "C" int parc_sim_refresh_bodies(void *stream, const parc_sim_model_t *mod
     if (!model || n_envs < 0) return PARC_EINVAL;
     int n = env_ids ? n_sel : n_envs;
     if (n <= 0) return n == 0 ? PARC_OK : PARC_EINVAL;
-    hipLaunchKernelGGL(sim_refresh_kernel, dim3((n + SIM_THREADS - 1) / SIM_THREADS), dim3(SIM_THREADS), 0, (hipStream_t)stream, model, n,
-                       env_ids, (const int32_t *)nullptr, root_state, dof_state, rigid_body_state, contact_forces);
+    hipLaunchKernelGGL(sim_refresh_bpl_kernel, dim3((n + BPL_EPB - 1) / BPL_EPB), dim3(64), 0, (hipStream_t)stream, model, n, env_ids,
+                       (const int32_t *)nullptr, root_state, dof_state, rigid_body_state, contact_forces);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }
@@ -119,8 +130,7 @@ extern "C" int parc_sim_refresh_bodies_masked(void *stream, const parc_sim_model
                                               float *contact_forces) {
     if (!model || n_envs < 0 || !mask) return PARC_EINVAL;
     if (n_envs == 0) return PARC_OK;
-    // few envs are masked per call: 16 lanes per workgroup spread the flagged ones over more CUs
-    hipLaunchKernelGGL(sim_refresh_kernel, dim3((n_envs + 15) / 16), dim3(16), 0, (hipStream_t)stream, model, n_envs,
+    hipLaunchKernelGGL(sim_refresh_bpl_kernel, dim3((n_envs + BPL_EPB - 1) / BPL_EPB), dim3(64), 0, (hipStream_t)stream, model, n_envs,
                        (const int64_t *)nullptr, mask, root_state, dof_state, rigid_body_state, contact_forces);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;

@@ -385,6 +385,7 @@ __device__ __forceinline__ void load_lane_state(const parc_sim_model_t &m, const
 }
 
 // state rows + body poses / velocities of the final state (one more outward sweep, carrying the world quaternion)
+template <bool WRITE_STATE = true>
 __device__ __forceinline__ void store_lane_state(const Lane &L, int b, int maxd, const LState &x, float *root_state, float *dof_state,
                                                  float *rigid_body_state, float *contact_forces) {
     Kin k;
@@ -396,7 +397,9 @@ __device__ __forceinline__ void store_lane_state(const Lane &L, int b, int maxd,
         Q4 Qp = Q4{shf(Q.x, L.p), shf(Q.y, L.p), shf(Q.z, L.p), shf(Q.w, L.p)};
         if (L.depth == l) Q = qnormalize(qmul(Qp, lq));
     }
-    if (b == 0) {
+    if (!WRITE_STATE) {
+        // refresh after a reset: only the body poses / velocities are published, the state rows stay as written
+    } else if (b == 0) {
         M3 R = qmat(x.root_rot);
         st(root_state, x.root_pos);
         root_state[3] = x.root_rot.x; root_state[4] = x.root_rot.y; root_state[5] = x.root_rot.z; root_state[6] = x.root_rot.w;

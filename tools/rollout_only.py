@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Rollout-only loop (no PPO update) for profiling the per-env-step kernel mix: python3 tools/rollout_only.py [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from parc_amd import workloads
+from parc_amd.util import mp_util
+
+dev = "cuda:0"
+mp_util.init(0, 1, dev)
+torch.manual_seed(0)
+env, _, _ = workloads.build_env("boxes_64clips", 4096, dev, seed=0)
+agent = workloads.build_agent(env, dev, mp_scale_rollout=False)
+agent._curr_obs, agent._curr_info = env.reset()
+agent._init_train()
+agent._rollout_train(8)          # warm-up + graph capture
+torch.cuda.synchronize()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+t0 = time.time()
+agent._rollout_train(n)
+torch.cuda.synchronize()
+dt = time.time() - t0
+print("rollout steps/s %.1f  ms/step %.3f  env-steps/s %.0f" % (n / dt, dt / n * 1e3, n * 4096 / dt))
