@@ -35,6 +35,20 @@ class AgentMode(enum.Enum):
 _LOSS_KEYS = ["norm_obs", "action", "a_logp", "tar_val", "adv", "rand_action_mask"]
 
 
+def enable_tuned_gemms():
+    """Use the offline GEMM solution selection shipped in parc_amd/tunableop_results.csv (PyTorch TunableOp over hipBLASLt /
+    rocBLAS, produced by tools/tune_gemms.py on an MI355X for the shapes of the 4096-env training iteration: the default
+    heuristic leaves 10-15 % on the first-layer GEMMs).  Selection only - nothing is tuned at run time; shapes that are not
+    in the file, or a file recorded for another library version / architecture, fall back to the default heuristic."""
+    import torch.cuda.tunable as tunable
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tunableop_results.csv")
+    if not os.path.exists(path) or tunable.is_enabled():
+        return
+    tunable.set_filename(path, False)
+    tunable.tuning_enable(False)
+    tunable.enable(True)
+
+
 class DMPPOAgent(torch.nn.Module):
     NAME = "DM_PPO"
 
@@ -60,6 +74,8 @@ class DMPPOAgent(torch.nn.Module):
         self._curr_obs = None
         self._curr_info = None
         self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self._device)
+        if str(self._device).startswith("cuda") and config.get("tuned_gemms", True):
+            enable_tuned_gemms()
         # hipGraph rollout: the fixed-shape part of one env step (policy forward, record, simulator, post-step kernel,
         # return tracker, record) is captured once and replayed; only the data-dependent reset of finished envs stays eager
         self._use_hip_graph = bool(config.get("hip_graph_rollout", True)) and str(self._device).startswith("cuda")

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Offline GEMM solution selection (PyTorch TunableOp over hipBLASLt / rocBLAS) for the shapes of one training iteration.
+Run on the GPU box; writes gpurun_out/tunableop_results.csv (copy to parc_amd/tunableop_results.csv to ship it).
+Prints the iteration time before (default heuristics) and after (tuned selections)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.cuda.tunable as tunable
+from parc_amd import workloads
+from parc_amd.util import mp_util
+
+dev = "cuda:0"
+mp_util.init(0, 1, dev)
+torch.manual_seed(0)
+env, _, _ = workloads.build_env("boxes_64clips", 4096, dev, seed=0)
+agent = workloads.build_agent(env, dev, mp_scale_rollout=False, tuned_gemms=False)
+agent._curr_obs, agent._curr_info = env.reset()
+agent._init_train()
+
+
+def timed(n):
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(n):
+        agent._train_iter()
+    torch.cuda.synchronize()
+    return (time.time() - t0) / n * 1e3
+
+
+agent._train_iter()
+print("default heuristics: %.1f ms / iteration" % timed(3), flush=True)
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tunableop_results.csv")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+tunable.enable(True)
+tunable.tuning_enable(True)
+tunable.set_filename(out, False)
+tunable.set_max_tuning_duration(30)        # ms per candidate solution
+tunable.set_max_tuning_iterations(10)
+agent._use_hip_graph = False               # tuning launches candidates eagerly
+agent._graphs.clear()
+agent._graph_pool = None
+t0 = time.time()
+agent._train_iter()
+torch.cuda.synchronize()
+print("tuning pass took %.1f s, %d shapes" % (time.time() - t0, len(tunable.get_results())), flush=True)
+tunable.tuning_enable(False)
+agent._use_hip_graph = True
+agent._graph_warm = 0
+agent._train_iter()
+print("tuned selections:   %.1f ms / iteration" % timed(3), flush=True)
+for r in tunable.get_results():
+    print(r)
