@@ -205,3 +205,8 @@ def convert_heightfield_to_voxelized_trimesh(hf, min_x, min_y, dx=0.1, padding=N
         v0, v1, v2, v3, v4, v5, v6, v7 = (n - 8 + k for k in range(8))
         tris[-8:] = [[v0, v4, v5], [v0, v5, v1], [v1, v5, v7], [v1, v7, v3], [v3, v7, v6], [v3, v6, v2], [v2, v6, v4], [v2, v4, v0]]
     return vertices, tris
+
+
+# procedural generators under the reference's names (util/terrain_util.py)
+from .terrain_procgen import (add_boxes_to_hf2, add_stairs_to_hf, draw_box, gen_paths_hf, linear_parkour_course,  # noqa: E402,F401
+                              random_linear_parkour_course)

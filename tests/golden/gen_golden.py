@@ -526,7 +526,44 @@ def gen_dataset_yaml():
     print("wrote g11_dataset_yaml.json", len(entries), "entries")
 
 
+def _seed_all(k):
+    import random
+    torch.manual_seed(k)
+    random.seed(k)
+    np.random.seed(k)
+
+
+def gen_procgen():
+    """G12: the procedural terrain generators (util/terrain_util.py:320-470,544-595,864-1043) under fixed torch / random /
+    numpy seeds: boxes with the kin-gen parameters (parc_2_kin_gen.py:36-43), stairs, curvy paths, gap / vault course."""
+    out = {}
+    _seed_all(12)
+    hf = torch.zeros((16, 16), dtype=torch.float32)
+    terrain_util.add_boxes_to_hf2(hf, box_max_height=3.0, box_min_height=-3.0, num_boxes=10, box_max_len=10, box_min_len=5)
+    out["boxes_hf"] = hf.numpy().copy()
+    _seed_all(13)
+    t = terrain_util.SubTerrain("s", 24, 20, 0.4, 0.4, -1.0, 0.5, device="cpu")
+    terrain_util.add_stairs_to_hf(t, num_stairs=2)
+    out["stairs_hf"] = t.hf.numpy().copy()
+    _seed_all(14)
+    t = terrain_util.SubTerrain("p", 30, 28, 0.4, 0.4, -2.0, -3.0, device="cpu")
+    terrain_util.gen_paths_hf(t, num_paths=3)
+    out["paths_hf"] = t.hf.numpy().copy()
+    _seed_all(15)
+    # (numpy terrain: with torch fields the reference's round(y / dy) raises under torch 2.10)
+    t = terrain_util.SubTerrain("c", 6, 400, 0.1, 0.1, 0.0, 0.0, device="cpu").numpy_copy()
+    t2, v, tr = terrain_util.random_linear_parkour_course(t, gap_width=11, gap_height=-1.0, vault_width=1, vault_height=1.0,
+                                                          num_padding_cells=4)
+    out["course_hf"] = np.asarray(t2.hf).copy()
+    out["course_verts"] = v
+    out["course_tris"] = tr
+    save("g12_procgen", **out)
+
+
 def main():
+    if "--only-procgen" in sys.argv:
+        gen_procgen()
+        return
     if "--only-dataset-yaml" in sys.argv:
         gen_dataset_yaml()
         return
@@ -548,6 +585,7 @@ def main():
     gen_td_lambda(rng)
     gen_voxel_mesh(np.random.default_rng(10))
     gen_dataset_yaml()
+    gen_procgen()
 
 
 if __name__ == "__main__":

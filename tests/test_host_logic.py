@@ -228,3 +228,40 @@ def test_create_dataset_yaml_matches_reference(tmp_path):
         assert False
     except NotImplementedError:
         pass
+
+
+def test_procgen_terrains_match_reference_under_seeds():
+    """G12: boxes / stairs / curvy paths / gap-vault course reproduce the reference's heightfields (and course mesh) bit for
+    bit when the torch, random and numpy generators are seeded alike."""
+    import random
+    from parc_amd.util import terrain_util
+    z = golden("g12_procgen")
+
+    def seed(k):
+        torch.manual_seed(k)
+        random.seed(k)
+        np.random.seed(k)
+
+    def ter(nx, ny, dx, mx, my):
+        return terrain_util.SubTerrain("t", nx, ny, dx, dx, mx, my, device="cpu")
+    seed(12)
+    hf = torch.zeros((16, 16), dtype=torch.float32)
+    terrain_util.add_boxes_to_hf2(hf, box_max_height=3.0, box_min_height=-3.0, num_boxes=10, box_max_len=10, box_min_len=5)
+    np.testing.assert_array_equal(hf.numpy(), z["boxes_hf"])
+    assert len(np.unique(z["boxes_hf"])) > 3
+    seed(13)
+    t = ter(24, 20, 0.4, -1.0, 0.5)
+    terrain_util.add_stairs_to_hf(t, num_stairs=2)
+    np.testing.assert_array_equal(t.hf.numpy(), z["stairs_hf"])
+    seed(14)
+    t = ter(30, 28, 0.4, -2.0, -3.0)
+    terrain_util.gen_paths_hf(t, num_paths=3)
+    np.testing.assert_array_equal(t.hf.numpy(), z["paths_hf"])
+    seed(15)
+    t = ter(6, 400, 0.1, 0.0, 0.0).numpy_copy()
+    t2, v, tr = terrain_util.random_linear_parkour_course(t, gap_width=11, gap_height=-1.0, vault_width=1, vault_height=1.0,
+                                                          num_padding_cells=4)
+    np.testing.assert_array_equal(np.asarray(t2.hf), z["course_hf"])
+    assert set(np.unique(z["course_hf"]).tolist()) == {-1.0, 0.0, 1.0}
+    np.testing.assert_array_equal(v, z["course_verts"])
+    np.testing.assert_array_equal(tr, z["course_tris"])
