@@ -58,14 +58,43 @@ def walking_clip(rng, num_frames, fps=30.0, speed=1.0, start_xy=(0.0, 0.0), head
     return fr.astype(np.float32), con
 
 
-def make_dataset(num_clips=64, seed=0, tile_cells=16, dx=0.4, frames_range=(120, 254), flat=False, boxes=10):
-    """-> list of dict(frames, contacts, fps, loop, weight, hf, min_point, dxdy) with per-clip local terrains."""
+def parkour_heightfield(kind, seed, dim, dx):
+    """Stairs / curvy raised paths / both, from the reference's generators (util/terrain_procgen.py; BASELINE configs[4])."""
+    import random
+    import torch
+    from .util import terrain_util
+    state = (torch.random.get_rng_state(), random.getstate(), np.random.get_state())
+    torch.manual_seed(seed)
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    try:
+        t = terrain_util.SubTerrain("t", dim, dim, dx, dx, -dim * dx / 2 + dx / 2, -dim * dx / 2 + dx / 2, device="cpu")
+        if kind in ("paths", "mix"):
+            terrain_util.gen_paths_hf(t, num_paths=4, maxpool_size=1, floor_height=0.0, path_min_height=-0.5, path_max_height=1.5, num_points=300)
+        if kind in ("stairs", "mix"):
+            terrain_util.add_stairs_to_hf(t, min_stair_start_height=-1.0, max_stair_start_height=0.5, num_stairs=2)
+        return t.hf.numpy().astype(np.float32).copy()
+    finally:
+        torch.random.set_rng_state(state[0])
+        random.setstate(state[1])
+        np.random.set_state(state[2])
+
+
+def make_dataset(num_clips=64, seed=0, tile_cells=16, dx=0.4, frames_range=(120, 254), flat=False, boxes=10, terrain_kind="boxes"):
+    """-> list of dict(frames, contacts, fps, loop, weight, hf, min_point, dxdy) with per-clip local terrains.
+    terrain_kind: "boxes" (kin-gen recipe) or "stairs" / "paths" / "mix" (parkour terrains), cycled per clip for "parkour"."""
     rng = np.random.default_rng(seed)
     clips = []
     size = tile_cells * dx
     for k in range(num_clips):
         nf = int(rng.integers(frames_range[0], frames_range[1] + 1))
-        hf = np.zeros((tile_cells, tile_cells), np.float32) if flat else box_heightfield(rng, tile_cells, tile_cells, boxes)
+        kind = ("stairs", "paths", "mix", "boxes")[k % 4] if terrain_kind == "parkour" else terrain_kind
+        if flat:
+            hf = np.zeros((tile_cells, tile_cells), np.float32)
+        elif kind == "boxes":
+            hf = box_heightfield(rng, tile_cells, tile_cells, boxes)
+        else:
+            hf = parkour_heightfield(kind, 1000 * seed + k, tile_cells, dx)
         min_point = np.array([-size / 2 + dx / 2, -size / 2 + dx / 2], dtype=np.float32)   # cell centres symmetric about 0
         heading = rng.random() * 2 * np.pi
         dur = (nf - 1) / 30.0

@@ -246,3 +246,28 @@ def test_fused_linear_relu_matches_plain_layers():
         assert torch.allclose(a, b, rtol=2e-3, atol=2e-3 * float(b.abs().max())), float((a - b).abs().max())
     with torch.no_grad():
         assert torch.allclose(net(x), y_ref, rtol=1e-4, atol=1e-4)
+
+
+def test_parkour_terrain_workload_rollout_and_record(tmp_path):
+    """BASELINE configs[4] shape at test size: stairs / curvy paths / boxes tiles from the reference's generators, a short
+    training rollout (graph path, device reset) and the deterministic record rollout of parc_4_phys_record."""
+    from parc_amd import workloads
+    from parc_amd.util import safe_pickle
+    torch.manual_seed(1)
+    e, clips, tiled = workloads.build_env("parkour_32clips", 64, DEV, seed=0)
+    assert tiled[0].shape == (6 * 34, 6 * 34) and float(tiled[0].max()) > 1.0
+    agent = workloads.build_agent(e, DEV, steps_per_iter=8, update_epochs=1, batch_size=2)
+    agent._curr_obs, agent._curr_info = e.reset()
+    agent._init_train()
+    info = agent._train_iter()
+    assert np.isfinite(info["mean_return"]) and torch.isfinite(e._obs_buf).all()
+    hfcols = e._obs_buf[:, 871:]
+    assert float(hfcols.min()) >= -3.0 and float(hfcols.max()) <= 3.0 and float(hfcols.std()) > 0.05    # the fans see relief
+    # record mode: deterministic policy, one clip per env, files in the reference's motion format
+    e._output_motion_dir = str(tmp_path / "recorded")
+    ok = agent.record_motions(max_steps=40)
+    files = sorted((tmp_path / "recorded").glob("*.pkl"))
+    assert len(ok) == 64 or ok is not None
+    if files:
+        d = safe_pickle.load_motion_file_safe(str(files[0]))
+        assert d["frames"].shape[1] == 34 and d["contacts"].shape[1] == 15 and d["fps"] == 30
