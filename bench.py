@@ -174,6 +174,18 @@ def main():
             tj = json.load(f)
         if tj.get("envs") == N:
             traffic = tj["traffic_bytes_corrected"]
+    # the kernel's arithmetic intensity sits above the VALU/HBM ridge: also report it against the vector-issue
+    # peak, from the SQ_INSTS_VALU count of the same PMC profile set (1024 SIMDs, 4 cycles per wave64 instruction, 2.4 GHz)
+    valu = None
+    sp = os.path.join(ROOT, "profiles", "r01_post_step_sq_counters.json")
+    if args.workload == "boxes_64clips" and N == 4096 and os.path.exists(sp):
+        with open(sp) as f:
+            n_valu = json.load(f)["per_dispatch_mean"].get("SQ_INSTS_VALU")
+        if n_valu:
+            issue_us = n_valu * 4.0 / (1024 * 2.4e3)
+            valu = {"wave_instructions_per_launch": n_valu, "lane_ops_per_algorithmic_byte": n_valu * 64.0 / alg_bytes,
+                    "ridge_lane_ops_per_byte": 1024 * 16 * 2.4e9 / (HBM_PEAK_GBPS * 1e9), "issue_bound_us": issue_us,
+                    "frac_of_valu_issue_peak": issue_us / kern_b2b_us}
 
     def time_launches(fn, iters):
         for _ in range(5):
@@ -239,7 +251,7 @@ def main():
             "roofline": {"kernel": "track_post_kernel (fused K5 heightmap gather + K3 K2 K4 K6-K10)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": kern_b2b_us,
-                         "us_per_launch_event_pairs_in_rollout_loop": kern_us, "launches_event_timed": len(evs)},
+                         "us_per_launch_event_pairs_in_rollout_loop": kern_us, "launches_event_timed": len(evs), "valu": valu},
             "rollout": ("one hipGraph replay per env step" + (", finished envs reset on the device inside the graph" if any(k[2] for k in agent._graphs)
                                                                else " + eager reset of finished envs")) if agent._graphs else "eager",
             "kernels": extra,
