@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--workload", default="boxes_64clips")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grad-allreduce", default="minibatch", choices=["minibatch", "epoch"],
+                    help="minibatch = the reference's cadence (default); epoch = one parameter exchange per PPO epoch (north-star)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,6 +107,7 @@ def main():
 
     env, clips, tiled = workloads.build_env(args.workload, args.envs, dev, seed=0)
     agent = workloads.build_agent(env, dev, mp_scale_rollout=False)
+    agent._optimizer._cadence = args.grad_allreduce
     N, T = env.get_num_envs(), agent._steps_per_iter
     agent._curr_obs, agent._curr_info = env.reset()
     agent._init_train()
@@ -247,7 +250,8 @@ def main():
                        if args.workload == "boxes_64clips" else args.workload,
                        "envs_per_gpu": N, "env_steps_per_bench_step": N * T, "rollout_steps": T, "update_epochs": agent._update_epochs,
                        "minibatch": agent._batch_size * N, "sim_substeps": env._sim_steps * env._substeps, "parallelism": "dp{}".format(world),
-                       "grad_allreduce": "per minibatch (reference cadence)"},
+                       "grad_allreduce": "per minibatch (reference cadence)" if args.grad_allreduce == "minibatch"
+                       else "per PPO epoch (parameter + momentum averaging)"},
             "roofline": {"kernel": "track_post_kernel (fused K5 heightmap gather + K3 K2 K4 K6-K10)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": kern_b2b_us,

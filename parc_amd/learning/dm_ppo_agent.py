@@ -493,6 +493,7 @@ class DMPPOAgent(torch.nn.Module):
                 for k, v in info.items():
                     v = v.detach()
                     acc[k] = acc[k] + v if k in acc else v.clone()
+            self._optimizer.end_epoch()          # exchange point of the per-epoch cadence (optimizer: grad_allreduce "epoch")
         steps = self._update_epochs * num_batches
         return {k: v / steps for k, v in acc.items()}
 

@@ -15,6 +15,11 @@ class MPOptimizer:
     def __init__(self, config, param_list):
         self._param_list = param_list
         self._steps = 0
+        # "minibatch": all-reduce the gradient on every step (the reference's cadence, default).
+        # "epoch": the north-star's cadence - one exchange per PPO epoch: ranks step locally and end_epoch() averages the
+        # parameters and the optimizer's moment buffers in one flat all-reduce (local SGD with periodic averaging).
+        self._cadence = config.get("grad_allreduce", "minibatch")
+        assert self._cadence in ("minibatch", "epoch")
         lr = float(config["learning_rate"])
         wd = float(config.get("weight_decay", 0.0))
         if config["type"] == "SGD":
@@ -34,7 +39,7 @@ class MPOptimizer:
     def step(self, loss, **kwargs):
         self._flat_grad.zero_()
         loss.backward()
-        if mp_util.enable_mp():
+        if mp_util.enable_mp() and self._cadence == "minibatch":
             torch.distributed.all_reduce(self._flat_grad, op=torch.distributed.ReduceOp.SUM)
             self._flat_grad /= mp_util.get_num_procs()
         if "model" in kwargs:
@@ -43,9 +48,27 @@ class MPOptimizer:
             norm = torch.linalg.vector_norm(self._flat_grad)
             self._flat_grad *= torch.clamp(max_norm / (norm + 1e-6), max=1.0)
         self._optimizer.step()
-        if mp_util.enable_mp() and self._steps % self.CHECK_SYNC_STEPS == 0:
+        if mp_util.enable_mp() and self._cadence == "minibatch" and self._steps % self.CHECK_SYNC_STEPS == 0:
             assert self._check_synced(), "Network parameters desynchronized"
         self._steps += 1
+
+    def end_epoch(self):
+        """Per-epoch exchange of the "epoch" cadence: average parameters and float optimizer state over the ranks with ONE
+        all-reduce of a flat buffer (no-op for the per-minibatch cadence or a single process)."""
+        if not (mp_util.enable_mp() and self._cadence == "epoch"):
+            return
+        with torch.no_grad():
+            tensors = list(self._param_list)
+            for p in self._param_list:
+                st = self._optimizer.state.get(p, {})
+                tensors += [v for v in st.values() if torch.is_tensor(v) and v.is_floating_point() and v.numel() == p.numel()]
+            flat = torch.cat([t.reshape(-1) for t in tensors])
+            torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
+            flat /= mp_util.get_num_procs()
+            off = 0
+            for t in tensors:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
 
     def get_steps(self):
         return self._steps

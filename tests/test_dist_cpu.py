@@ -38,8 +38,20 @@ def _worker(rank, world, port, out):
     nrm.record(torch.full((5, 3), float(rank + 1)))
     nrm.update()
     # plain numpy in the queue: torch tensors would be handed over through shared-memory handles that die with the child
+    # per-epoch cadence: local steps diverge, end_epoch() averages parameters and momentum buffers
+    torch.manual_seed(200 + rank)
+    m2 = torch.nn.Linear(4, 2)
+    o2 = mp_optimizer.MPOptimizer({"type": "SGD", "learning_rate": 0.05, "grad_allreduce": "epoch"}, list(m2.parameters()))
+    for k in range(3):
+        xx = torch.randn(5, 4)
+        o2.step(torch.mean(torch.square(m2(xx) - float(rank))))
+    local = [p.detach().clone() for p in m2.parameters()]
+    mom_local = [o2._optimizer.state[p]["momentum_buffer"].clone() for p in m2.parameters()]
+    o2.end_epoch()
+    epoch_res = ([p.numpy().copy() for p in local], [p.detach().numpy().copy() for p in m2.parameters()],
+                 [b.numpy().copy() for b in mom_local], [o2._optimizer.state[p]["momentum_buffer"].numpy().copy() for p in m2.parameters()])
     out.put((rank, [p.detach().numpy().copy() for p in model.parameters()], [w.numpy().copy() for w in w_init],
-             nrm._mean.detach().numpy().copy(), nrm._count.item(), mp_util.reduce_sum(rank + 1)))
+             nrm._mean.detach().numpy().copy(), nrm._count.item(), mp_util.reduce_sum(rank + 1), epoch_res))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -56,7 +68,17 @@ def test_dp_optimizer_and_normalizer_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     T = torch.from_numpy
-    res = [(r, [T(a) for a in w], [T(a) for a in i], T(m), c, s) for r, w, i, m, c, s in res]
+    epoch = [t[6] for t in res]
+    res = [(r, [T(a) for a in w], [T(a) for a in i], T(m), c, s) for r, w, i, m, c, s, _e in res]
+    # per-epoch cadence: after end_epoch both ranks hold the mean of the two local parameter / momentum sets
+    import numpy as np
+    for k in range(2):
+        assert not np.allclose(epoch[0][0][k], epoch[1][0][k])                    # local steps really diverged
+        mean_p = 0.5 * (epoch[0][0][k] + epoch[1][0][k])
+        mean_m = 0.5 * (epoch[0][2][k] + epoch[1][2][k])
+        for r in range(2):
+            np.testing.assert_allclose(epoch[r][1][k], mean_p, rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(epoch[r][3][k], mean_m, rtol=1e-6, atol=1e-7)
     (r0, w0, init0, m0, c0, s0), (r1, w1, init1, m1, c1, s1) = res
     for a, b in zip(init0, init1):
         assert torch.equal(a, b)                        # broadcast from rank 0 at construction
