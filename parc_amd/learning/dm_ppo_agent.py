@@ -292,17 +292,29 @@ class DMPPOAgent(torch.nn.Module):
             eb.set_device_head(self._head_t)
             self._in_graph_step = True
             count0 = self._obs_norm._new_count
+            captured = False
             try:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self._graph_pool):
+                # thread_local: calls made by other threads of the process (e.g. the RCCL watchdog of a multi-GPU job) must
+                # not invalidate the capture
+                with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
                     done = self._train_step_body(device_reset)
                 if self._graph_pool is None:
                     self._graph_pool = g.pool()
+                captured = True
+            except Exception as exc:                 # keep training: eager launches are always available
+                Logger.print("hipGraph capture of the rollout step failed ({}); continuing with eager launches".format(exc))
+                self._use_hip_graph = False
             finally:
                 eb.set_device_head(None)
                 self._in_graph_step = False
             self._obs_norm._new_count = count0       # capture enqueues nothing; the replay below is this step
+            if not captured:
+                torch.cuda.synchronize()
+                done = self._train_step_body(False)
+                self._graph_fallback_reset = True
+                return done
             self._graphs[key] = (g, done)
         g, done = self._graphs[key]
         g.replay()
@@ -316,6 +328,9 @@ class DMPPOAgent(torch.nn.Module):
             if self._graph_ok():
                 dev_reset = self._device_reset_ok()
                 done = self._train_step_graph(dev_reset)
+                if getattr(self, "_graph_fallback_reset", False):     # capture failed: this step ran eagerly without the device reset
+                    self._graph_fallback_reset = False
+                    dev_reset = False
             else:
                 dev_reset = False
                 done = self._train_step_body()
