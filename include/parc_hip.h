@@ -235,6 +235,13 @@ int parc_ppo_loss(void *stream, int B, int A, const float *mean, const float *lo
                   float *g_logstd, float *g_pred, float *out, float *workspace);
 int parc_ppo_workspace_floats(int B);
 
+/* ---- measurement knobs (exported for tools/bench_kernels.py; not part of the stable ABI, defaults are the product path) ----
+ * parc_tune_hf_envs_per_block(1|2|4|8): envs per workgroup of the standalone heightmap kernel;
+ * parc_tune_hf_ablation(0..5): timing-only variants of it (outputs wrong for != 0);
+ * bits 16/17/18 of `what` in parc_track_post_step drop the target / reference / character waves (timing only). */
+int parc_tune_hf_envs_per_block(int envs_per_block);
+int parc_tune_hf_ablation(int variant);
+
 int parc_abi_version(void);
 
 #ifdef __cplusplus

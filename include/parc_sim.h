@@ -63,6 +63,11 @@ int parc_sim_refresh_bodies(void *stream, const parc_sim_model_t *model, int n_e
 int parc_sim_refresh_bodies_masked(void *stream, const parc_sim_model_t *model, int n_envs, const int32_t *mask,
                                    const float *root_state, const float *dof_state, float *rigid_body_state, float *contact_forces);
 
+/* measurement knobs (not part of the stable ABI): parc_tune_sim_variant(1 = body-per-lane kernel, default; 0 = one env per
+ * lane, the single-source reference core), parc_tune_sim_threads(8|16|32|64) lanes per workgroup of variant 0 */
+int parc_tune_sim_variant(int variant);
+int parc_tune_sim_threads(int threads);
+
 int parc_sim_abi(void);
 
 #ifdef __cplusplus
