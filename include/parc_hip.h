@@ -235,6 +235,19 @@ int parc_ppo_loss(void *stream, int B, int A, const float *mean, const float *lo
                   float *g_logstd, float *g_pred, float *out, float *workspace);
 int parc_ppo_workspace_floats(int B);
 
+/* ---- K15 experience record: ExperienceBuffer.record  learning/experience_buffer.py:55-59 for a group of buffers at once.
+ * Field f copies src [N, row_bytes] into row *head of dst [T, N, row_bytes] (row_bytes a multiple of 4; 16-byte vector copies
+ * when sizes and pointers allow).  convert = 1: src is int64 [N], dst int32 [T, N] (the reference's ep_num buffer), row_bytes = 8.
+ * head: device int64 scalar (so the launch can sit inside a captured graph); fields: HOST array of n_fields <= 8 descriptors,
+ * read during the call (they travel as kernel arguments). */
+typedef struct {
+    const void *src;
+    void *dst;
+    int32_t row_bytes;
+    int32_t convert;
+} parc_record_field_t;
+int parc_record_step(void *stream, int n_envs, const int64_t *head, int n_fields, const parc_record_field_t *fields);
+
 /* ---- measurement knobs (exported for tools/bench_kernels.py; not part of the stable ABI, defaults are the product path) ----
  * parc_tune_hf_envs_per_block(1|2|4|8): envs per workgroup of the standalone heightmap kernel;
  * parc_tune_hf_ablation(0..5): timing-only variants of it (outputs wrong for != 0);

@@ -81,6 +81,10 @@ class EnvBuffersS(ctypes.Structure):
                 ("env_mask", c_vp), ("init_noise_xy", c_vp)]
 
 
+class RecordFieldS(ctypes.Structure):
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("row_bytes", c_i32), ("convert", c_i32)]
+
+
 class PPOCfgS(ctypes.Structure):
     _fields_ = [("clip_ratio", c_f), ("bound_w", c_f), ("entropy_w", c_f), ("reg_w", c_f), ("critic_w", c_f),
                 ("large_critic_loss", c_f), ("critic_l1", c_i32)]
@@ -149,6 +153,8 @@ def _declare(L):
     L.parc_ppo_loss.restype = c_int
     L.parc_ppo_workspace_floats.argtypes = [c_int]
     L.parc_ppo_workspace_floats.restype = c_int
+    L.parc_record_step.argtypes = [c_vp, c_int, c_vp, c_int, c_vp]
+    L.parc_record_step.restype = c_int
     L.parc_reset_apply.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int] + [c_vp] * 9
     L.parc_reset_apply.restype = c_int
     for name in ("parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
@@ -162,7 +168,7 @@ def _declare(L):
 
 EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
             "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step",
-            "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize", "parc_reset_apply", "parc_ppo_loss", "parc_ppo_workspace_floats"]
+            "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize", "parc_reset_apply", "parc_ppo_loss", "parc_ppo_workspace_floats", "parc_record_step"]
 
 
 def check(rc, what):

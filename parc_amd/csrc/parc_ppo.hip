@@ -159,3 +159,51 @@ extern "C" int parc_ppo_loss(void *stream, int B, int A, const float *mean, cons
 }
 
 extern "C" int parc_ppo_workspace_floats(int B) { return ((B + PPO_THREADS - 1) / PPO_THREADS) * PPO_W; }
+
+// =============================================================================================
+// K15 experience record: ExperienceBuffer.record (learning/experience_buffer.py:55-59) for a whole group of named buffers in one
+// launch: field f copies its [N, row] source into row `*head` of its time-major [T, N, row] buffer.  head is a DEVICE scalar
+// so the launch can sit inside the captured rollout graph.
+// =============================================================================================
+#define PARC_RECORD_MAX_FIELDS 8
+struct record_fields_t {
+    parc_record_field_t f[PARC_RECORD_MAX_FIELDS];
+};
+
+__global__ __launch_bounds__(256) void record_step_kernel(int n_envs, const int64_t *__restrict__ head, record_fields_t fields) {
+    const parc_record_field_t f = fields.f[blockIdx.y];
+    const size_t total = (size_t)n_envs * (size_t)f.row_bytes;            // bytes of one time row
+    const size_t h = (size_t)head[0];
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    if (f.convert == 1) {                                                 // int64 source -> int32 buffer (ep_num)
+        const int64_t *s = (const int64_t *)f.src;
+        int32_t *d = (int32_t *)f.dst + h * (total / 8);
+        for (size_t i = tid; i < total / 8; i += nthr) d[i] = (int32_t)s[i];
+        return;
+    }
+    char *d = (char *)f.dst + h * total;
+    const char *s = (const char *)f.src;
+    if (((total | (uintptr_t)d | (uintptr_t)s) & 15) == 0) {
+        for (size_t i = tid; i < total / 16; i += nthr) ((uint4 *)d)[i] = ((const uint4 *)s)[i];
+    } else {
+        for (size_t i = tid; i < total / 4; i += nthr) ((uint32_t *)d)[i] = ((const uint32_t *)s)[i];
+    }
+}
+
+extern "C" int parc_record_step(void *stream, int n_envs, const int64_t *head, int n_fields, const parc_record_field_t *fields) {
+    if (n_envs <= 0 || n_fields <= 0 || n_fields > PARC_RECORD_MAX_FIELDS || !head || !fields) return PARC_EINVAL;
+    record_fields_t args;
+    int max_row = 0;
+    for (int i = 0; i < n_fields; ++i) {
+        args.f[i] = fields[i];
+        if (fields[i].row_bytes <= 0 || (fields[i].row_bytes & 3) || !fields[i].src || !fields[i].dst) return PARC_EINVAL;
+        if (fields[i].row_bytes > max_row) max_row = fields[i].row_bytes;
+    }
+    for (int i = n_fields; i < PARC_RECORD_MAX_FIELDS; ++i) args.f[i] = fields[0];
+    size_t units = ((size_t)n_envs * (size_t)max_row + 15) / 16;
+    unsigned gx = (unsigned)((units + 255) / 256);
+    if (gx > 2048u) gx = 2048u;                                          // grid-stride beyond that
+    hipLaunchKernelGGL(record_step_kernel, dim3(gx, (unsigned)n_fields), dim3(256), 0, (hipStream_t)stream, n_envs, head, args);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}

@@ -226,6 +226,14 @@ class DMPPOAgent(torch.nn.Module):
 
     def _record_data_pre_step(self, obs, info, action, action_info):
         eb = self._exp_buffer
+        if getattr(self, "_in_graph_step", False):
+            # captured step: the five pre-step buffers in one launch (K15), sources at stable addresses
+            if self._need_normalizer_update():
+                self._obs_norm.record(obs)
+            eb.record_group([("obs", obs), ("action", action), ("a_logp", action_info["a_logp"]),
+                             ("rand_action_mask", action_info["rand_action_mask"]),
+                             ("prev_char_contact_forces", self._env._char_contact_forces)])
+            return
         eb.record("obs", obs)
         eb.record("action", action)
         if self._need_normalizer_update():
@@ -239,6 +247,14 @@ class DMPPOAgent(torch.nn.Module):
 
     def _record_data_post_step(self, next_obs, r, done, next_info):
         eb = self._exp_buffer
+        if getattr(self, "_in_graph_step", False):
+            eb.record_group([("next_obs", next_obs), ("reward", r), ("done", done), ("timestep", next_info["timestep"]),
+                             ("ep_num", next_info["ep_num"]), ("next_char_contact_forces", next_info["char_contact_forces"]),
+                             ("env_id", self._env_ids)])
+            if self._is_terrain_runner:
+                eb.record("replan_timer", self._env.get_replan_time_buf().expand(self.get_num_envs()))
+                eb.record("replan_counter", self._env.get_replan_counter())
+            return
         eb.record("next_obs", next_obs)
         eb.record("reward", r)
         eb.record("done", done)

@@ -50,6 +50,30 @@ class ExperienceBuffer:
         else:
             self._buffers[name][self._buffer_head] = data
 
+    def record_group(self, items):
+        """record() for several buffers in ONE launch (K15, parc_record_step): items = [(name, tensor [N, ...]), ...].
+        GPU only, with a device head (the captured rollout step); falls back to record() otherwise."""
+        if self._device_head is None or not items[0][1].is_cuda:
+            for name, data in items:
+                self.record(name, data)
+            return
+        from .. import _hip
+        arr = (_hip.RecordFieldS * len(items))()
+        keep = []
+        for i, (name, data) in enumerate(items):
+            buf = self._buffers[name]
+            assert data.shape[0] == self._batch_size
+            conv = 1 if (data.dtype == torch.int64 and buf.dtype == torch.int32) else 0
+            if not conv and data.dtype != buf.dtype:
+                data = data.to(buf.dtype)
+            data = data.contiguous()
+            keep.append(data)
+            row = data[0].numel() * data.element_size()
+            assert row % 4 == 0 and (conv == 1 or row == buf[0, 0].numel() * buf.element_size())
+            arr[i] = _hip.RecordFieldS(data.data_ptr(), buf.data_ptr(), row, conv)
+        _hip.check(_hip.lib().parc_record_step(_hip.stream(), self._batch_size, _hip.ptr(self._device_head), len(items), arr),
+                   "parc_record_step")
+
     def set_device_head(self, head_t):
         """head_t: int64 device tensor [1] mirroring ``_buffer_head`` (None switches back to host indexing)."""
         self._device_head = head_t
