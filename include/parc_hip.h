@@ -105,6 +105,7 @@ typedef struct {
     int32_t num_ray_points;                      /* 441 */
     int32_t obs_dim;                             /* 1312 */
     float task1_w, task2_w, target_radius;       /* task reward terms, logged only while rel_task_w == 0 */
+    float target_future_min, target_future_max;  /* dm.target_xy_future_time_min/max (PARC_POST_TARGETS) */
 } parc_track_cfg_t;
 
 /*
@@ -135,6 +136,9 @@ typedef struct {
     /* device-side reset (no host round trip): see PARC_POST_MASKED / PARC_POST_INIT_CHAR; both may be NULL otherwise */
     const int32_t *env_mask;        /* [N]  nonzero = env takes part in a PARC_POST_MASKED launch */
     const float *init_noise_xy;     /* [N,2] or NULL: added to the root xy written by PARC_POST_INIT_CHAR (already scaled) */
+    /* PARC_POST_TARGETS: DeepMimicEnv._update_motion_targets (dm_env.py:617-654) inside the launch */
+    float *next_target_time;        /* [N]   time at which an env draws its next xy target */
+    const float *target_rand;       /* [N,3] uniforms in [0,1): look-ahead time, and a Box-Muller pair for the 0.05 m target noise */
 } parc_env_buffers_t;
 
 /* ---- K5: local heightmap ---------------------------------------------------------------------
@@ -193,6 +197,10 @@ int parc_motion_lib_build(void *stream, parc_char_model_t model, parc_motion_lib
  * written through their const pointers in this mode only). */
 #define PARC_POST_MASKED 16
 #define PARC_POST_INIT_CHAR 32
+/* bit6: envs whose time reached next_target_time draw a new xy target = clip root position at (clip time + U[future_min,
+ * future_max]) + N(0, 0.05 m), written to target_xy / next_target_time (target_xy is written through its const pointer in
+ * this mode only) before the task reward terms read it. */
+#define PARC_POST_TARGETS 64
 int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
                          parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
                          const float *ray_xy);

@@ -27,6 +27,7 @@ POST_REWARD_DONE = 4
 POST_HF = 8
 POST_MASKED = 16
 POST_INIT_CHAR = 32
+POST_TARGETS = 64
 
 c_int = ctypes.c_int
 c_i32 = ctypes.c_int32
@@ -66,7 +67,8 @@ class TrackCfgS(ctypes.Structure):
                 ("num_contact_bodies", c_i32), ("contact_body_mask", c_i32 * MAX_BODIES),
                 ("episode_length", c_f), ("contact_eps", c_f), ("min_obs_h", c_f), ("max_obs_h", c_f),
                 ("num_ray_points", c_i32), ("obs_dim", c_i32),
-                ("task1_w", c_f), ("task2_w", c_f), ("target_radius", c_f)]
+                ("task1_w", c_f), ("task2_w", c_f), ("target_radius", c_f),
+                ("target_future_min", c_f), ("target_future_max", c_f)]
 
 
 class EnvBuffersS(ctypes.Structure):
@@ -78,7 +80,7 @@ class EnvBuffersS(ctypes.Structure):
                 ("ref_joint_rot", c_vp), ("ref_dof_vel", c_vp), ("ref_dof_pos", c_vp),
                 ("ref_contacts", c_vp), ("ref_body_pos", c_vp),
                 ("obs", c_vp), ("reward", c_vp), ("reward_terms", c_vp), ("done", c_vp), ("done_kind", c_vp),
-                ("env_mask", c_vp), ("init_noise_xy", c_vp)]
+                ("env_mask", c_vp), ("init_noise_xy", c_vp), ("next_target_time", c_vp), ("target_rand", c_vp)]
 
 
 class RecordFieldS(ctypes.Structure):

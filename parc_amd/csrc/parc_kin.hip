@@ -592,6 +592,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     __shared__ float hfp[POST_EPB][8];
     __shared__ __attribute__((aligned(16))) float envd[POST_EPB][12];                            // root pos 3 | root rot 4 | heading^-1 4 | env id
     __shared__ __attribute__((aligned(16))) float qryd[1 + PARC_MAX_TAR_STEPS][POST_EPB][8];    // frame idx0, idx1, blend, root xyz
+    __shared__ float tgt_xy[POST_EPB][2];                                                       // xy target the task terms read
     const int tid = threadIdx.x;
     const int wv = tid >> 6, gg = (tid & 63) >> 4, b = tid & 15;
     const int B = m.num_bodies, J = B - 1, D = m.dof_size, K = cfg.num_key_bodies, S = cfg.num_tar_steps;
@@ -644,6 +645,37 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         float4 *qd = reinterpret_cast<float4 *>(qryd[pq][ple]);
         qd[0] = make_float4(__int_as_float(fq.idx0), __int_as_float(fq.idx1), fq.blend, pr.x);
         qd[1] = make_float4(pr.y, pr.z, 0.f, 0.f);
+    }
+    // xy target resample (PARC_POST_TARGETS): lanes 4 (1 + S) .. 4 (2 + S) - 1 of wave 0, one per env
+    if (wv == 0 && tid >= POST_EPB * (1 + S) && tid < POST_EPB * (2 + S)) {
+        const int ple = tid - POST_EPB * (1 + S);
+        const int pel = blockIdx.x * POST_EPB + ple;
+        const int pelc = min(pel, n_total - 1);
+        const int pe = env_ids ? (int)env_ids[pelc] : pelc;
+        float tx = buf.target_xy[2 * pe], ty = buf.target_xy[2 * pe + 1];
+        if ((what & PARC_POST_TARGETS) && pel < n_total && (!masked || buf.env_mask[pe] != 0)) {
+            // DeepMimicEnv._update_motion_targets  dm_env.py:617-654
+            const float tm = buf.time_buf[pe];
+            if (tm >= buf.next_target_time[pe]) {
+                const float *u = buf.target_rand + 3 * (size_t)pe;
+                const float fut = u[0] * (cfg.target_future_max - cfg.target_future_min) + cfg.target_future_min;
+                const int64_t mid = buf.motion_ids[pe];
+                const frame_query fq = make_query(ml, mid, tm + buf.motion_time_offsets[pe] + fut);
+                const v3 pr = query_root_pos(ml, fq, mid);
+                // N(0, 0.05) noise from the two remaining uniforms (Box-Muller)
+                const float rr = 0.05f * fsqrt(-2.0f * __logf(fmaxf(1.0f - u[1], 1e-12f)));
+                float sn, cs;
+                fsincos(6.283185307179586f * u[2], sn, cs);
+                tx = pr.x + buf.motion_xy_offset[2 * pe] - buf.env_offsets[3 * pe] + rr * cs;
+                ty = pr.y + buf.motion_xy_offset[2 * pe + 1] - buf.env_offsets[3 * pe + 1] + rr * sn;
+                float *wt = const_cast<float *>(buf.target_xy);
+                wt[2 * pe] = tx;
+                wt[2 * pe + 1] = ty;
+                buf.next_target_time[pe] = tm + fut;
+            }
+        }
+        tgt_xy[ple][0] = tx;
+        tgt_xy[ple][1] = ty;
     }
     // loads that do not depend on phase 0
     int key_slot = -1;
@@ -850,7 +882,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                     buf.reward_terms[5 * (size_t)N + e] = cp;
                     {
                         // task terms  ig_parkour_env.py:1346-1393 (logged; they scale the reward only if rel_task_w > 0)
-                        float tx = buf.target_xy[2 * e] - c_pos.x, ty = buf.target_xy[2 * e + 1] - c_pos.y;
+                        float tx = tgt_xy[le][0] - c_pos.x, ty = tgt_xy[le][1] - c_pos.y;
                         float terr = tx * tx + ty * ty;
                         float task_r1 = fexp(-0.075f * terr);
                         float tl = fsqrt(terr);
@@ -989,6 +1021,7 @@ extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_
     if (((uintptr_t)buf.obs & 15) || ((uintptr_t)mlib.frames & 15) || (mlib.row_stride & 3)) return PARC_EINVAL;
     if ((what & PARC_POST_MASKED) && (env_ids || !buf.env_mask)) return PARC_EINVAL;
     if ((what & PARC_POST_INIT_CHAR) && !(what & PARC_POST_REF)) return PARC_EINVAL;
+    if ((what & PARC_POST_TARGETS) && (!buf.next_target_time || !buf.target_rand)) return PARC_EINVAL;
     int n = env_ids ? n_sel : buf.num_envs;
     if (n < 0) return PARC_EINVAL;
     if (n == 0) return PARC_OK;

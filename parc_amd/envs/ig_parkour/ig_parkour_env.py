@@ -244,8 +244,8 @@ class IGParkourEnv(base_env.BaseEnv):
                                                           _hip.ptr(env_ids), int(env_ids.shape[0]), _hip.ptr(c.root_state),
                                                           _hip.ptr(c.dof_state), _hip.ptr(c.rigid_body_state), _hip.ptr(c.contact_forces)),
                        "parc_sim_refresh_bodies")
-            self._update_motion_targets()
-            c.post_step(_hip.POST_OBS | _hip.POST_HF, env_ids)
+            c.target_rand.uniform_()
+            c.post_step(_hip.POST_OBS | _hip.POST_HF | _hip.POST_TARGETS, env_ids)      # + xy target resample for these envs
             self._ep_num_buf[env_ids] += 1
         self._update_info()
         return self._obs_buf, self._info
@@ -281,8 +281,8 @@ class IGParkourEnv(base_env.BaseEnv):
         _hip.check(L.parc_sim_refresh_bodies_masked(_hip.stream(), self._sim_model.device_ptr(self._device), N, _hip.ptr(c.reset_mask),
                                                     _hip.ptr(c.root_state), _hip.ptr(c.dof_state), _hip.ptr(c.rigid_body_state),
                                                     _hip.ptr(c.contact_forces)), "parc_sim_refresh_bodies_masked")
-        self._update_motion_targets()
-        c.post_step(_hip.POST_OBS | _hip.POST_HF | _hip.POST_MASKED)
+        c.target_rand.uniform_()
+        c.post_step(_hip.POST_OBS | _hip.POST_HF | _hip.POST_MASKED | _hip.POST_TARGETS)
         self._update_info()
         return self._obs_buf, self._info
 
@@ -299,9 +299,9 @@ class IGParkourEnv(base_env.BaseEnv):
         # _update_time (ig_env.py:862-865)
         self._timestep_buf += 1
         torch.mul(self._timestep_buf, self._timestep, out=self._time_buf)
-        self._update_motion_targets()
-        # _update_misc/_update_observations/_update_reward/_update_done in one launch
-        c.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF)
+        # _update_misc (incl. the xy target resample) / _update_observations / _update_reward / _update_done in one launch
+        c.target_rand.uniform_()
+        c.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS)
         c.update_fail_rates(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight)
         if self._never_done:
             self._done_buf[:] = base_env.DoneFlags.NULL.value
@@ -311,8 +311,9 @@ class IGParkourEnv(base_env.BaseEnv):
         return self._obs_buf, self._reward_buf, self._done_buf, self._info
 
     def _update_motion_targets(self):
-        """DeepMimicEnv._update_motion_targets (dm_env.py:617-654) without the host sync of boolean indexing: every
-        env draws a candidate, only those whose timer expired take it.  Feeds the logged task reward only."""
+        """DeepMimicEnv._update_motion_targets (dm_env.py:617-654) as torch ops: every env draws a candidate, only those whose
+        timer expired take it.  The env itself now does this inside the post-step launch (PARC_POST_TARGETS); this version is
+        kept as the readable statement of the rule (tests compare the two).  Feeds the logged task reward only."""
         c = self._core
         dm = self._dm_env
         N = self._num_envs

@@ -93,6 +93,8 @@ class TrackerConfig:
         s.task1_w = float(env_config.get("task1_w", 0.7))
         s.task2_w = float(env_config.get("task2_w", 0.3))
         s.target_radius = float(env_config.get("target_radius", 1.0))
+        s.target_future_min = float(env_config["dm"]["target_xy_future_time_min"])
+        s.target_future_max = float(env_config["dm"]["target_xy_future_time_max"])
         K, S = len(keys), len(steps)
         self.char_obs_dim = 12 + 6 * J + D + 3 * K
         self.tar_obs_dim = 9 + 6 * J + 3 * K
@@ -152,6 +154,7 @@ class TrackerCore:
         # device-side reset (PARC_POST_MASKED / PARC_POST_INIT_CHAR)
         self.reset_mask = z((N,), dtype=torch.int, device=device)
         self.init_noise_xy = z((N, 2), **f32)
+        self.target_rand = z((N, 3), **f32)          # PARC_POST_TARGETS: per-env uniforms, refilled by the env before the launch
         self.ray_xy_points = ray_xy_points.to(device=device, dtype=torch.float32).contiguous()
         P = self.ray_xy_points.shape[0]
         assert P == cfg.struct.num_ray_points
@@ -178,7 +181,7 @@ class TrackerCore:
                 p(self.ref_root_pos), p(self.ref_root_rot), p(self.ref_root_vel), p(self.ref_root_ang_vel),
                 p(self.ref_joint_rot), p(self.ref_dof_vel), p(self.ref_dof_pos), p(self.ref_contacts), p(self.ref_body_pos),
                 p(self.obs), p(self.reward), p(self.reward_terms), p(self.done), p(self.done_kind),
-                p(self.reset_mask), p(self.init_noise_xy))
+                p(self.reset_mask), p(self.init_noise_xy), p(self.next_target_xy_time), p(self.target_rand))
         return self._buf_struct
 
     # ---- K5 (IGParkourEnv._refresh_obs_hfs)

@@ -271,3 +271,32 @@ def test_parkour_terrain_workload_rollout_and_record(tmp_path):
     if files:
         d = safe_pickle.load_motion_file_safe(str(files[0]))
         assert d["frames"].shape[1] == 34 and d["contacts"].shape[1] == 15 and d["fps"] == 30
+
+
+def test_in_kernel_target_resample_matches_rule(env):
+    """PARC_POST_TARGETS: envs whose timer expired take target = clip root xy at (clip time + U[min, max]) + N(0, 0.05) and a
+    new timer; the others keep both.  Checked against the rule evaluated with torch on the same uniforms."""
+    from parc_amd import _hip
+    c, dm = env._core, env._dm_env
+    env.reset()
+    act = torch.zeros((96, 28), device=DEV)
+    for _ in range(2):
+        env.step(act)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    u = torch.rand((96, 3), generator=g).to(DEV)
+    c.target_rand.copy_(u)
+    c.next_target_xy_time[:] = torch.where(torch.arange(96, device=DEV) % 3 == 0, torch.zeros(96, device=DEV), torch.full((96,), 1e9, device=DEV))
+    old_xy, old_t = c.target_xy.clone(), c.next_target_xy_time.clone()
+    c.post_step(_hip.POST_OBS | _hip.POST_TARGETS)
+    torch.cuda.synchronize()
+    due = old_t <= c.time_buf
+    assert due.sum().item() == 32
+    fut = u[:, 0] * (dm._target_xy_future_time_max - dm._target_xy_future_time_min) + dm._target_xy_future_time_min
+    root = dm._motion_lib.calc_motion_frame(c.motion_ids, c.time_buf + c.motion_time_offsets + fut)[0]
+    rr = 0.05 * torch.sqrt(-2.0 * torch.log(1.0 - u[:, 1]))
+    noise = torch.stack([rr * torch.cos(2 * np.pi * u[:, 2]), rr * torch.sin(2 * np.pi * u[:, 2])], dim=-1)
+    want = root[:, 0:2] + c.motion_xy_offset - c.env_offsets[:, 0:2] + noise
+    assert torch.allclose(c.target_xy[due], want[due], atol=2e-5)
+    assert torch.allclose(c.next_target_xy_time[due], (c.time_buf + fut)[due], atol=1e-6)
+    assert torch.equal(c.target_xy[~due], old_xy[~due]) and torch.equal(c.next_target_xy_time[~due], old_t[~due])
+    assert float(noise.std()) > 0.03 and float(noise.std()) < 0.07
