@@ -256,6 +256,13 @@ typedef struct {
 } parc_record_field_t;
 int parc_record_step(void *stream, int n_envs, const int64_t *head, int n_fields, const parc_record_field_t *fields);
 
+/* ---- K21 episodic return tracker: DMPPOReturnTracker.update  learning/dm_ppo_return_tracker.py:6-99 in one launch.
+ * rewards [K, reward_stride] (row k = term k, first n_envs entries), done [N] i32; state: return_buf [K,N], ep_len [N] i64,
+ * eps_per_env [N] i64, mean_return [K], mean_ep_len [1], episodes [1] f64.  K <= 12. */
+int parc_return_tracker_update(void *stream, int n_envs, int K, const float *rewards, int64_t reward_stride, const int32_t *done,
+                               float *return_buf, int64_t *ep_len, int64_t *eps_per_env, float *mean_return, float *mean_ep_len,
+                               double *episodes);
+
 /* ---- measurement knobs (exported for tools/bench_kernels.py; not part of the stable ABI, defaults are the product path) ----
  * parc_tune_hf_envs_per_block(1|2|4|8): envs per workgroup of the standalone heightmap kernel;
  * parc_tune_hf_ablation(0..5): timing-only variants of it (outputs wrong for != 0);

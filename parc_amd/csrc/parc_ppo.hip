@@ -207,3 +207,74 @@ extern "C" int parc_record_step(void *stream, int n_envs, const int64_t *head, i
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }
+
+// =============================================================================================
+// K21 episodic return tracker: DMPPOReturnTracker.update (learning/dm_ppo_return_tracker.py:6-99) in one launch.
+// One workgroup walks all envs: accumulate the K reward terms and the episode length, fold the envs that finished into the
+// running means (weights by episode count, as the reference), clear them.  Reductions in a fixed order (deterministic).
+// =============================================================================================
+#define TRK_THREADS 1024
+#define TRK_MAX_K 12
+
+__device__ __forceinline__ float lerp_torch(float a, float b, float w) { return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.0f - w); }
+
+__global__ __launch_bounds__(TRK_THREADS) void return_tracker_kernel(int n_envs, int K, const float *__restrict__ rewards, int64_t reward_stride,
+                                                                     const int32_t *__restrict__ done, float *return_buf, int64_t *ep_len,
+                                                                     int64_t *eps_per_env, float *mean_return, float *mean_ep_len, double *episodes) {
+    __shared__ float s_part[TRK_THREADS / 64][TRK_MAX_K + 2];
+    __shared__ float s_tot[TRK_MAX_K + 2];
+    const int tid = threadIdx.x;
+    float acc[TRK_MAX_K + 2];
+#pragma unroll
+    for (int k = 0; k < TRK_MAX_K + 2; ++k) acc[k] = 0.f;
+    for (int e = tid; e < n_envs; e += TRK_THREADS) {
+        const bool fin = done[e] != 0;
+        const int64_t len = ep_len[e] + 1;
+        if (fin) {
+            acc[TRK_MAX_K] += (float)len;
+            acc[TRK_MAX_K + 1] += 1.0f;
+            eps_per_env[e] += 1;
+        }
+        ep_len[e] = fin ? 0 : len;
+#pragma unroll
+        for (int k = 0; k < TRK_MAX_K; ++k) {
+            if (k < K) {
+                float v = return_buf[(size_t)k * n_envs + e] + rewards[(size_t)k * reward_stride + e];
+                if (fin) acc[k] += v;
+                return_buf[(size_t)k * n_envs + e] = fin ? 0.f : v;
+            }
+        }
+    }
+    const int wv = tid >> 6, ln = tid & 63;
+#pragma unroll
+    for (int k = 0; k < TRK_MAX_K + 2; ++k) {
+        float v = wave_sum(acc[k]);
+        if (ln == 0) s_part[wv][k] = v;
+    }
+    __syncthreads();
+    if (tid < TRK_MAX_K + 2) {
+        float v = 0.f;
+        for (int w = 0; w < TRK_THREADS / 64; ++w) v += s_part[w][tid];
+        s_tot[tid] = v;
+    }
+    __syncthreads();
+    const float n_new = s_tot[TRK_MAX_K + 1];
+    if (n_new > 0.f) {
+        const double new_count = episodes[0] + (double)n_new;
+        const float w_new = (float)((double)n_new / (new_count < 1.0 ? 1.0 : new_count));
+        if (tid < K) mean_return[tid] = lerp_torch(mean_return[tid], s_tot[tid] / n_new, w_new);
+        if (tid == K) mean_ep_len[0] = lerp_torch(mean_ep_len[0], s_tot[TRK_MAX_K] / n_new, w_new);
+        __syncthreads();
+        if (tid == 0) episodes[0] = new_count;
+    }
+}
+
+extern "C" int parc_return_tracker_update(void *stream, int n_envs, int K, const float *rewards, int64_t reward_stride, const int32_t *done,
+                                          float *return_buf, int64_t *ep_len, int64_t *eps_per_env, float *mean_return, float *mean_ep_len,
+                                          double *episodes) {
+    if (n_envs <= 0 || K <= 0 || K > TRK_MAX_K || reward_stride < n_envs) return PARC_EINVAL;
+    hipLaunchKernelGGL(return_tracker_kernel, dim3(1), dim3(TRK_THREADS), 0, (hipStream_t)stream, n_envs, K, rewards, reward_stride, done, return_buf,
+                       ep_len, eps_per_env, mean_return, mean_ep_len, episodes);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}

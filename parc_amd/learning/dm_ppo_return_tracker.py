@@ -21,6 +21,7 @@ class DMPPOReturnTracker:
         self._eps_per_env_buf = torch.zeros([num_envs], device=device, dtype=torch.long)
         self._return_buf = torch.zeros([K, num_envs], device=device, dtype=torch.float32)
         self._mean_return = torch.zeros([K], device=device, dtype=torch.float32)
+        self._use_kernel = True
 
     def get_mean_return(self):
         return self._mean_return[0:1]
@@ -67,7 +68,17 @@ class DMPPOReturnTracker:
         return torch.stack([rewards[k] for k in self._keys], dim=0)
 
     def update(self, info, done):
-        self._return_buf += self._stack_rewards(info)
+        block = self._stack_rewards(info)
+        if block.is_cuda and block.stride(-1) == 1 and done.dtype == torch.int32 and self._use_kernel:
+            # K21 in one launch (parc_return_tracker_update); the torch expression below is the same rule
+            from .. import _hip
+            p = _hip.ptr
+            _hip.check(_hip.lib().parc_return_tracker_update(_hip.stream(), int(done.shape[0]), len(self._keys), p(block), int(block.stride(0)),
+                                                             p(done), p(self._return_buf), p(self._ep_len_buf), p(self._eps_per_env_buf),
+                                                             p(self._mean_return), p(self._mean_ep_len), p(self._episodes_t)),
+                       "parc_return_tracker_update")
+            return
+        self._return_buf += block
         self._ep_len_buf += 1
         mask = done != base_env.DoneFlags.NULL.value
         maskf = mask.to(torch.float32)

@@ -300,3 +300,25 @@ def test_in_kernel_target_resample_matches_rule(env):
     assert torch.allclose(c.next_target_xy_time[due], (c.time_buf + fut)[due], atol=1e-6)
     assert torch.equal(c.target_xy[~due], old_xy[~due]) and torch.equal(c.next_target_xy_time[~due], old_t[~due])
     assert float(noise.std()) > 0.03 and float(noise.std()) < 0.07
+
+
+def test_return_tracker_kernel_matches_torch_rule():
+    """K21: parc_return_tracker_update against the torch statement of DMPPOReturnTracker.update over a random episode stream."""
+    from parc_amd.learning.dm_ppo_return_tracker import DMPPOReturnTracker
+    g = torch.Generator().manual_seed(5)
+    N = 1000
+    a, b = DMPPOReturnTracker(N, DEV, target_task=True), DMPPOReturnTracker(N, DEV, target_task=True)
+    b._use_kernel = False
+    names = ["total_r", "pose_r", "vel_r", "root_pos_r", "root_vel_r", "key_pos_r", "contact_penalty", "task_r1", "task_r2", "total_task_r"]
+    for step in range(40):
+        blk = torch.rand((10, N), generator=g).to(DEV)
+        done = (torch.rand(N, generator=g) < (0.0 if step in (0, 7) else 0.06)).to(torch.int32).to(DEV) * (1 + step % 3)
+        info = {"rewards_all": (names, blk)}
+        a.update(info, done)
+        b.update(info, done)
+    torch.cuda.synchronize()
+    assert a.get_episodes() == b.get_episodes() and a.get_episodes() > 1000
+    assert torch.equal(a._ep_len_buf, b._ep_len_buf) and torch.equal(a.get_eps_per_env(), b.get_eps_per_env())
+    assert torch.allclose(a._return_buf, b._return_buf, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(a._mean_return, b._mean_return, rtol=2e-5) and torch.allclose(a.get_mean_ep_len(), b.get_mean_ep_len(), rtol=2e-5)
+    assert abs(a.summary()["mean_return"] - b.summary()["mean_return"]) < 1e-4

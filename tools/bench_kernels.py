@@ -122,7 +122,7 @@ def bench_post_step(n, iters):
     core.root_state[:, 3:7] = core.ref_root_rot
     core.dof_state.view(n, 28, 2)[..., 0] = core.ref_dof_pos
     core.rigid_body_state.view(n, 15, 13)[..., 0:3] = core.ref_body_pos
-    full = _hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF
+    full = _hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS      # the product step's flags
     abl = [int(a.split("=")[1], 0) for a in sys.argv if a.startswith("--ablate=")]
     if abl:                      # PMC runs of one role ablation: every launch of the process uses it
         full |= abl[0]
