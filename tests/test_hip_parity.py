@@ -419,3 +419,70 @@ def test_fused_ppo_loss_matches_autograd(case):
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-9, (name, float((a - b).abs().max()), scale)
     if case == "critic_off_gate":
         assert float(g_f[0].abs().max()) == 0.0 and float(g_f[1].abs().max()) == 0.0 and float(g_f[2].abs().max()) > 0.0
+
+
+def test_post_step_and_sim_are_per_env_functions_at_8192_envs(km):
+    """BASELINE configs[4] size (8192 envs/GPU): size-independent property instead of an oracle run - every output row
+    depends on that env's inputs only, so permuting the envs permutes the outputs bit for bit (fused post-step kernel,
+    simulator step), and an env_ids subset launch reproduces the same rows."""
+    from parc_amd import _hip, synthetic
+    from parc_amd.anim.motion_lib import MotionLib
+    from parc_amd.envs.ig_parkour.default_config import default_env_config
+    from parc_amd.sim_model import SimModel
+    from parc_amd.tracker_core import TrackerConfig, TrackerCore
+    from parc_amd.util import geom_util
+    from parc_amd.util.terrain_util import SubTerrain
+    n = 8192
+    clips = synthetic.make_dataset(16, seed=3)
+    ml = MotionLib(clips, km, DEV, init_type="clips", contact_info=True)
+    hf, mn, dxdy, offs = synthetic.tile_square(clips)
+    rays = geom_util.get_xy_points_cone(torch.zeros(2), 0.05, 2, 60, 3, 3, 0.26179938779)
+    cfg = TrackerConfig(default_env_config()["env"], km, rays.shape[0])
+    g = torch.Generator().manual_seed(9)
+    perm = torch.randperm(n, generator=g).to(DEV)
+    mids = torch.randint(0, 16, (n,), generator=g).to(DEV)
+    toff = (torch.rand(n, generator=g) * 3.0).to(DEV)
+    tbuf = (torch.randint(1, 60, (n,), generator=g).float() / 30.0).to(DEV)
+    jitter = (torch.randn((n, 3), generator=g) * 0.05).to(DEV)
+    djit = (torch.randn((n, 28), generator=g) * 0.1).to(DEV)
+    act = (torch.randn((n, 28), generator=g) * 0.3).to(DEV)
+    sm = SimModel(km)
+    lo = torch.full((28,), -3.0, device=DEV)
+    hi = torch.full((28,), 3.0, device=DEV)
+
+    def run(order):
+        core = TrackerCore(n, DEV, km, ml, cfg, rays)
+        core.set_terrain(SubTerrain.from_arrays(hf, mn, dxdy, device=DEV))
+        core.motion_ids[:] = mids[order]
+        core.motion_xy_offset[:] = torch.tensor(offs[:, 0]).to(DEV)[core.motion_ids]
+        core.motion_time_offsets[:] = toff[order]
+        core.time_buf[:] = tbuf[order]
+        core.post_step(_hip.POST_REF)
+        core.root_state[:, 0:3] = core.ref_root_pos + jitter[order]
+        core.root_state[:, 3:7] = core.ref_root_rot
+        core.dof_state.view(n, 28, 2)[..., 0] = core.ref_dof_pos + djit[order]
+        L = _hip.lib()
+        _hip.check(L.parc_sim_step(_hip.stream(), sm.device_ptr(DEV), core._terrain_struct, n, _hip.ptr(core.root_state), _hip.ptr(core.dof_state),
+                                   _hip.ptr(core.rigid_body_state), _hip.ptr(core.contact_forces), _hip.ptr(core.env_offsets),
+                                   _hip.ptr(act[order].contiguous()), _hip.ptr(lo), _hip.ptr(hi), 4, 1.0 / 120.0), "sim")
+        core.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF)
+        torch.cuda.synchronize()
+        return core
+    ident = torch.arange(n, device=DEV)
+    a, b = run(ident), run(perm)
+    for name in ("root_state", "obs", "reward", "done", "ref_body_pos", "ref_dof_pos"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert torch.equal(x.reshape(n, -1)[perm], y.reshape(n, -1)), name
+    assert torch.equal(a.rigid_body_state.reshape(n, -1)[perm], b.rigid_body_state.reshape(n, -1))
+    assert torch.equal(a.reward_terms[:, perm], b.reward_terms)
+    assert torch.isfinite(a.obs).all() and torch.isfinite(a.root_state).all()
+    # subset launch: the listed rows equal the all-env launch, the rest is untouched
+    ids = perm[:777].sort().values
+    snap = a.obs.clone()
+    a.obs[:] = -9.0
+    a.post_step(_hip.POST_OBS | _hip.POST_HF, ids)
+    torch.cuda.synchronize()
+    assert torch.equal(a.obs[ids], snap[ids])
+    rest = torch.ones(n, dtype=torch.bool, device=DEV)
+    rest[ids] = False
+    assert torch.all(a.obs[rest] == -9.0)
