@@ -29,6 +29,7 @@ __global__ __launch_bounds__(64) void sim_step_bpl_kernel(const parc_sim_model_t
                                                           const float *__restrict__ act_hi, int n_sub, float h) {
     using namespace parc_sim_bpl;
     __shared__ float lds[BPL_EPB][BPL_G * BPL_CONTRIB];
+    __shared__ float ccache[64][BPL_CC_SLOTS * BPL_CC_FLOATS + 1];     // +1: odd row stride against bank conflicts
     const int g = threadIdx.x / BPL_G, b = threadIdx.x % BPL_G;
     const int e = min((int)blockIdx.x * BPL_EPB + g, n_envs - 1);      // tail groups recompute the last env (same values)
     const parc_sim_model_t &m = *model;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(64) void sim_step_bpl_kernel(const parc_sim_model_t
     load_lane_state(m, L, b, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e, action + (size_t)D * e, act_lo, act_hi, x);
     const parc_sim::V3 off = parc_sim::ld(env_offsets + 3 * (size_t)e);
     const float w = 1.0f / (float)n_sub;
-    for (int s = 0; s < n_sub; ++s) substep(m, ter, off, L, b, maxd, x, h, w, lds[g]);
+    for (int s = 0; s < n_sub; ++s) substep(m, ter, off, L, b, maxd, x, h, w, lds[g], ccache[threadIdx.x]);
     store_lane_state(L, b, maxd, x, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e, rigid_body_state + 13 * (size_t)B * e,
                      contact_forces + 3 * (size_t)B * e);
 }

@@ -142,8 +142,12 @@ __device__ __forceinline__ ContactEval eval_contact(const parc_sim_model_t &m, c
     return ce;
 }
 
+#define BPL_CC_SLOTS 8      // contacts per body kept in LDS between the impedance pass and the force report
+#define BPL_CC_FLOATS 11    // rc, nb, F0, cn, ct
+
 __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_off, const Lane &L, int b, int maxd,
-                                        LState &x, float h, float cweight, float *lds /* [16][BPL_CONTRIB] of this env */) {
+                                        LState &x, float h, float cweight, float *lds /* [16][BPL_CONTRIB] of this env */,
+                                        float *cc /* [BPL_CC_SLOTS][BPL_CC_FLOATS] of this lane */) {
     Kin k;
     kin_pass(L, b, maxd, x, k);
     const bool valid = L.depth >= 0;
@@ -165,10 +169,20 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
         pA.l = pA.l - fg;
     }
     // ---- contacts of this body's sample spheres: implicit spring-damper + regularised friction
+    int n_hit = 0;                    // active contacts of this body; the first BPL_CC_SLOTS are parked in LDS for the report
+    unsigned long long overflow = 0ull;
     for (unsigned long long mm = valid ? L.sph : 0ull; mm; mm &= mm - 1) {
         const int s = __ffsll((long long)mm) - 1;
         ContactEval ce = eval_contact(m, ter, env_off, k, s);
         if (!ce.hit) continue;
+        if (n_hit < BPL_CC_SLOTS) {
+            float *o = cc + n_hit * BPL_CC_FLOATS;
+            o[0] = ce.rc.x; o[1] = ce.rc.y; o[2] = ce.rc.z; o[3] = ce.nb.x; o[4] = ce.nb.y; o[5] = ce.nb.z;
+            o[6] = ce.F0.x; o[7] = ce.F0.y; o[8] = ce.F0.z; o[9] = ce.cn; o[10] = ce.ct;
+            ++n_hit;
+        } else {
+            overflow |= 1ull << s;
+        }
         M3 Z = add(ident(ce.ct), outer(((ce.cn + h * m.contact_kn) - ce.ct) * ce.nb, ce.nb));
         M3 Sr = skew(ce.rc);
         M3 SZ = mul(Sr, Z);
@@ -187,30 +201,47 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
     V3 u = v3(0, 0, 0);
 #pragma unroll
     for (int q = 0; q < 9; ++q) Ua.m[q] = Ul.m[q] = Dinv.m[q] = 0.f;
+    // drive torque and the diagonal augmentation of D depend on this joint's own state only: once per substep, not per level
+    float tau[3] = {0.f, 0.f, 0.f}, aug[3] = {0.f, 0.f, 0.f};
+    if (L.jt == PARC_JOINT_SPHERICAL) {
+        V3 err = q_to_exp(qmul(qconj(x.jq), x.tq)) - h * x.jw;
+        V3 e = q_to_exp(x.jq);
+        const float ev[3] = {err.x, err.y, err.z}, wv[3] = {x.jw.x, x.jw.y, x.jw.z}, ee[3] = {e.x, e.y, e.z};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float kp = m.kp[L.d0 + q], kd = m.kd[L.d0 + q];
+            float t = kp * ev[q] - kd * wv[q];
+            float lim = m.effort[L.d0 + q];
+            float sc = (lim > 0.f && fabsf(t) > lim) ? lim * p_rcp(fabsf(t)) : 1.0f;
+            tau[q] = sc * t;
+            aug[q] = m.armature[L.d0 + q] + sc * (h * kd + h * h * kp);
+            float hi = m.limit_hi[L.d0 + q], lo = m.limit_lo[L.d0 + q];
+            float over = ee[q] > hi ? ee[q] - hi : (ee[q] < lo ? ee[q] - lo : 0.f);
+            if (over != 0.f) {
+                tau[q] += -m.limit_kp * (over + h * wv[q]) - m.limit_kd * wv[q];
+                aug[q] += h * m.limit_kd + h * h * m.limit_kp;
+            }
+        }
+    } else if (L.jt == PARC_JOINT_HINGE) {
+        float w = x.jw.x;
+        float kp = m.kp[L.d0], kd = m.kd[L.d0];
+        float t = kp * (x.tang - x.jang - h * w) - kd * w;
+        float lim = m.effort[L.d0];
+        float sc = (lim > 0.f && fabsf(t) > lim) ? lim * p_rcp(fabsf(t)) : 1.0f;
+        tau[0] = sc * t;
+        aug[0] = m.armature[L.d0] + sc * (h * kd + h * h * kp);
+        float hi = m.limit_hi[L.d0], lo = m.limit_lo[L.d0];
+        float over = x.jang > hi ? x.jang - hi : (x.jang < lo ? x.jang - lo : 0.f);
+        if (over != 0.f) {
+            tau[0] += -m.limit_kp * (over + h * w) - m.limit_kd * w;
+            aug[0] += h * m.limit_kd + h * h * m.limit_kp;
+        }
+    }
     for (int l = maxd; l >= 1; --l) {
         if (L.depth == l) {
             SI Ia = IA;
             SV pa = pA;
             if (L.jt == PARC_JOINT_SPHERICAL) {
-                V3 err = q_to_exp(qmul(qconj(x.jq), x.tq)) - h * x.jw;
-                V3 e = q_to_exp(x.jq);
-                float tau[3], aug[3];
-                const float ev[3] = {err.x, err.y, err.z}, wv[3] = {x.jw.x, x.jw.y, x.jw.z}, ee[3] = {e.x, e.y, e.z};
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    float kp = m.kp[L.d0 + q], kd = m.kd[L.d0 + q];
-                    float t = kp * ev[q] - kd * wv[q];
-                    float lim = m.effort[L.d0 + q];
-                    float sc = (lim > 0.f && fabsf(t) > lim) ? lim * p_rcp(fabsf(t)) : 1.0f;
-                    tau[q] = sc * t;
-                    aug[q] = m.armature[L.d0 + q] + sc * (h * kd + h * h * kp);
-                    float hi = m.limit_hi[L.d0 + q], lo = m.limit_lo[L.d0 + q];
-                    float over = ee[q] > hi ? ee[q] - hi : (ee[q] < lo ? ee[q] - lo : 0.f);
-                    if (over != 0.f) {
-                        tau[q] += -m.limit_kp * (over + h * wv[q]) - m.limit_kd * wv[q];
-                        aug[q] += h * m.limit_kd + h * h * m.limit_kp;
-                    }
-                }
                 M3 D = Ia.A;
                 D.m[0] += aug[0]; D.m[4] += aug[1]; D.m[8] += aug[2];
                 Dinv = inv_sym(D);
@@ -226,23 +257,10 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
                 pa.a = pa.a + Iac.a + mul(Ua, Diu);
                 pa.l = pa.l + Iac.l + mul(Ul, Diu);
             } else if (L.jt == PARC_JOINT_HINGE) {
-                float w = x.jw.x;
-                float kp = m.kp[L.d0], kd = m.kd[L.d0];
-                float t = kp * (x.tang - x.jang - h * w) - kd * w;
-                float lim = m.effort[L.d0];
-                float sc = (lim > 0.f && fabsf(t) > lim) ? lim * p_rcp(fabsf(t)) : 1.0f;
-                float tau = sc * t;
-                float aug = m.armature[L.d0] + sc * (h * kd + h * h * kp);
-                float hi = m.limit_hi[L.d0], lo = m.limit_lo[L.d0];
-                float over = x.jang > hi ? x.jang - hi : (x.jang < lo ? x.jang - lo : 0.f);
-                if (over != 0.f) {
-                    tau += -m.limit_kp * (over + h * w) - m.limit_kd * w;
-                    aug += h * m.limit_kd + h * h * m.limit_kp;
-                }
                 V3 ua = mul(Ia.A, L.ax), ul = mulT(Ia.B, L.ax);
-                float D = dot(L.ax, ua) + aug;
+                float D = dot(L.ax, ua) + aug[0];
                 float Di = p_rcp(D);
-                float uu = tau - dot(L.ax, pa.a);
+                float uu = tau[0] - dot(L.ax, pa.a);
                 Ua.m[0] = ua.x; Ua.m[1] = ua.y; Ua.m[2] = ua.z;
                 Ul.m[0] = ul.x; Ul.m[1] = ul.y; Ul.m[2] = ul.z;
                 Dinv.m[0] = Di;
@@ -323,17 +341,27 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
     }
     // ---- realised contact force of this body, world frame (F+ = F0 - Z h J a), averaged over the substeps
     if (cweight > 0.f) {
-        for (unsigned long long mm = valid ? L.sph : 0ull; mm; mm &= mm - 1) {
-            const int s = __ffsll((long long)mm) - 1;
-            ContactEval ce = eval_contact(m, ter, env_off, k, s);
-            if (!ce.hit) continue;
+        V3 Fb = v3(0, 0, 0);
+        for (int c = 0; c < n_hit; ++c) {
+            const float *o = cc + c * BPL_CC_FLOATS;
+            const V3 rc = v3(o[0], o[1], o[2]), nb = v3(o[3], o[4], o[5]), F0 = v3(o[6], o[7], o[8]);
+            V3 dv = h * (a.l + cross(a.a, rc));
+            float dvn = dot(dv, nb);
+            V3 F = F0 - (o[9] + h * m.contact_kn) * dvn * nb - o[10] * (dv - dvn * nb);
+            float fnn = dot(F, nb);
+            if (fnn < 0.f) F = F - fnn * nb;
+            Fb = Fb + F;
+        }
+        for (unsigned long long mm = overflow; mm; mm &= mm - 1) {      // more simultaneous contacts than slots: re-evaluate
+            ContactEval ce = eval_contact(m, ter, env_off, k, __ffsll((long long)mm) - 1);
             V3 dv = h * (a.l + cross(a.a, ce.rc));
             float dvn = dot(dv, ce.nb);
             V3 F = ce.F0 - (ce.cn + h * m.contact_kn) * dvn * ce.nb - ce.ct * (dv - dvn * ce.nb);
             float fnn = dot(F, ce.nb);
             if (fnn < 0.f) F = F - fnn * ce.nb;
-            x.cforce = x.cforce + cweight * mul(k.R, F);
+            Fb = Fb + F;
         }
+        x.cforce = x.cforce + cweight * mul(k.R, Fb);
     }
     // ---- semi-implicit Euler
     const float wmax = m.max_angular_velocity;
