@@ -35,13 +35,73 @@ class MPOptimizer:
             p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
         self.sync()
+        # Overlap of the per-minibatch exchange with backward: the flat gradient is cut into a few contiguous buckets at
+        # parameter boundaries; a bucket's all-reduce starts (asynchronously, on RCCL's stream) as soon as the last of its
+        # gradients has been accumulated, while autograd is still producing the others.  Parameters are registered actor
+        # first, critic second and backward visits each network last-layer-first, so with 4 buckets only the first critic
+        # layer's 10.7 MB are exchanged after backward ends instead of all 42.6 MB.
+        self._overlap = bool(config.get("overlap_allreduce", True)) and self._cadence == "minibatch" and \
+            hasattr(param_list[0], "register_post_accumulate_grad_hook")
+        self._buckets = []
+        self._in_backward = False
+        if self._overlap:
+            self._build_buckets(int(config.get("allreduce_buckets", 4)))
+
+    def _build_buckets(self, n_buckets):
+        total = self._flat_grad.numel()
+        cap = total / float(max(n_buckets, 1))
+        off, start, count = 0, 0, 0
+        for i, p in enumerate(self._param_list):
+            off += p.numel()
+            count += 1
+            last = i == len(self._param_list) - 1
+            # close after a bias (1-D parameter) so a layer's weight and bias, whose gradients arrive together, share a bucket
+            if last or (off - start >= cap * 0.95 and p.dim() == 1):
+                self._buckets.append({"lo": start, "hi": off, "n": count, "pending": 0, "work": None})
+                start, count = off, 0
+        b = 0
+        seen = 0
+        for p in self._param_list:
+            bucket = self._buckets[b]
+            p.register_post_accumulate_grad_hook(lambda _p, bucket=bucket: self._grad_ready(bucket))
+            seen += 1
+            if seen == bucket["n"]:
+                b, seen = b + 1, 0
+
+    def _grad_ready(self, bucket):
+        if not self._in_backward:
+            return
+        bucket["pending"] -= 1
+        if bucket["pending"] == 0:
+            bucket["work"] = torch.distributed.all_reduce(self._flat_grad[bucket["lo"]:bucket["hi"]], op=torch.distributed.ReduceOp.SUM,
+                                                          async_op=True)
+
+    def _backward_and_exchange(self, loss):
+        """loss.backward() followed by (or, with buckets, overlapped with) the all-reduce(mean) of the flat gradient."""
+        mp = mp_util.enable_mp() and self._cadence == "minibatch"
+        if mp and self._overlap:
+            for bk in self._buckets:
+                bk["pending"], bk["work"] = bk["n"], None
+            self._in_backward = True
+            try:
+                loss.backward()
+            finally:
+                self._in_backward = False
+            for bk in self._buckets:
+                if bk["work"] is None:       # a parameter of this bucket received no gradient in this graph: exchange it now
+                    torch.distributed.all_reduce(self._flat_grad[bk["lo"]:bk["hi"]], op=torch.distributed.ReduceOp.SUM)
+                else:
+                    bk["work"].wait()
+            self._flat_grad /= mp_util.get_num_procs()
+            return
+        loss.backward()
+        if mp:
+            torch.distributed.all_reduce(self._flat_grad, op=torch.distributed.ReduceOp.SUM)
+            self._flat_grad /= mp_util.get_num_procs()
 
     def step(self, loss, **kwargs):
         self._flat_grad.zero_()
-        loss.backward()
-        if mp_util.enable_mp() and self._cadence == "minibatch":
-            torch.distributed.all_reduce(self._flat_grad, op=torch.distributed.ReduceOp.SUM)
-            self._flat_grad /= mp_util.get_num_procs()
+        self._backward_and_exchange(loss)
         if "model" in kwargs:
             # the gradient norm of the flat buffer == norm over model parameters (all trainable params are in it)
             max_norm = kwargs["max_norm"]

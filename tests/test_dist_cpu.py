@@ -38,6 +38,22 @@ def _worker(rank, world, port, out):
     nrm.record(torch.full((5, 3), float(rank + 1)))
     nrm.update()
     # plain numpy in the queue: torch tensors would be handed over through shared-memory handles that die with the child
+    # bucketed exchange overlapped with backward == one all-reduce after backward (same data, same mean)
+    res_ov = []
+    for overlap in (True, False):
+        torch.manual_seed(300)
+        m3 = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2))
+        o3 = mp_optimizer.MPOptimizer({"type": "SGD", "learning_rate": 0.1, "overlap_allreduce": overlap, "allreduce_buckets": 3},
+                                      list(m3.parameters()))
+        assert (len(o3._buckets) >= 2) == overlap
+        for k in range(3):
+            torch.manual_seed(400 + 10 * k + rank)
+            xx = torch.randn(7, 6)
+            o3.step(torch.mean(torch.square(m3(xx) - 1.0)))
+        assert o3._check_synced()
+        res_ov.append([p.detach().numpy().copy() for p in m3.parameters()])
+    for a_, b_ in zip(*res_ov):
+        assert (a_ == b_).all() or abs(a_ - b_).max() < 1e-7
     # per-epoch cadence: local steps diverge, end_epoch() averages parameters and momentum buffers
     torch.manual_seed(200 + rank)
     m2 = torch.nn.Linear(4, 2)
