@@ -221,6 +221,10 @@ def test_device_reset_equals_indexed_reset(env):
         if n in ("target_xy", "next_target_xy_time"):       # drawn from the RNG in a different order
             continue
         assert torch.equal(a[n], b[n]), n
+    # both paths re-arm the xy target of the reset envs (drawn from different random streams, hence not compared above)
+    for snap_ in (a, b):
+        assert torch.all(snap_["next_target_xy_time"][ids] > 0.0) and torch.isfinite(snap_["target_xy"][ids]).all()
+        assert torch.equal(snap_["next_target_xy_time"][done == 0], snap["next_target_xy_time"][done == 0])
     keep = done == 0
     for n in ("root_state", "dof_state", "obs", "motion_ids", "time_buf", "ref_root_pos"):
         assert torch.equal(b[n].reshape(96, -1)[keep], snap[n].reshape(96, -1)[keep]), n
