@@ -263,6 +263,16 @@ int parc_return_tracker_update(void *stream, int n_envs, int K, const float *rew
                                float *return_buf, int64_t *ep_len, int64_t *eps_per_env, float *mean_return, float *mean_ep_len,
                                double *episodes);
 
+/* ---- K12: Normalizer.normalize  learning/normalizer.py:60-63 in one pass: out = clamp((x - mean) / std, -clip, clip).
+ * x, out [rows, dim] row-major, mean / std [dim]; dim a multiple of 4, 16-byte aligned pointers; out may alias x. */
+int parc_normalize_clamp(void *stream, int64_t rows, int dim, const float *x, const float *mean, const float *stdv, float clip, float *out);
+
+/* ---- K14: the part of PPOAgent._decide_action (learning/ppo_agent.py:87-119) after the actor MLP: sample / mode by the
+ * exploration mask, log-probability, un-normalised action.  mean, noise, action [n, A]; logstd, a_mean, a_std [A]; explore,
+ * logp [n]. */
+int parc_action_head(void *stream, int n, int A, const float *mean, const float *logstd, const float *noise, const float *explore,
+                     const float *a_mean, const float *a_std, float *action, float *logp);
+
 /* ---- measurement knobs (exported for tools/bench_kernels.py; not part of the stable ABI, defaults are the product path) ----
  * parc_tune_hf_envs_per_block(1|2|4|8): envs per workgroup of the standalone heightmap kernel;
  * parc_tune_hf_ablation(0..5): timing-only variants of it (outputs wrong for != 0);

@@ -278,3 +278,68 @@ extern "C" int parc_return_tracker_update(void *stream, int n_envs, int K, const
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }
+
+// =============================================================================================
+// K12 observation normalisation: Normalizer.normalize (learning/normalizer.py:60-63)  out = clamp((x - mean) / std, -clip, clip)
+// in one pass (torch: subtract, divide, clamp = three passes).  Same fp32 operations, so the result is bit-identical.
+// =============================================================================================
+__global__ __launch_bounds__(256) void normalize_clamp_kernel(size_t n4, int dim4, const float4 *__restrict__ x, const float4 *__restrict__ mean,
+                                                              const float4 *__restrict__ stdv, float clip, float4 *__restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (size_t)dim4);
+        const float4 v = x[i], m = mean[c], s = stdv[c];
+        float4 o;
+        o.x = fminf(fmaxf((v.x - m.x) / s.x, -clip), clip);
+        o.y = fminf(fmaxf((v.y - m.y) / s.y, -clip), clip);
+        o.z = fminf(fmaxf((v.z - m.z) / s.z, -clip), clip);
+        o.w = fminf(fmaxf((v.w - m.w) / s.w, -clip), clip);
+        out[i] = o;
+    }
+}
+
+extern "C" int parc_normalize_clamp(void *stream, int64_t rows, int dim, const float *x, const float *mean, const float *stdv, float clip,
+                                    float *out) {
+    if (rows < 0 || dim <= 0 || (dim & 3) || (((uintptr_t)x | (uintptr_t)mean | (uintptr_t)stdv | (uintptr_t)out) & 15)) return PARC_EINVAL;
+    if (rows == 0) return PARC_OK;
+    const size_t n4 = (size_t)rows * (size_t)(dim / 4);
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(normalize_clamp_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n4, dim / 4, (const float4 *)x,
+                       (const float4 *)mean, (const float4 *)stdv, clip, (float4 *)out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}
+
+// =============================================================================================
+// K14 action head of the rollout: PPOAgent._decide_action (learning/ppo_agent.py:87-119) after the actor MLP.
+// norm_a = mean + std * noise where the env explores (mask 1), the mode otherwise; a_logp = log N(norm_a; mean, std);
+// action = a_mean + a_std * norm_a (Normalizer.unnormalize).  One thread per env.
+// =============================================================================================
+__global__ __launch_bounds__(256) void action_head_kernel(int n, int A, const float *__restrict__ mean, const float *__restrict__ logstd,
+                                                          const float *__restrict__ noise, const float *__restrict__ explore,
+                                                          const float *__restrict__ a_mean, const float *__restrict__ a_std, float *action,
+                                                          float *logp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool ex = explore[i] == 1.0f;
+    float acc = 0.f, sum_ls = 0.f;
+    for (int j = 0; j < A; ++j) {
+        const float ls = logstd[j], sd = __expf(ls);
+        const float mu = mean[(size_t)i * A + j];
+        const float na = ex ? mu + sd * noise[(size_t)i * A + j] : mu;
+        const float z = (na - mu) / sd;
+        acc = fmaf(z, z, acc);
+        sum_ls += ls;
+        action[(size_t)i * A + j] = na * a_std[j] + a_mean[j];
+    }
+    logp[i] = -0.5f * acc + (-0.5f * (float)A * 1.8378770664093453f - sum_ls);
+}
+
+extern "C" int parc_action_head(void *stream, int n, int A, const float *mean, const float *logstd, const float *noise, const float *explore,
+                                const float *a_mean, const float *a_std, float *action, float *logp) {
+    if (n <= 0 || A <= 0) return PARC_EINVAL;
+    hipLaunchKernelGGL(action_head_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, A, mean, logstd, noise, explore, a_mean,
+                       a_std, action, logp);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}

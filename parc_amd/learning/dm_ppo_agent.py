@@ -202,6 +202,8 @@ class DMPPOAgent(torch.nn.Module):
     def _decide_action(self, obs, info):
         norm_obs = self._obs_norm.normalize(obs)
         dist = self._model.eval_actor(norm_obs)
+        if obs.is_cuda and dist.logstd.dim() == 2 and dist.logstd.stride(0) == 0 and self._config.get("fused_action_head", True):
+            return self._decide_action_fused(dist, obs.shape[0])
         if self._mode == AgentMode.TRAIN:
             exp_prob = self._get_exp_prob()
             if exp_prob >= 1.0:
@@ -217,6 +219,30 @@ class DMPPOAgent(torch.nn.Module):
             mask = torch.zeros_like(norm_a[..., 0])
         logp = dist.log_prob(norm_a)
         a = self._a_norm.unnormalize(norm_a)
+        return a, {"a_logp": logp, "rand_action_mask": mask}
+
+    def _decide_action_fused(self, dist, n):
+        """Same rule as the branches of _decide_action, with sampling, log-probability and un-normalisation in one launch
+        (parc_action_head) after the random draws."""
+        from .. import _hip
+        mean = dist.mean.contiguous()
+        A = mean.shape[1]
+        if self._mode == AgentMode.TRAIN:
+            exp_prob = self._get_exp_prob()
+            if exp_prob >= 1.0:
+                mask = torch.ones(n, dtype=torch.float32, device=mean.device)
+            else:
+                self._exp_prob_t.fill_(exp_prob)
+                mask = torch.bernoulli(self._exp_prob_t.expand(n, 1)).squeeze(-1).contiguous()
+            noise = torch.randn_like(mean)
+        else:
+            mask = torch.zeros(n, dtype=torch.float32, device=mean.device)
+            noise = mean                   # unused where the mask is 0
+        a = torch.empty_like(mean)
+        logp = torch.empty(n, dtype=torch.float32, device=mean.device)
+        p = _hip.ptr
+        _hip.check(_hip.lib().parc_action_head(_hip.stream(), n, A, p(mean), p(dist.logstd[0].contiguous()), p(noise), p(mask),
+                                               p(self._a_norm.get_mean()), p(self._a_norm.get_std()), p(a), p(logp)), "parc_action_head")
         return a, {"a_logp": logp, "rand_action_mask": mask}
 
     def step(self):
@@ -402,9 +428,7 @@ class DMPPOAgent(torch.nn.Module):
         """(V(obs), V(next_obs)) over the whole rollout buffer, [T, N] each; also fills the "norm_obs" cache."""
         eb = self._exp_buffer
         obs, next_obs, done = eb.get_data("obs"), eb.get_data("next_obs"), eb.get_data("done")
-        norm_obs = eb.get_data("norm_obs")
-        torch.sub(obs, self._obs_norm.get_mean(), out=norm_obs)
-        norm_obs.div_(self._obs_norm.get_std()).clamp_(-self._obs_norm._clip, self._obs_norm._clip)    # == Normalizer.normalize
+        norm_obs = self._obs_norm.normalize(obs, out=eb.get_data("norm_obs"))
         vals = self._model.eval_critic(norm_obs).squeeze(-1)
         # V(next_obs[t]) == V(obs[t+1]) wherever env did not finish at t (the two rows hold the same observation), so the
         # second critic pass of the reference (ppo_agent.py:146-150) only has to run on the last step and on finished envs

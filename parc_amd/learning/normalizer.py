@@ -69,8 +69,21 @@ class Normalizer(torch.nn.Module):
     def get_std(self):
         return self._std
 
-    def normalize(self, x):
-        return torch.clamp((x - self._mean) / self._std, -self._clip, self._clip).type(self.dtype)
+    def normalize(self, x, out=None):
+        if (x.is_cuda and x.dtype == torch.float32 and self.dtype == torch.float32 and x.is_contiguous() and self._mean.dim() == 1
+                and self._mean.shape[0] % 4 == 0 and x.shape[-1] == self._mean.shape[0] and x.data_ptr() % 16 == 0 and np.isfinite(self._clip)):
+            # one pass (parc_normalize_clamp), same fp32 operations as the expression below
+            from .. import _hip
+            if out is None:
+                out = torch.empty_like(x)
+            _hip.check(_hip.lib().parc_normalize_clamp(_hip.stream(), x.numel() // x.shape[-1], int(x.shape[-1]), _hip.ptr(x), _hip.ptr(self._mean),
+                                                       _hip.ptr(self._std), float(self._clip), _hip.ptr(out)), "parc_normalize_clamp")
+            return out
+        res = torch.clamp((x - self._mean) / self._std, -self._clip, self._clip).type(self.dtype)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
     def unnormalize(self, norm_x):
         return (norm_x * self._std + self._mean).type(self.dtype)

@@ -486,3 +486,37 @@ def test_post_step_and_sim_are_per_env_functions_at_8192_envs(km):
     rest = torch.ones(n, dtype=torch.bool, device=DEV)
     rest[ids] = False
     assert torch.all(a.obs[rest] == -9.0)
+
+
+def test_normalize_and_action_head_match_torch_expressions():
+    """K12 (parc_normalize_clamp) bit-identical to clamp((x - mean) / std); K14 (parc_action_head) equal to the reference's
+    sample / log_prob / unnormalize chain on the same noise."""
+    from parc_amd import _hip
+    from parc_amd.learning.normalizer import Normalizer
+    g = torch.Generator().manual_seed(21)
+    nrm = Normalizer((1312,), device=DEV, clip=10.0)
+    nrm._mean[:] = torch.randn(1312, generator=g).to(DEV)
+    nrm._std[:] = (torch.rand(1312, generator=g) * 2 + 0.01).to(DEV)
+    x = (torch.randn((3, 37, 1312), generator=g) * 8).to(DEV)
+    want = torch.clamp((x - nrm._mean) / nrm._std, -10.0, 10.0)
+    got = nrm.normalize(x)
+    assert torch.equal(got, want) and float(want.abs().max()) == 10.0
+    buf = torch.empty_like(x)
+    assert nrm.normalize(x, out=buf) is buf and torch.equal(buf, want)
+    # action head
+    n, A = 1000, 28
+    mean = torch.randn((n, A), generator=g).to(DEV)
+    logstd = (torch.randn(A, generator=g) * 0.3 - 2.0).to(DEV)
+    noise = torch.randn((n, A), generator=g).to(DEV)
+    mask = (torch.rand(n, generator=g) < 0.7).float().to(DEV)
+    a_mean, a_std = torch.randn(A, generator=g).to(DEV), (torch.rand(A, generator=g) + 0.5).to(DEV)
+    a, logp = torch.empty_like(mean), torch.empty(n, device=DEV)
+    p = _hip.ptr
+    _hip.check(_hip.lib().parc_action_head(_hip.stream(), n, A, p(mean), p(logstd), p(noise), p(mask), p(a_mean), p(a_std), p(a), p(logp)), "head")
+    std = torch.exp(logstd)
+    na = torch.where(mask.unsqueeze(-1) == 1.0, mean + std * noise, mean)
+    lp = -0.5 * torch.sum(torch.square((na - mean) / std), dim=-1) + (-0.5 * A * np.log(2.0 * np.pi) - torch.sum(logstd))
+    torch.cuda.synchronize()
+    assert torch.allclose(a, na * a_std + a_mean, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(logp, lp, rtol=1e-5, atol=1e-4)
+    assert torch.all(logp[mask == 0] == logp[mask == 0][0])            # mode actions: z = 0, log-prob is the normalising constant
