@@ -98,7 +98,7 @@ _lib = None
 # per-source optimisation level.  parc_sim.hip is built at -O2: at -O3 hipcc (ROCm 7.2, gfx950) miscompiles the
 # one-env-per-lane simulator core (results diverge from the -O0/-O1/-O2 builds and from the g++ host build of the
 # same source; -O3 -fno-unroll-loops or -O3 -fno-slp-vectorize are correct again) -- see DESIGN.md.
-OPT_LEVEL = {"parc_kin.hip": "-O3", "parc_sim.hip": "-O2"}
+OPT_LEVEL = {"parc_kin.hip": "-O3 -fno-slp-vectorize", "parc_sim.hip": "-O2"}
 
 
 def build(force=False, verbose=False):
@@ -115,7 +115,7 @@ def build(force=False, verbose=False):
     objs = []
     for s in srcs:
         o = os.path.join(obj_dir, s.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", OPT_LEVEL.get(s, "-O3"), "-std=c++17", "-fPIC", "-c", "-o", o, os.path.join(CSRC, s)]
+        cmd = [hipcc, "--offload-arch=gfx950"] + OPT_LEVEL.get(s, "-O3").split() + ["-std=c++17", "-fPIC", "-c", "-o", o, os.path.join(CSRC, s)]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -575,7 +575,7 @@ extern "C" int parc_forward_kinematics(void *stream, parc_char_model_t model, in
 #define POST_MAX_THREADS 512  // 64 * (2 + PARC_MAX_TAR_STEPS)
 #define POST_MAX_ROW 1408
 #ifndef POST_MIN_WAVES
-#define POST_MIN_WAVES 5   // register budget 102/lane; forcing 8 (64 VGPRs, one resident round for 4096 envs) spills 22 registers and measured 33 us vs 27 us
+#define POST_MIN_WAVES 8   // 64 VGPRs: all 1024 workgroups of a 4096-env launch resident in one round (needs -fno-slp-vectorize: 5 spills; with SLP packing 22 spills and slower)
 #endif
 
 // Workgroup = POST_EPB envs, one ROLE per wave so no wave diverges:

@@ -151,17 +151,20 @@ PARC_DEV q4 exp_map_to_quat(v3 em) {
 // Library-precision variants for the one-time clip database build: the stored frame quaternions then equal the
 // reference's to the last bit, which matters because slerp between nearly identical frames amplifies input ulps.
 PARC_DEV q4 quat_unit_lib(q4 q) {
+#pragma clang fp contract(off)      // op by op like torch: no fused multiply-adds in the *_lib functions
     float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-9f);
     return q4{q.x / n, q.y / n, q.z / n, q.w / n};
 }
 PARC_DEV q4 axis_angle_to_quat_lib(v3 axis, float angle) {
+#pragma clang fp contract(off)
     float theta = angle / 2.f;
-    float n = fmaxf(sqrtf(dot3(axis, axis)), 1e-9f);
+    float n = fmaxf(sqrtf((axis.x * axis.x + axis.y * axis.y) + axis.z * axis.z), 1e-9f);
     float s = sinf(theta);
     return quat_unit_lib(q4{axis.x / n * s, axis.y / n * s, axis.z / n * s, cosf(theta)});
 }
 PARC_DEV q4 exp_map_to_quat_lib(v3 em) {
-    float a = sqrtf(dot3(em, em));
+#pragma clang fp contract(off)
+    float a = sqrtf((em.x * em.x + em.y * em.y) + em.z * em.z);
     v3 ax = v3{em.x / a, em.y / a, em.z / a};
     a = atan2f(sinf(a), cosf(a));
     if (!(fabsf(a) > 1e-5f)) {
@@ -202,6 +205,14 @@ PARC_DEV float quat_diff_angle(q4 q0, q4 q1) {
     return an;
 }
 
+// sum of the four rounded products, left to right (no fma contraction): slerp between nearly identical frames amplifies one
+// ulp of this cosine by 1/sin^2, so it has to be evaluated the way the reference (and the oracle) evaluates it
+PARC_DEV float dot4_unfused(q4 a, q4 b) {
+#pragma clang fp contract(off)
+    float p0 = a.x * b.x, p1 = a.y * b.y, p2 = a.z * b.z, p3 = a.w * b.w;
+    return ((p0 + p1) + p2) + p3;
+}
+
 // 1 - c*c with the product rounded first (no fma contraction), as torch evaluates it
 PARC_DEV float one_minus_sq_unfused(float c) {
 #pragma clang fp contract(off)
@@ -211,7 +222,7 @@ PARC_DEV float one_minus_sq_unfused(float c) {
 
 // util/torch_util.py:443-468
 PARC_DEV q4 slerp(q4 q0, q4 q1, float t) {
-    float c = q0.x * q1.x + q0.y * q1.y + q0.z * q1.z + q0.w * q1.w;
+    float c = dot4_unfused(q0, q1);
     float sg = c < 0.f ? -1.f : 1.f;
     q1 = q4{sg * q1.x, sg * q1.y, sg * q1.z, sg * q1.w};
     c = fabsf(c);
