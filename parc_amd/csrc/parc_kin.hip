@@ -685,21 +685,18 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     // diagnostic role ablations (timing only): bits 16/17/18 drop the target / reference / character waves
     if (((what & 0x10000) && is_tar) || ((what & 0x20000) && is_ref) || ((what & 0x40000) && is_char)) return;
 
-    const float4 e0 = reinterpret_cast<const float4 *>(envd[le])[0], e1 = reinterpret_cast<const float4 *>(envd[le])[1],
-                 e2 = reinterpret_cast<const float4 *>(envd[le])[2];
-    const v3 c_pos = mk3(e0.x, e0.y, e0.z);
-    const q4 c_rot = mk4(e0.w, e1.x, e1.y, e1.z);
-    const q4 hinv = mk4(e1.w, e2.x, e2.y, e2.z);
-    const int e = __float_as_int(e2.w);
+    const int e = __float_as_int(envd[le][11]);
     const float *rs = buf.root_state + (size_t)e * 13;
     const float *dofs = buf.dof_state + (size_t)e * D * 2;  // interleaved pos,vel
 
     // ---- phase A: every group gets its pose (root transform + one joint rotation per lane)
     frame_query fq;
     q4 jq = mk4(0.f, 0.f, 0.f, 1.f);
-    v3 p_root = c_pos;
-    q4 r_root = c_rot;
+    v3 p_root = mk3(0.f, 0.f, 0.f);
+    q4 r_root = mk4(0.f, 0.f, 0.f, 1.f);
     if (is_char) {
+        p_root = mk3(envd[le][0], envd[le][1], envd[le][2]);
+        r_root = mk4(envd[le][3], envd[le][4], envd[le][5], envd[le][6]);
         if (valid && b > 0) jq = joint_dof_to_rot(m, b, dofs, 2);      // K1 (kin_char_model.py:478-491)
     } else {
         const float4 q0 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[0];
@@ -720,6 +717,15 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     v3 pos;
     q4 rot;
     group_fk(m, b, p_root, r_root, jq, pos, rot);
+
+    // the simulated root pose and heading are only needed from here on: read them after the tree walk (11 fewer live
+    // registers through it; the compiler barrier keeps the LDS reads from being hoisted back up)
+    asm volatile("" ::: "memory");
+    const float4 e0 = reinterpret_cast<const float4 *>(envd[le])[0], e1 = reinterpret_cast<const float4 *>(envd[le])[1],
+                 e2 = reinterpret_cast<const float4 *>(envd[le])[2];
+    const v3 c_pos = mk3(e0.x, e0.y, e0.z);
+    const q4 c_rot = mk4(e0.w, e1.x, e1.y, e1.z);
+    const q4 hinv = mk4(e1.w, e2.x, e2.y, e2.z);
 
     // ---- phase C: per-group epilogues
     if (is_char) {
