@@ -766,55 +766,61 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 row[Wc + S * Wt + s * B + b] = lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend);
         }
     }
-    // The reference wave writes no observation columns: it passes both barriers right away and does its epilogue
-    // (reference state, reward, termination) while the other waves gather the heightmap and stream the rows out.
+    // ---- reference wave, part 1 (before the barrier, while the target waves are still busy): reference state out
+    const v3 r_pos = p_root;
+    const q4 r_rot = r_root;
+    const q4 rq = jq;
+    float r_contact = 0.f;
+    v3 r_vel = mk3(0.f, 0.f, 0.f), r_avel = mk3(0.f, 0.f, 0.f);
+    if (is_ref && (what & (PARC_POST_REF | PARC_POST_REWARD_DONE))) {
+        // DeepMimicEnv._update_ref_motion  dm_env.py:570-595
+        r_contact = valid ? lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend) : 0.f;
+        r_vel = ld3(fq.row0 + ml.off_root_vel);
+        r_avel = ld3(fq.row0 + ml.off_root_ang_vel);
+        if ((what & PARC_POST_REF) && live) {
+            if (b == 0) {
+                st3(buf.ref_root_pos + 3 * (size_t)e, r_pos);
+                st4(buf.ref_root_rot + 4 * (size_t)e, r_rot);
+                st3(buf.ref_root_vel + 3 * (size_t)e, r_vel);
+                st3(buf.ref_root_ang_vel + 3 * (size_t)e, r_avel);
+            } else if (valid) {
+                st4(buf.ref_joint_rot + ((size_t)e * J + (b - 1)) * 4, rq);
+                joint_rot_to_dof(m, b, rq, buf.ref_dof_pos + (size_t)e * D);      // K4
+            }
+            if (valid) {
+                buf.ref_contacts[(size_t)e * B + b] = r_contact;
+                st3(buf.ref_body_pos + ((size_t)e * B + b) * 3, pos);
+            }
+#pragma unroll 1
+            for (int d = b; d < D; d += GRP) buf.ref_dof_vel[(size_t)e * D + d] = fq.row0[ml.off_dof_vel + d];
+            if (what & PARC_POST_INIT_CHAR) {
+                // RefCharEnv._char_state_init_from_ref + add_noise_to_char_state  mgdm_dm_util.py:119-136
+                float *wrs = const_cast<float *>(buf.root_state) + (size_t)e * 13;
+                float *wds = const_cast<float *>(buf.dof_state) + (size_t)e * D * 2;
+                if (b == 0) {
+                    v3 ip = r_pos;
+                    if (buf.init_noise_xy) {
+                        ip.x += buf.init_noise_xy[2 * e];
+                        ip.y += buf.init_noise_xy[2 * e + 1];
+                    }
+                    st3(wrs, ip);
+                    st4(wrs + 3, r_rot);
+                    st3(wrs + 7, r_vel);
+                    st3(wrs + 10, r_avel);
+                } else if (valid) {
+                    joint_rot_to_dof(m, b, rq, buf.ref_dof_pos + (size_t)e * D, wds);
+                }
+#pragma unroll 1
+                for (int d = b; d < D; d += GRP) wds[2 * d + 1] = fq.row0[ml.off_dof_vel + d];
+            }
+        }
+    }
+    // The reference wave writes no observation columns: it passes both barriers right away and does the rest of its epilogue
+    // (reward, termination) while the other waves gather the heightmap and stream the rows out.
     if (what & PARC_POST_OBS) __syncthreads();          // B1: pose-derived columns are in LDS
     if (is_ref) {
         if ((what & PARC_POST_OBS) && do_hf) __syncthreads();   // B2, early
         if (what & (PARC_POST_REF | PARC_POST_REWARD_DONE)) {
-            // DeepMimicEnv._update_ref_motion  dm_env.py:570-595
-            const v3 r_pos = p_root;
-            const q4 r_rot = r_root;
-            const q4 rq = jq;
-            float r_contact = valid ? lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend) : 0.f;
-            v3 r_vel = ld3(fq.row0 + ml.off_root_vel), r_avel = ld3(fq.row0 + ml.off_root_ang_vel);
-            if ((what & PARC_POST_REF) && live) {
-                if (b == 0) {
-                    st3(buf.ref_root_pos + 3 * (size_t)e, r_pos);
-                    st4(buf.ref_root_rot + 4 * (size_t)e, r_rot);
-                    st3(buf.ref_root_vel + 3 * (size_t)e, r_vel);
-                    st3(buf.ref_root_ang_vel + 3 * (size_t)e, r_avel);
-                } else if (valid) {
-                    st4(buf.ref_joint_rot + ((size_t)e * J + (b - 1)) * 4, rq);
-                    joint_rot_to_dof(m, b, rq, buf.ref_dof_pos + (size_t)e * D);      // K4
-                }
-                if (valid) {
-                    buf.ref_contacts[(size_t)e * B + b] = r_contact;
-                    st3(buf.ref_body_pos + ((size_t)e * B + b) * 3, pos);
-                }
-                #pragma unroll 1
-                for (int d = b; d < D; d += GRP) buf.ref_dof_vel[(size_t)e * D + d] = fq.row0[ml.off_dof_vel + d];
-                if (what & PARC_POST_INIT_CHAR) {
-                    // RefCharEnv._char_state_init_from_ref + add_noise_to_char_state  mgdm_dm_util.py:119-136
-                    float *wrs = const_cast<float *>(buf.root_state) + (size_t)e * 13;
-                    float *wds = const_cast<float *>(buf.dof_state) + (size_t)e * D * 2;
-                    if (b == 0) {
-                        v3 ip = r_pos;
-                        if (buf.init_noise_xy) {
-                            ip.x += buf.init_noise_xy[2 * e];
-                            ip.y += buf.init_noise_xy[2 * e + 1];
-                        }
-                        st3(wrs, ip);
-                        st4(wrs + 3, r_rot);
-                        st3(wrs + 7, r_vel);
-                        st3(wrs + 10, r_avel);
-                    } else if (valid) {
-                        joint_rot_to_dof(m, b, rq, buf.ref_dof_pos + (size_t)e * D, wds);
-                    }
-#pragma unroll 1
-                    for (int d = b; d < D; d += GRP) wds[2 * d + 1] = fq.row0[ml.off_dof_vel + d];
-                }
-            }
             if (what & PARC_POST_REWARD_DONE) {
                 // compute_deepmimic_reward  mgdm_dm_util.py:327-390 (track_root, track_root_h)
                 float pose_e = 0.f, vel_e = 0.f, key_e = 0.f, cpen = 0.f;
