@@ -644,7 +644,10 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         pr.y += buf.motion_xy_offset[2 * pe + 1] - buf.env_offsets[3 * pe + 1];
         float4 *qd = reinterpret_cast<float4 *>(qryd[pq][ple]);
         qd[0] = make_float4(__int_as_float(fq.idx0), __int_as_float(fq.idx1), fq.blend, pr.x);
-        qd[1] = make_float4(pr.y, pr.z, 0.f, 0.f);
+        // (reference query only) env time and the motion-end flag of DeepMimicEnv.update_done, dm_env.py:746-783: the clip
+        // length / loop mode were just loaded for the query, the termination code reads the result from LDS
+        const int motion_end = (pq == 0) && (mtime >= ml.length[mid]) && (ml.loop_mode[mid] != 1);
+        qd[1] = make_float4(pr.y, pr.z, buf.time_buf[pe], __int_as_float(motion_end));
     }
     // xy target resample (PARC_POST_TARGETS): lanes 4 (1 + S) .. 4 (2 + S) - 1 of wave 0, one per env
     if (wv == 0 && tid >= POST_EPB * (1 + S) && tid < POST_EPB * (2 + S)) {
@@ -916,7 +919,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                         buf.reward_terms[8 * (size_t)N + e] = task_r;
                     }
                     // done
-                    const float tm = buf.time_buf[e];
+                    const float tm = qryd[0][le][6];
                     int done = PARC_DONE_NULL;
                     if (tm >= cfg.episode_length) done = PARC_DONE_TIME;
                     if (cfg.enable_early_termination) {
@@ -935,9 +938,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                         if (failed) done = PARC_DONE_FAIL;
                     }
                     // DeepMimicEnv.update_done  dm_env.py:746-783
-                    const int64_t mid = buf.motion_ids[e];
-                    const float mtime = tm + buf.motion_time_offsets[e];                          // dm_env.py:597-602
-                    int motion_end = (mtime >= ml.length[mid]) && (ml.loop_mode[mid] != 1);
+                    const int motion_end = __float_as_int(qryd[0][le][7]);
                     int kind = 0;
                     if (done != PARC_DONE_NULL || motion_end) kind = (done == PARC_DONE_FAIL) ? 1 : 2;
                     if (motion_end) done = PARC_DONE_FAIL;
