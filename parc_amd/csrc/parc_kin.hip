@@ -590,9 +590,10 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                                                                      const float *__restrict__ ray_xy) {
     __shared__ __attribute__((aligned(16))) float rows[POST_EPB * POST_MAX_ROW];   // 4 rows at stride obs_dim (contiguous, like the 4 output rows)
     __shared__ float hfp[POST_EPB][8];
-    __shared__ __attribute__((aligned(16))) float envd[POST_EPB][12];                            // root pos 3 | root rot 4 | heading^-1 4 | env id
+    __shared__ __attribute__((aligned(16))) float envd[POST_EPB][20];   // root pos 3 | root rot 4 | heading^-1 4 | env id | root vel 3 | ang vel 3
     __shared__ __attribute__((aligned(16))) float qryd[1 + PARC_MAX_TAR_STEPS][POST_EPB][8];    // frame idx0, idx1, blend, root xyz
-    __shared__ float tgt_xy[POST_EPB][2];                                                       // xy target the task terms read
+    __shared__ float tgt_xy[POST_EPB][2];
+    __shared__ __attribute__((aligned(16))) float cjq[POST_EPB][GRP][4];   // simulated character's joint rotations, for the pose reward                                                       // xy target the task terms read
     const int tid = threadIdx.x;
     const int wv = tid >> 6, gg = (tid & 63) >> 4, b = tid & 15;
     const int B = m.num_bodies, J = B - 1, D = m.dof_size, K = cfg.num_key_bodies, S = cfg.num_tar_steps;
@@ -635,6 +636,8 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             ed[0] = make_float4(prs[0], prs[1], prs[2], cr.x);
             ed[1] = make_float4(cr.y, cr.z, cr.w, hi.x);
             ed[2] = make_float4(hi.y, hi.z, hi.w, __int_as_float(pe));
+            ed[3] = make_float4(prs[7], prs[8], prs[9], prs[10]);
+            ed[4] = make_float4(prs[11], prs[12], 0.f, 0.f);
         }
         // K3 index part: MotionLib.calc_motion_frame at t (ref) or t + dt_s (targets); dm_env.py:570-582, mgdm_dm_util.py:279-302
         const float t = mtime + (pq > 0 ? cfg.tar_dt[pq - 1] : 0.f);
@@ -689,7 +692,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     if (((what & 0x10000) && is_tar) || ((what & 0x20000) && is_ref) || ((what & 0x40000) && is_char)) return;
 
     const int e = __float_as_int(envd[le][11]);
-    const float *rs = buf.root_state + (size_t)e * 13;
     const float *dofs = buf.dof_state + (size_t)e * D * 2;  // interleaved pos,vel
 
     // ---- phase A: every group gets its pose (root transform + one joint rotation per lane)
@@ -701,6 +703,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         p_root = mk3(envd[le][0], envd[le][1], envd[le][2]);
         r_root = mk4(envd[le][3], envd[le][4], envd[le][5], envd[le][6]);
         if (valid && b > 0) jq = joint_dof_to_rot(m, b, dofs, 2);      // K1 (kin_char_model.py:478-491)
+        *reinterpret_cast<float4 *>(cjq[le][b]) = make_float4(jq.x, jq.y, jq.z, jq.w);
     } else {
         const float4 q0 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[0];
         const float4 q1 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[1];
@@ -736,8 +739,8 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             // compute_char_obs  envs/ig_char_env.py:582-626 (global_obs False, no root height)
             if (b == 0) {
                 quat_to_tan_norm(quat_mul(hinv, c_rot), row);
-                st3(row + 6, quat_rotate(hinv, ld3(rs + 7)));
-                st3(row + 9, quat_rotate(hinv, ld3(rs + 10)));
+                st3(row + 6, quat_rotate(hinv, ld3(envd[le] + 12)));     // simulated root velocities, staged by phase 0
+                st3(row + 9, quat_rotate(hinv, ld3(envd[le] + 15)));
             } else if (valid) {
                 quat_to_tan_norm(jq, row + 12 + 6 * (b - 1));
             }
@@ -820,7 +823,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     }
     // The reference wave writes no observation columns: it passes both barriers right away and does the rest of its epilogue
     // (reward, termination) while the other waves gather the heightmap and stream the rows out.
-    if (what & PARC_POST_OBS) __syncthreads();          // B1: pose-derived columns are in LDS
+    if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) __syncthreads();   // B1: pose-derived columns and cjq are in LDS
     if (is_ref) {
         if ((what & PARC_POST_OBS) && do_hf) __syncthreads();   // B2, early
         if (what & (PARC_POST_REF | PARC_POST_REWARD_DONE)) {
@@ -832,7 +835,8 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 const v3 sim_pos = ld3(bs);
                 const v3 sim_root = ld3(buf.rigid_body_state + (size_t)e * B * 13);
                 if (valid && b > 0) {
-                    q4 cj = joint_dof_to_rot(m, b, dofs, 2);
+                    const float4 cq = *reinterpret_cast<const float4 *>(cjq[le][b]);    // from the character wave (before B1)
+                    q4 cj = mk4(cq.x, cq.y, cq.z, cq.w);
                     float da = quat_diff_angle(cj, rq);
                     pose_e = cfg.joint_err_w[b - 1] * da * da;
                 }
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                     float root_pos_err = dot3(dp, dp);
                     float rre = quat_diff_angle(c_rot, r_rot);
                     float rre2 = rre * rre;
-                    v3 dv = r_vel - ld3(rs + 7), dw = r_avel - ld3(rs + 10);
+                    v3 dv = r_vel - ld3(envd[le] + 12), dw = r_avel - ld3(envd[le] + 15);
                     float pose_r = fexp(-0.25f * pose_e);
                     float vel_r = fexp(-0.01f * vel_e);
                     float root_pose_r = fexp(-5.0f * (root_pos_err + 0.1f * rre2));
@@ -903,7 +907,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                         float tl = fsqrt(terr);
                         float itl = frcp(tl);
                         float dxn = tl > 0.01f ? tx * itl : 0.f, dyn = tl > 0.01f ? ty * itl : 0.f;
-                        float mve = fmaxf(2.0f - (dxn * rs[7] + dyn * rs[8]), 0.f);
+                        float mve = fmaxf(2.0f - (dxn * envd[le][12] + dyn * envd[le][13]), 0.f);
                         float min_vel_r = fexp(-(mve * mve));
                         // heading direction (cos h, sin h) = normalised xy of the rotated x axis
                         float ha = 1.0f - 2.0f * (c_rot.y * c_rot.y + c_rot.z * c_rot.z), hb = 2.0f * (c_rot.w * c_rot.z + c_rot.x * c_rot.y);
