@@ -322,6 +322,8 @@ PARC_DEV void joint_rot_to_dof(const parc_char_model_t &m, int b, q4 q, float *d
 
 // anim/kin_char_model.py:509-541, level-synchronous over the tree: lane b ends with body b's world
 // position/rotation.  jq = joint rotation of lane's body (ignored for the root lane).
+// LEAF_ROT = false: the rotations of the deepest level are not produced (callers that only use positions)
+template <bool LEAF_ROT = true>
 PARC_DEV void group_fk(const parc_char_model_t &m, int b, v3 root_pos, q4 root_rot, q4 jq, v3 &pos, q4 &rot) {
     const bool valid = b < m.num_bodies;
     const int par = (valid && b > 0) ? m.parent[b] : 0;
@@ -339,7 +341,7 @@ PARC_DEV void group_fk(const parc_char_model_t &m, int b, v3 root_pos, q4 root_r
         q4 pr = shfl16(rot, par);
         if (dep == lev) {
             pos = pp + quat_rotate(pr, lt);
-            rot = quat_mul(pr, lq);
+            if (LEAF_ROT || lev < m.max_depth) rot = quat_mul(pr, lq);
         }
     }
 }
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     // doubling in the root frame - drifts ~1e-4 from the reference's body positions)
     v3 pos;
     q4 rot;
-    group_fk(m, b, p_root, r_root, jq, pos, rot);
+    group_fk<false>(m, b, p_root, r_root, jq, pos, rot);
 
     // the simulated root pose and heading are only needed from here on: read them after the tree walk (11 fewer live
     // registers through it; the compiler barrier keeps the LDS reads from being hoisted back up)
