@@ -267,14 +267,22 @@ static bool model_ok(const parc_char_model_t &m) { return m.num_bodies >= 1 && m
 PARC_DEV float shfl16(float v, int src) { return __shfl(v, src, GRP); }
 PARC_DEV q4 shfl16(q4 q, int src) { return q4{shfl16(q.x, src), shfl16(q.y, src), shfl16(q.z, src), shfl16(q.w, src)}; }
 PARC_DEV v3 shfl16(v3 v, int src) { return v3{shfl16(v.x, src), shfl16(v.y, src), shfl16(v.z, src)}; }
+// all-reduce over the 16 lanes of a group = one DPP row: rotate-and-add with row_ror 8, 4, 2, 1 (dpp_ctrl 0x120 + n).  DPP
+// operands ride on the VALU instruction itself - no ds_bpermute round trip per step as with __shfl_xor.
+template <int CTRL>
+PARC_DEV float row_ror_f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false)); }
 PARC_DEV float sum16(float v) {
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, GRP);
+    v += row_ror_f<0x128>(v);
+    v += row_ror_f<0x124>(v);
+    v += row_ror_f<0x122>(v);
+    v += row_ror_f<0x121>(v);
     return v;
 }
 PARC_DEV int any16(int v) {
-#pragma unroll
-    for (int m = 8; m >= 1; m >>= 1) v |= __shfl_xor(v, m, GRP);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);
     return v;
 }
 
