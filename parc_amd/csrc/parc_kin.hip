@@ -783,12 +783,16 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         }
     }
     // ---- reference wave, part 1 (before the barrier, while the target waves are still busy): reference state out
-    const v3 r_pos = p_root;
-    const q4 r_rot = r_root;
-    const q4 rq = jq;
-    float r_contact = 0.f;
-    v3 r_vel = mk3(0.f, 0.f, 0.f), r_avel = mk3(0.f, 0.f, 0.f);
-    if (is_ref && (what & (PARC_POST_REF | PARC_POST_REWARD_DONE))) {
+    // Everything the reference wave does lives in this one branch (its values never meet the other roles' registers), including
+    // its own copies of the two barriers: it requests the simulator outputs it needs, writes the reference state, meets the
+    // other waves at B1, passes B2 at once, and finishes reward / termination while they gather the heightmap and copy out.
+    if (is_ref) {
+      const v3 r_pos = p_root;
+      const q4 r_rot = r_root;
+      const q4 rq = jq;
+      float r_contact = 0.f;
+      v3 r_vel = mk3(0.f, 0.f, 0.f), r_avel = mk3(0.f, 0.f, 0.f);
+      if (what & (PARC_POST_REF | PARC_POST_REWARD_DONE)) {
         // DeepMimicEnv._update_ref_motion  dm_env.py:570-595
         r_contact = valid ? lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend) : 0.f;
         r_vel = ld3(fq.row0 + ml.off_root_vel);
@@ -831,19 +835,16 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             }
         }
     }
-    // The reference wave writes no observation columns: it passes both barriers right away and does the rest of its epilogue
-    // (reward, termination) while the other waves gather the heightmap and stream the rows out.
-    if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) __syncthreads();   // B1: pose-derived columns and cjq are in LDS
-    if (is_ref) {
-        if ((what & PARC_POST_OBS) && do_hf) __syncthreads();   // B2, early
+      if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) __syncthreads();   // B1 (reference wave's arrival)
+      if ((what & PARC_POST_OBS) && do_hf) __syncthreads();                  // B2, early
         if (what & (PARC_POST_REF | PARC_POST_REWARD_DONE)) {
             if (what & PARC_POST_REWARD_DONE) {
                 // compute_deepmimic_reward  mgdm_dm_util.py:327-390 (track_root, track_root_h)
                 float pose_e = 0.f, vel_e = 0.f, key_e = 0.f, cpen = 0.f;
                 int pose_fail = 0, fall_contact = 0, fall_height = 0;
-                const float *bs = buf.rigid_body_state + ((size_t)e * B + (valid ? b : 0)) * 13;
-                const v3 sim_pos = ld3(bs);
-                const v3 sim_root = ld3(buf.rigid_body_state + (size_t)e * B * 13);
+                const v3 sim_pos = ld3(buf.rigid_body_state + ((size_t)e * B + (valid ? b : 0)) * 13);
+                const v3 sim_root = shfl16(sim_pos, 0);          // body 0 is the root
+                const v3 sim_f = ld3(buf.contact_forces + ((size_t)e * B + (valid ? b : 0)) * 3);
                 if (valid && b > 0) {
                     const float4 cq = *reinterpret_cast<const float4 *>(cjq[le][b]);    // from the character wave (before B1)
                     q4 cj = mk4(cq.x, cq.y, cq.z, cq.w);
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 }
                 if (valid) {
                     // compute_contact_reward  mgdm_dm_util.py:555-576
-                    v3 f = ld3(buf.contact_forces + ((size_t)e * B + b) * 3);
+                    const v3 f = sim_f;
                     float fn = fminf(fsqrt(dot3(f, f)), 1.0f);
                     float cr = -(1.0f - r_contact) * fn;
                     cr += r_contact * fn;
@@ -963,6 +964,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         }
         return;
     }
+    if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) __syncthreads();   // B1: pose-derived columns and cjq are in LDS
     if (what & PARC_POST_OBS) {
         const int nthr = blockDim.x - 64;               // all waves but the reference wave
         const int tid = is_char ? (int)threadIdx.x : (int)threadIdx.x - 64;
