@@ -648,6 +648,11 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             ed[2] = make_float4(hi.y, hi.z, hi.w, __int_as_float(pe));
             ed[3] = make_float4(prs[7], prs[8], prs[9], prs[10]);
             ed[4] = make_float4(prs[11], prs[12], 0.f, 0.f);
+            if (do_hf) {       // affine cell-unit maps of this env's heightmap fan (see hf_gather_kernel)
+                hf_env_prm pr = hf_env_params<true>(pe, buf.root_state, buf.env_offsets, ter, 1.0f / ter.dx, 1.0f / ter.dy);
+                hfp[ple][0] = pr.ax; hfp[ple][1] = pr.bx; hfp[ple][2] = pr.cx; hfp[ple][3] = pr.ay; hfp[ple][4] = pr.by; hfp[ple][5] = pr.cy;
+                hfp[ple][6] = pr.gz;
+            }
         }
         // K3 index part: MotionLib.calc_motion_frame at t (ref) or t + dt_s (targets); dm_env.py:570-582, mgdm_dm_util.py:279-302
         const float t = mtime + (pq > 0 ? cfg.tar_dt[pq - 1] : 0.f);
@@ -757,10 +762,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             #pragma unroll 1
             for (int d = b; d < D; d += GRP) row[12 + 6 * J + d] = dofs[2 * d + 1];
             if (key_slot >= 0) st3(row + 12 + 6 * J + D + 3 * key_slot, quat_rotate(hinv, pos - c_pos));
-            if (b == 0 && do_hf) {
-                hf_env_prm pr = hf_env_params<true>(e, buf.root_state, buf.env_offsets, ter, 1.0f / ter.dx, 1.0f / ter.dy);
-                hfp[le][0] = pr.ax; hfp[le][1] = pr.bx; hfp[le][2] = pr.cx; hfp[le][3] = pr.ay; hfp[le][4] = pr.by; hfp[le][5] = pr.cy; hfp[le][6] = pr.gz;
-            }
             // char contacts  ig_parkour_env.py:841-848
             if (valid) {
                 v3 f = ld3(buf.contact_forces + ((size_t)e * B + b) * 3);
@@ -836,7 +837,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         }
     }
       if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) __syncthreads();   // B1 (reference wave's arrival)
-      if ((what & PARC_POST_OBS) && do_hf) __syncthreads();                  // B2, early
         if (what & (PARC_POST_REF | PARC_POST_REWARD_DONE)) {
             if (what & PARC_POST_REWARD_DONE) {
                 // compute_deepmimic_reward  mgdm_dm_util.py:327-390 (track_root, track_root_h)
@@ -964,11 +964,12 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         }
         return;
     }
-    if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) __syncthreads();   // B1: pose-derived columns and cjq are in LDS
+    const int nthr = blockDim.x - 64;               // all waves but the reference wave
+    const int tid2 = is_char ? (int)threadIdx.x : (int)threadIdx.x - 64;
     if (what & PARC_POST_OBS) {
-        const int nthr = blockDim.x - 64;               // all waves but the reference wave
-        const int tid = is_char ? (int)threadIdx.x : (int)threadIdx.x - 64;
-        int out_len = row_len;
+        // The heightmap columns depend on phase 0 only (hfp), not on the other waves' columns: every wave gathers its share as soon
+        // as its own role is done, ahead of the barrier - the early finishers fill the wait with it and one barrier goes away.
+        const int tid = tid2;
         if (do_hf) {
             // K5 fused: RefCharEnv._refresh_ray_obs_hfs (mgdm_dm_util.py:158-179) for the 4 envs of this workgroup,
             // same affine cell-unit form as hf_gather_kernel
@@ -984,9 +985,13 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 uj = __builtin_amdgcn_fmed3f(rintf(uj), 0.f, max_j);
                 rows[l2 * RS + row_len + p] = __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - h6, cfg.min_obs_h, cfg.max_obs_h);
             }
-            out_len = cfg.obs_dim;
-            __syncthreads();
         }
+    }
+    if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) __syncthreads();   // B1: all observation columns and cjq are in LDS
+    if (what & PARC_POST_OBS) {
+        const int tid = tid2;
+        int out_len = row_len;
+        if (do_hf) out_len = cfg.obs_dim;
         const int nlive = min(POST_EPB, n_total - (int)blockIdx.x * POST_EPB);
         if (!env_ids && !masked && out_len == RS) {
             // consecutive envs, whole rows: the LDS image IS the output image
