@@ -599,7 +599,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                                                                      const int64_t *__restrict__ env_ids, int n_total, int what,
                                                                      const float *__restrict__ ray_xy) {
     __shared__ __attribute__((aligned(16))) float rows[POST_EPB * POST_MAX_ROW];   // 4 rows at stride obs_dim (contiguous, like the 4 output rows)
-    __shared__ float hfp[POST_EPB][8];
     __shared__ __attribute__((aligned(16))) float envd[POST_EPB][20];   // root pos 3 | root rot 4 | heading^-1 4 | env id | root vel 3 | ang vel 3
     __shared__ __attribute__((aligned(16))) float qryd[1 + PARC_MAX_TAR_STEPS][POST_EPB][8];    // frame idx0, idx1, blend, root xyz
     __shared__ float tgt_xy[POST_EPB][2];
@@ -648,11 +647,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             ed[2] = make_float4(hi.y, hi.z, hi.w, __int_as_float(pe));
             ed[3] = make_float4(prs[7], prs[8], prs[9], prs[10]);
             ed[4] = make_float4(prs[11], prs[12], 0.f, 0.f);
-            if (do_hf) {       // affine cell-unit maps of this env's heightmap fan (see hf_gather_kernel)
-                hf_env_prm pr = hf_env_params<true>(pe, buf.root_state, buf.env_offsets, ter, 1.0f / ter.dx, 1.0f / ter.dy);
-                hfp[ple][0] = pr.ax; hfp[ple][1] = pr.bx; hfp[ple][2] = pr.cx; hfp[ple][3] = pr.ay; hfp[ple][4] = pr.by; hfp[ple][5] = pr.cy;
-                hfp[ple][6] = pr.gz;
-            }
         }
         // K3 index part: MotionLib.calc_motion_frame at t (ref) or t + dt_s (targets); dm_env.py:570-582, mgdm_dm_util.py:279-302
         const float t = mtime + (pq > 0 ? cfg.tar_dt[pq - 1] : 0.f);
@@ -697,6 +691,28 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         }
         tgt_xy[ple][0] = tx;
         tgt_xy[ple][1] = ty;
+    }
+    // K5 fused, ahead of everything: RefCharEnv._refresh_ray_obs_hfs (mgdm_dm_util.py:158-179) for the 4 envs of this workgroup.
+    // The heightmap columns need the simulated root state only, so waves 1.. gather them while wave 0 walks the dependent loads of
+    // phase 0 (clip ids -> clip table -> frame rows) that they would otherwise just wait for.  Same affine cell-unit form as
+    // hf_gather_kernel; every thread derives the map of its env itself.
+    if ((what & PARC_POST_OBS) && do_hf && wv >= 1) {
+        const int P = cfg.num_ray_points;
+        const int hthr = blockDim.x - 64, ht = tid - 64;
+        const int tpe = hthr / POST_EPB, l2 = ht / tpe;            // blockDim = 64*(2+S): hthr is a multiple of POST_EPB
+        const int hel = min((int)blockIdx.x * POST_EPB + l2, n_total - 1);
+        const int he = env_ids ? (int)env_ids[hel] : hel;
+        const hf_env_prm pr = hf_env_params<true>(he, buf.root_state, buf.env_offsets, ter, 1.0f / ter.dx, 1.0f / ter.dy);
+        const float max_i = (float)(ter.dim_x - 1), max_j = (float)(ter.dim_y - 1);
+        float *hrow = rows + l2 * cfg.obs_dim + (cfg.obs_dim - P);
+        for (int p = ht - l2 * tpe; p < P; p += tpe) {
+            float rx = ray_xy[2 * p], ry = ray_xy[2 * p + 1];
+            float ui = fmaf(rx, pr.ax, fmaf(ry, pr.bx, pr.cx));
+            float uj = fmaf(rx, pr.ay, fmaf(ry, pr.by, pr.cy));
+            ui = __builtin_amdgcn_fmed3f(rintf(ui), 0.f, max_i);
+            uj = __builtin_amdgcn_fmed3f(rintf(uj), 0.f, max_j);
+            hrow[p] = __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - pr.gz, cfg.min_obs_h, cfg.max_obs_h);
+        }
     }
     // loads that do not depend on phase 0
     int key_slot = -1;
@@ -966,27 +982,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     }
     const int nthr = blockDim.x - 64;               // all waves but the reference wave
     const int tid2 = is_char ? (int)threadIdx.x : (int)threadIdx.x - 64;
-    if (what & PARC_POST_OBS) {
-        // The heightmap columns depend on phase 0 only (hfp), not on the other waves' columns: every wave gathers its share as soon
-        // as its own role is done, ahead of the barrier - the early finishers fill the wait with it and one barrier goes away.
-        const int tid = tid2;
-        if (do_hf) {
-            // K5 fused: RefCharEnv._refresh_ray_obs_hfs (mgdm_dm_util.py:158-179) for the 4 envs of this workgroup,
-            // same affine cell-unit form as hf_gather_kernel
-            const int P = cfg.num_ray_points;
-            const float max_i = (float)(ter.dim_x - 1), max_j = (float)(ter.dim_y - 1);
-            const int tpe = nthr / POST_EPB, l2 = tid / tpe;       // blockDim = 64*(2+S): a multiple of POST_EPB
-            const float h0 = hfp[l2][0], h1 = hfp[l2][1], h2 = hfp[l2][2], h3 = hfp[l2][3], h4 = hfp[l2][4], h5 = hfp[l2][5], h6 = hfp[l2][6];
-            for (int p = tid - l2 * tpe; p < P; p += tpe) {
-                float rx = ray_xy[2 * p], ry = ray_xy[2 * p + 1];
-                float ui = fmaf(rx, h0, fmaf(ry, h1, h2));
-                float uj = fmaf(rx, h3, fmaf(ry, h4, h5));
-                ui = __builtin_amdgcn_fmed3f(rintf(ui), 0.f, max_i);
-                uj = __builtin_amdgcn_fmed3f(rintf(uj), 0.f, max_j);
-                rows[l2 * RS + row_len + p] = __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - h6, cfg.min_obs_h, cfg.max_obs_h);
-            }
-        }
-    }
     if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) __syncthreads();   // B1: all observation columns and cjq are in LDS
     if (what & PARC_POST_OBS) {
         const int tid = tid2;
