@@ -600,7 +600,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                                                                      const float *__restrict__ ray_xy) {
     __shared__ __attribute__((aligned(16))) float rows[POST_EPB * POST_MAX_ROW];   // 4 rows at stride obs_dim (contiguous, like the 4 output rows)
     __shared__ __attribute__((aligned(16))) float envd[POST_EPB][20];   // root pos 3 | root rot 4 | heading^-1 4 | env id | root vel 3 | ang vel 3
-    __shared__ __attribute__((aligned(16))) float qryd[1 + PARC_MAX_TAR_STEPS][POST_EPB][8];    // frame idx0, idx1, blend, root xyz
+    __shared__ __attribute__((aligned(16))) float qryd[1 + PARC_MAX_TAR_STEPS][POST_EPB][12];   // idx0 idx1 blend - | loop shift xyz, time | tile offset xy, motion end
     __shared__ float tgt_xy[POST_EPB][2];
     __shared__ __attribute__((aligned(16))) float cjq[POST_EPB][GRP][4];   // simulated character's joint rotations, for the pose reward                                                       // xy target the task terms read
     const int tid = threadIdx.x;
@@ -651,15 +651,23 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         // K3 index part: MotionLib.calc_motion_frame at t (ref) or t + dt_s (targets); dm_env.py:570-582, mgdm_dm_util.py:279-302
         const float t = mtime + (pq > 0 ? cfg.tar_dt[pq - 1] : 0.f);
         const frame_query fq = make_query(ml, mid, t);
-        v3 pr = query_root_pos(ml, fq, mid);
-        pr.x += buf.motion_xy_offset[2 * pe] - buf.env_offsets[3 * pe];              // _move_to_motion_terrain dm_env.py:604-615
-        pr.y += buf.motion_xy_offset[2 * pe + 1] - buf.env_offsets[3 * pe + 1];
+        // The frame rows themselves (root position included) are loaded by the pose lanes after the barrier, together with the
+        // quaternions: this lane only publishes what does not need them - indices, blend, the loop shift of wrapping clips
+        // (motion_lib.py:458-475) and the tile offset (_move_to_motion_terrain dm_env.py:604-615) - so the barrier is reached one
+        // memory round trip earlier.
+        v3 shift = mk3(0.f, 0.f, 0.f);
+        if (fq.wrap) {
+            const float *d = ml.pos_delta + 3 * mid;
+            shift = mk3(fq.loop_phase * d[0], fq.loop_phase * d[1], fq.loop_phase * d[2]);
+        }
         float4 *qd = reinterpret_cast<float4 *>(qryd[pq][ple]);
-        qd[0] = make_float4(__int_as_float(fq.idx0), __int_as_float(fq.idx1), fq.blend, pr.x);
+        qd[0] = make_float4(__int_as_float(fq.idx0), __int_as_float(fq.idx1), fq.blend, 0.f);
         // (reference query only) env time and the motion-end flag of DeepMimicEnv.update_done, dm_env.py:746-783: the clip
         // length / loop mode were just loaded for the query, the termination code reads the result from LDS
         const int motion_end = (pq == 0) && (mtime >= ml.length[mid]) && (ml.loop_mode[mid] != 1);
-        qd[1] = make_float4(pr.y, pr.z, buf.time_buf[pe], __int_as_float(motion_end));
+        qd[1] = make_float4(shift.x, shift.y, shift.z, buf.time_buf[pe]);
+        qd[2] = make_float4(buf.motion_xy_offset[2 * pe] - buf.env_offsets[3 * pe], buf.motion_xy_offset[2 * pe + 1] - buf.env_offsets[3 * pe + 1],
+                            __int_as_float(motion_end), 0.f);
     }
     // xy target resample (PARC_POST_TARGETS): lanes 4 (1 + S) .. 4 (2 + S) - 1 of wave 0, one per env
     if (wv == 0 && tid >= POST_EPB * (1 + S) && tid < POST_EPB * (2 + S)) {
@@ -738,13 +746,21 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     } else {
         const float4 q0 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[0];
         const float4 q1 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[1];
+        const float4 q2 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[2];
         fq.idx0 = __float_as_int(q0.x);
         fq.idx1 = __float_as_int(q0.y);
         fq.blend = q0.z;
         fq.row0 = ml.frames + (size_t)fq.idx0 * ml.row_stride;
         fq.row1 = ml.frames + (size_t)fq.idx1 * ml.row_stride;
         if (valid) jq = query_quat(fq, b);
-        p_root = mk3(q0.w, q1.x, q1.y);
+        {
+            // root position: lerp of the two rows, + loop shift, + tile offset (the order of query_root_pos and dm_env.py:604-615)
+            const float *p0 = fq.row0 + ml.off_pos, *p1 = fq.row1 + ml.off_pos;
+            p_root = mk3(lerp_ref(p0[0], p1[0], fq.blend), lerp_ref(p0[1], p1[1], fq.blend), lerp_ref(p0[2], p1[2], fq.blend));
+            p_root = p_root + mk3(q1.x, q1.y, q1.z);
+            p_root.x += q2.x;
+            p_root.y += q2.y;
+        }
         r_root = shfl16(jq, 0);
     }
     // ---- phase B: K2 forward kinematics, level-synchronous inside the 16-lane group
@@ -950,7 +966,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                         buf.reward_terms[8 * (size_t)N + e] = task_r;
                     }
                     // done
-                    const float tm = qryd[0][le][6];
+                    const float tm = qryd[0][le][7];
                     int done = PARC_DONE_NULL;
                     if (tm >= cfg.episode_length) done = PARC_DONE_TIME;
                     if (cfg.enable_early_termination) {
@@ -969,7 +985,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                         if (failed) done = PARC_DONE_FAIL;
                     }
                     // DeepMimicEnv.update_done  dm_env.py:746-783
-                    const int motion_end = __float_as_int(qryd[0][le][7]);
+                    const int motion_end = __float_as_int(qryd[0][le][10]);
                     int kind = 0;
                     if (done != PARC_DONE_NULL || motion_end) kind = (done == PARC_DONE_FAIL) ? 1 : 2;
                     if (motion_end) done = PARC_DONE_FAIL;
