@@ -114,7 +114,10 @@ def main():
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            if torch.distributed.get_backend() == "nccl":
+                torch.distributed.barrier(device_ids=[torch.cuda.current_device()])
+            else:
+                torch.distributed.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -284,11 +287,11 @@ def main():
             "mean_episode_return": info["mean_return"] if info else None,
             "mean_episode_length": info["mean_ep_len"] if info else None,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # (the CPU leg is a single-GPU datum: rank 0 at N=1 only)
             out["cpu_baseline"] = cpu_baseline(env, clips, tiled)
         print(json.dumps(out))
     if world > 1:
-        torch.distributed.barrier()
+        barrier()
         torch.distributed.destroy_process_group()
 
 

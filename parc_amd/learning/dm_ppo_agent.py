@@ -46,6 +46,7 @@ def enable_tuned_gemms():
         return
     tunable.set_filename(path, False)
     tunable.tuning_enable(False)
+    tunable.write_file_on_exit(False)       # selection only: never rewrite the shipped file (N ranks share it)
     tunable.enable(True)
 
 
