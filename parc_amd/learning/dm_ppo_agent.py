@@ -46,7 +46,8 @@ def enable_tuned_gemms():
         return
     tunable.set_filename(path, False)
     tunable.tuning_enable(False)
-    tunable.write_file_on_exit(False)       # selection only: never rewrite the shipped file (N ranks share it)
+    if hasattr(tunable, "write_file_on_exit"):
+        tunable.write_file_on_exit(False)   # selection only: never rewrite the shipped file (N ranks share it)
     tunable.enable(True)
 
 

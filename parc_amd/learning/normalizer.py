@@ -21,41 +21,53 @@ class Normalizer(torch.nn.Module):
         if init_std is not None:
             self._std[:] = init_std
         self._mean_sq = None
+        # statistics gathered since the last update(): row 0 = sum x, row 1 = sum x^2 (one buffer, so a record() is two
+        # reductions into adjacent rows and update() exchanges it between ranks in ONE all-reduce together with the count)
         self._new_count = 0
-        self._new_sum = torch.zeros_like(self._mean)
-        self._new_sum_sq = torch.zeros_like(self._mean)
+        self._acc = torch.zeros((2,) + tuple(self._mean.shape), device=device, dtype=dtype)
+
+    @property
+    def _new_sum(self):
+        return self._acc[0]
+
+    @property
+    def _new_sum_sq(self):
+        return self._acc[1]
 
     def record(self, x):
-        shape = self._mean.shape
-        assert len(x.shape) > len(shape)
-        x = x.flatten(start_dim=0, end_dim=len(x.shape) - len(shape) - 1)
-        self._new_count += x.shape[0]
-        self._new_sum += torch.sum(x, dim=0)
-        self._new_sum_sq += torch.sum(torch.square(x), dim=0)
+        lead = x.dim() - self._mean.dim()
+        assert lead > 0
+        rows = x.reshape((-1,) + tuple(self._mean.shape))
+        self._new_count += rows.shape[0]           # (host-side int: the graph rollout accounts for it itself)
+        self._acc[0] += rows.sum(dim=0)
+        self._acc[1] += (rows * rows).sum(dim=0)
 
     def update(self):
+        """Fold the recorded batch into the running moments (count-weighted average of E[x] and E[x^2], learning/normalizer.py:36-62
+        of the reference); with several ranks the batch statistics are summed over all of them first."""
         if self._mean_sq is None:
-            self._mean_sq = (torch.square(self._std) + torch.square(self._mean)).type(self.dtype)
-        self._new_count = mp_util.reduce_sum(self._new_count)
-        mp_util.reduce_inplace_sum(self._new_sum)
-        mp_util.reduce_inplace_sum(self._new_sum_sq)
-        new_count = self._new_count
-        new_mean = self._new_sum / new_count
-        new_mean_sq = self._new_sum_sq / new_count
-        new_total = self._count + new_count
-        w_old = self._count.type(torch.float) / new_total.type(torch.float)
-        w_new = float(new_count) / new_total.type(torch.float)
-        self._mean[:] = w_old * self._mean + w_new * new_mean
-        self._mean_sq[:] = w_old * self._mean_sq + w_new * new_mean_sq
-        self._count[:] = new_total
-        var = torch.clamp_min(self._mean_sq - torch.square(self._mean), self._min_var)
-        self._std[:] = torch.sqrt(var).type(self.dtype)
-        self._new_count = 0
-        self._new_sum[:] = 0
-        self._new_sum_sq[:] = 0
-        if self._non_norm_indices is not None:
+            self._mean_sq = (self._std * self._std + self._mean * self._mean).type(self.dtype)
+        n_new = self._new_count
+        if mp_util.enable_mp():
+            # one exchange: [sum | sum of squares | count] in float64 (exact for the count, no loss for the fp32 sums)
+            packed = torch.cat([self._acc.reshape(-1).double(), torch.tensor([float(n_new)], dtype=torch.float64, device=self._acc.device)])
+            mp_util.reduce_inplace_sum(packed)
+            self._acc.copy_(packed[:-1].reshape(self._acc.shape))
+            n_new = int(round(packed[-1].item()))
+        n_old = self._count
+        n_tot = n_old + n_new
+        keep = n_old.type(torch.float) / n_tot.type(torch.float)
+        take = float(n_new) / n_tot.type(torch.float)
+        batch = self._acc / n_new                       # row 0 = batch mean, row 1 = batch mean of squares
+        self._mean[:] = keep * self._mean + take * batch[0]
+        self._mean_sq[:] = keep * self._mean_sq + take * batch[1]
+        self._count[:] = n_tot
+        self._std[:] = (self._mean_sq - self._mean * self._mean).clamp_min(self._min_var).sqrt().type(self.dtype)
+        if self._non_norm_indices is not None:          # columns that must pass through unchanged
             self._mean[self._non_norm_indices] = 0.0
             self._std[self._non_norm_indices] = 1.0
+        self._new_count = 0
+        self._acc.zero_()
 
     def get_shape(self):
         return self._mean.shape
