@@ -284,3 +284,41 @@ def update_ref_motion(char, mlib, motion_ids, motion_times, motion_xy_offset):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def points_hf_sdf(points, hf, min_box_center, dxdy, base_z=-10.0, inverted=True, radius=None):
+    """numpy restatement of terrain_util.points_hf_sdf (util/terrain_util.py:1835-1893, with points_boxes_sdf :1774-1804 and
+    geom_util.sdBox util/geom_util.py:122-143): fp32 throughout, min over all cells taken batch by batch, 64 points at a time."""
+    points, hf, mbc, dxdy = _f(points), _f(hf), _f(min_box_center), _f(dxdy)
+    B, N = points.shape[:2]
+    X, Y = hf.shape[1:]
+
+    def linspace32(end, n):          # torch.linspace(0, end, n) in fp32: forward steps up to the middle, backward from the end after it
+        if n == 1:
+            return np.zeros(1, np.float32)
+        step = np.float32(np.float32(end) / np.float32(n - 1))
+        i = np.arange(n)
+        return np.where(i < n // 2, np.float32(0) + step * i.astype(np.float32), np.float32(end) - step * (n - 1 - i).astype(np.float32)).astype(np.float32)
+
+    xs = linspace32((X - 1.0) * float(dxdy[0]), X)
+    ys = linspace32((Y - 1.0) * float(dxdy[1]), Y)
+    out = np.zeros((B, N), np.float32)
+    for b in range(B):
+        cx = np.repeat(xs + mbc[b, 0], Y)
+        cy = np.tile(ys + mbc[b, 1], X)
+        h = hf[b].reshape(-1)
+        if inverted:
+            top = np.float32(-base_z)
+            cz, hz = (h + top) / np.float32(2), (top - h) / np.float32(2)
+        else:
+            cz, hz = (h + np.float32(base_z)) / np.float32(2), (h - np.float32(base_z)) / np.float32(2)
+        c = np.stack([cx, cy, cz], -1).astype(np.float32)
+        hd = np.stack([np.full_like(cx, dxdy[0] / np.float32(2)), np.full_like(cx, dxdy[1] / np.float32(2)), hz], -1).astype(np.float32)
+        for s in range(0, N, 64):
+            q = np.abs(points[b, s:s + 64, None, :] - c[None]) - hd[None]
+            pos = np.maximum(q, np.float32(0))
+            sd = np.sqrt((pos * pos).sum(-1, dtype=np.float32)) + np.minimum(q.max(-1), np.float32(0))
+            if radius is not None:
+                sd = sd - np.float32(radius)
+            out[b, s:s + 64] = sd.min(-1)
+    return -out if inverted else out

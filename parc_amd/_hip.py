@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libparc_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["parc_kin.hip", "parc_sim.hip", "parc_ppo.hip"]
+SOURCES = ["parc_kin.hip", "parc_sim.hip", "parc_ppo.hip", "parc_terrain.hip"]
 
 MAX_BODIES = 16
 MAX_DOFS = 64
@@ -159,6 +159,8 @@ def _declare(L):
     L.parc_normalize_clamp.restype = c_int
     L.parc_action_head.argtypes = [c_vp, c_int, c_int] + [c_vp] * 8
     L.parc_action_head.restype = c_int
+    L.parc_points_hf_sdf.argtypes = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 5 + [c_f, c_f, c_f, c_int, c_f, c_vp]
+    L.parc_points_hf_sdf.restype = c_int
     L.parc_return_tracker_update.argtypes = [c_vp, c_int, c_int, c_vp, c_i64] + [c_vp] * 7
     L.parc_return_tracker_update.restype = c_int
     L.parc_record_step.argtypes = [c_vp, c_int, c_vp, c_int, c_vp]
@@ -177,7 +179,7 @@ def _declare(L):
 EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
             "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step",
             "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize", "parc_reset_apply", "parc_ppo_loss", "parc_ppo_workspace_floats", "parc_record_step", "parc_return_tracker_update", "parc_normalize_clamp",
-            "parc_action_head"]
+            "parc_action_head", "parc_points_hf_sdf"]
 
 
 def check(rc, what):

@@ -71,8 +71,14 @@ BODIES = [
 _AXIS = dict(x="1 0 0", y="0 1 0", z="0 0 1")
 
 
+def _num(x):
+    """shortest decimal that reads back as the same double (no 6-digit rounding of the geometry)"""
+    r = repr(float(x))
+    return r[:-2] if r.endswith(".0") else r
+
+
 def _fmt(v):
-    return " ".join("{:g}".format(float(x)) for x in v)
+    return " ".join(_num(x) for x in v)
 
 
 def _joint_names(j):
@@ -94,17 +100,17 @@ def _body_xml(spec, children, indent):
     if j is not None:
         names = _joint_names(j)
         for a, (lo, hi) in j["axes"].items():
-            lines.append('{}  <joint name="{}" type="hinge" axis="{}" range="{:g} {:g}" stiffness="{:g}" damping="{:g}" armature="{:g}"/>'.format(
-                pad, names[a], _AXIS[a], lo, hi, j["kp"], j["kd"], j["arm"]))
+            lines.append('{}  <joint name="{}" type="hinge" axis="{}" range="{} {}" stiffness="{}" damping="{}" armature="{}"/>'.format(
+                pad, names[a], _AXIS[a], _num(lo), _num(hi), _num(j["kp"]), _num(j["kd"]), _num(j["arm"])))
     for gi, g in enumerate(spec["geoms"]):
         gname = spec["name"] if gi == 0 else "{}_g{}".format(spec["name"], gi)
         if g[0] == "sphere":
-            lines.append('{}  <geom name="{}" type="sphere" pos="{}" size="{:g}" density="{:g}"/>'.format(pad, gname, _fmt(g[1]), g[2], g[3]))
+            lines.append('{}  <geom name="{}" type="sphere" pos="{}" size="{}" density="{}"/>'.format(pad, gname, _fmt(g[1]), _num(g[2]), _num(g[3])))
         elif g[0] == "capsule":
-            lines.append('{}  <geom name="{}" type="capsule" fromto="{} {}" size="{:g}" density="{:g}"/>'.format(
-                pad, gname, _fmt(g[1]), _fmt(g[2]), g[3], g[4]))
+            lines.append('{}  <geom name="{}" type="capsule" fromto="{} {}" size="{}" density="{}"/>'.format(
+                pad, gname, _fmt(g[1]), _fmt(g[2]), _num(g[3]), _num(g[4])))
         elif g[0] == "box":
-            lines.append('{}  <geom name="{}" type="box" pos="{}" size="{}" density="{:g}"/>'.format(pad, gname, _fmt(g[1]), _fmt(g[2]), g[3]))
+            lines.append('{}  <geom name="{}" type="box" pos="{}" size="{}" density="{}"/>'.format(pad, gname, _fmt(g[1]), _fmt(g[2]), _num(g[3])))
     for c in children.get(spec["name"], []):
         lines.extend(_body_xml(c, children, indent + 1))
     lines.append("{}</body>".format(pad))

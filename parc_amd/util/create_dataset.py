@@ -6,8 +6,9 @@ weight is ``clip length x (intended class fraction / actual class fraction)``, s
 regardless of how many seconds of motion it holds.  Motion files are read with the non-executing reader
 (``util.safe_pickle``): only ``frames``, ``fps``, the terrain's heightfield shape and an optional ``loss`` are needed.
 
-The reference's optional ``compute_preprocessing_data`` step (``terrain_util.compute_hf_extra_vals``, consumed by the motion
-diffusion model's training only) is outside the tracker path and raises NotImplementedError here.
+The optional ``compute_preprocessing_data`` step (``terrain_util.compute_hf_extra_vals`` per clip, written back into the
+motion file as ``hf_mask_inds`` + the updated terrain, PARC/util/create_dataset.py:147-160) runs the character through the FK
+kernels, so it needs the GPU like the rest of the package; files that already carry ``hf_mask_inds`` are left alone.
 """
 from pathlib import Path
 from typing import List
@@ -28,11 +29,45 @@ def _motion_summary(path):
     return frames.shape[0] / fps, hf_shape, loss
 
 
+class _Preprocessor:
+    """Per-clip heightfield preprocessing (hf_mask / hf_maxmin / per-frame cell lists) written back into the motion file."""
+    Z_BUF, JUMP_BUF = 3.0, 0.8          # PARC/util/create_dataset.py:94-95
+
+    def __init__(self, char_filepath, device="cuda:0"):
+        from ..anim import kin_char_model
+        from . import geom_util
+        self._device = device
+        self._char = kin_char_model.KinCharModel(device)
+        self._char.load_char_file(char_filepath if char_filepath else kin_char_model.default_char_file())
+        self._points = geom_util.get_char_point_samples(self._char)
+
+    def run(self, path):
+        import pickle
+
+        import numpy as np
+        import torch
+
+        from . import terrain_util
+        d = safe_pickle.load_motion_file_safe(str(path))
+        if "hf_mask_inds" in d:
+            return False
+        t = d["terrain"]
+        ter = terrain_util.SubTerrain.from_arrays(t["hf"], np.asarray(t["min_point"], np.float32), np.asarray(t["dxdy"], np.float32),
+                                                  device=self._device)
+        frames = torch.tensor(np.asarray(d["frames"], np.float32), device=self._device)
+        inds = terrain_util.compute_hf_extra_vals(frames, ter, self._char, self._points, z_buf=self.Z_BUF, jump_buf=self.JUMP_BUF)
+        out = {k: v for k, v in d.items() if isinstance(v, (np.ndarray, int, float, str, bool))}
+        out["terrain"] = ter.numpy_copy()
+        out["hf_mask_inds"] = [i.cpu() for i in inds]
+        with open(str(path), "wb") as f:
+            pickle.dump(out, f)
+        return True
+
+
 def create_dataset_yaml(folder_paths: List[Path], save_path: Path, char_filepath: str = None, compute_preprocessing_data: bool = False,
                         cut_some_classes_in_half: bool = False, motion_classes_to_cut_in_half: List[str] = (),
                         max_terrain_dim_x: int = 45, max_terrain_dim_y: int = 45):
-    if compute_preprocessing_data:
-        raise NotImplementedError("compute_hf_extra_vals preprocessing feeds the diffusion model only (out of the tracker's scope)")
+    prep = _Preprocessor(char_filepath) if compute_preprocessing_data else None
     folder_paths = [Path(p) for p in folder_paths]
     motion_classes = []
     proportions = dict()
@@ -60,6 +95,8 @@ def create_dataset_yaml(folder_paths: List[Path], save_path: Path, char_filepath
                 continue                                  # "Large terrain excluded"
             if loss is not None and loss > 20.0:
                 continue                                  # bad generated motion
+            if prep is not None:
+                prep.run(fp)
             for c in motion_classes:
                 if ("/" + c + "/") in str(fp):
                     motions[c].append((fp, length))

@@ -210,3 +210,141 @@ def convert_heightfield_to_voxelized_trimesh(hf, min_x, min_y, dx=0.1, padding=N
 # procedural generators under the reference's names (util/terrain_util.py)
 from .terrain_procgen import (add_boxes_to_hf2, add_stairs_to_hf, draw_box, gen_paths_hf, linear_parkour_course,  # noqa: E402,F401
                               random_linear_parkour_course)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Terrain / body-geometry queries around the tracker ("next" rows): penetration distance of point
+# sets into a heightfield (HIP kernel parc_points_hf_sdf) and the per-clip heightfield preprocessing of the dataset
+# builder.  The character's pose comes from the same FK kernels the tracker uses (KinCharModel.dof_to_rot /
+# forward_kinematics); everything here is forward-only (no autograd graph is recorded through the kernels).
+# ---------------------------------------------------------------------------------------------------------------------
+def points_hf_sdf(points, hf, hf_min_box_center, hf_dxdy, base_z=-10.0, inverted=True, radius=None):
+    """Signed distance of points [B, N, 3] to heightfields hf [B, X, Y] made of dx x dy columns whose cell (0, 0) is centred at
+    hf_min_box_center [B, 2]; inverted (default) = negative depth below the surface for points in the ground.
+    Reference: util/terrain_util.py:1835-1893.  One launch, no [B, N, X*Y, 3] temporaries."""
+    from .. import _hip
+    assert points.dim() == 3 and hf.dim() == 3 and hf_min_box_center.dim() == 2 and hf_dxdy.dim() == 1
+    B, N = int(points.shape[0]), int(points.shape[1])
+    assert hf.shape[0] == B and hf_min_box_center.shape[0] == B
+    X, Y = int(hf.shape[1]), int(hf.shape[2])
+    dev = points.device
+    # cell-centre coordinates relative to cell (0, 0): torch's own linspace, evaluated on the host (X + Y values)
+    xs = torch.linspace(0.0, (X - 1.0) * hf_dxdy[0].item(), X).to(dev)
+    ys = torch.linspace(0.0, (Y - 1.0) * hf_dxdy[1].item(), Y).to(dev)
+    half = (hf_dxdy.to(torch.float32) / 2.0).cpu()
+    if radius is not None:
+        assert isinstance(radius, float) and radius > 0.0
+    out = torch.empty((B, N), dtype=torch.float32, device=dev)
+    pts = points.to(torch.float32).contiguous()
+    hfc = hf.to(torch.float32).contiguous()
+    mbc = hf_min_box_center.to(torch.float32).contiguous()
+    _hip.check(_hip.lib().parc_points_hf_sdf(_hip.stream(), B, N, X, Y, _hip.ptr(pts), _hip.ptr(hfc), _hip.ptr(mbc), _hip.ptr(xs), _hip.ptr(ys),
+                                             float(half[0]), float(half[1]), float(base_z), 1 if inverted else 0,
+                                             float(radius) if radius is not None else 0.0, _hip.ptr(out)), "parc_points_hf_sdf")
+    return out
+
+
+def _exp_map_to_quat(e):
+    """[..., 3] rotation vectors -> unit quaternions (x, y, z, w); angles below 1e-5 map to the identity
+    (torch_util.exp_map_to_quat of the reference, util/torch_util.py:394-419)."""
+    ang = torch.linalg.vector_norm(e, dim=-1)
+    axis = e / ang.unsqueeze(-1)
+    ang = torch.atan2(torch.sin(ang), torch.cos(ang))
+    big = ang.abs() > 1e-5
+    ang = torch.where(big, ang, torch.zeros_like(ang))
+    zaxis = torch.zeros_like(e)
+    zaxis[..., 2] = 1
+    axis = torch.where(big.unsqueeze(-1), axis, zaxis)
+    half = (ang / 2).unsqueeze(-1)
+    q = torch.cat([axis / torch.linalg.vector_norm(axis, dim=-1).clamp(min=1e-9).unsqueeze(-1) * half.sin(), half.cos()], dim=-1)
+    return q / torch.linalg.vector_norm(q, dim=-1).clamp(min=1e-9).unsqueeze(-1)
+
+
+def _quat_rotate(q, v):
+    qv, qw = q[..., :3], q[..., 3:]
+    t = 2 * torch.cross(qv.expand_as(v), v, dim=-1)
+    return v + qw * t + torch.cross(qv.expand_as(v), t, dim=-1)
+
+
+def _body_points_world(motion_frames, char_model, char_point_samples):
+    """frames [..., 34] -> (world positions [..., P, 3] of every sample point, owning body [P]); bodies in order, a body's
+    points in the order of its sample tensor."""
+    root_rot = _exp_map_to_quat(motion_frames[..., 3:6])
+    joint_rot = char_model.dof_to_rot(motion_frames[..., 6:])
+    body_pos, body_rot = char_model.forward_kinematics(motion_frames[..., 0:3], root_rot, joint_rot)
+    dev = motion_frames.device
+    owner = torch.cat([torch.full((p.shape[0],), b, dtype=torch.int64, device=dev) for b, p in enumerate(char_point_samples)])
+    local = torch.cat([p.to(dev) for p in char_point_samples], dim=0)
+    return _quat_rotate(body_rot[..., owner, :], local.expand(body_rot.shape[:-2] + local.shape)) + body_pos[..., owner, :], owner
+
+
+def motion_frames_hf_sdf_loss(motion_frames, char_point_samples, hf, hf_min_box_center, hf_dxdy, char_model, ret_vis_info=False,
+                              interior_distance=True):
+    """0.5 * sum over all body sample points and frames of the squared terrain penetration of motion_frames [B, T, 34] (frames in
+    the heightfields' coordinate frame).  Reference: util/terrain_util.py:1895-1951; point order of the returned arrays as there
+    (body-major: all frames of body 0's points, then body 1's, ...)."""
+    B, T = motion_frames.shape[0], motion_frames.shape[1]
+    world, owner = _body_points_world(motion_frames, char_model, char_point_samples)          # [B, T, P, 3]
+    blocks, start = [], 0
+    for p in char_point_samples:
+        n = p.shape[0]
+        blocks.append(world[:, :, start:start + n].reshape(B, T * n, 3))
+        start += n
+    pts = torch.cat(blocks, dim=1)
+    sdf = points_hf_sdf(pts, hf, hf_min_box_center, hf_dxdy, base_z=-10.0, inverted=interior_distance)
+    pen = sdf.clamp(max=0.0) if interior_distance else sdf.clamp(min=0.0)
+    loss = 0.5 * (pen * pen).sum(dim=-1)
+    return (loss, pts, sdf) if ret_vis_info else loss
+
+
+def compute_hf_mask_inds(motion_frames, terrain, char_model, char_body_points):
+    """For a clip [T, 34] on its terrain: per frame the (sorted, unique) grid cells under any body sample point, and per cell
+    the lowest sample-point height over the whole clip (99999.9999 where nothing passes).  Clears terrain.hf_mask like the
+    reference (util/terrain_util.py:1953-2000), whose per-frame / per-body / per-point Python loops become one FK launch, one
+    scatter-min and one sort."""
+    T = motion_frames.shape[0]
+    world, _ = _body_points_world(motion_frames, char_model, char_body_points)                 # [T, P, 3]
+    terrain.hf_mask[...] = False
+    g = terrain.get_grid_index(world[..., 0:2])                                                 # [T, P, 2]
+    Y = terrain.hf.shape[1]
+    flat = g[..., 0] * Y + g[..., 1]
+    lowest = torch.full((terrain.hf.numel(),), 99999.9999, dtype=terrain.hf.dtype, device=terrain.hf.device)
+    lowest.scatter_reduce_(0, flat.reshape(-1), world[..., 2].reshape(-1).to(lowest.dtype), reduce="amin", include_self=True)
+    # unique cells per frame: sort the (frame, cell) keys once, drop repeats, split by frame
+    keys = torch.unique(torch.arange(T, device=flat.device).unsqueeze(1) * terrain.hf.numel() + flat)
+    frame_of = torch.div(keys, terrain.hf.numel(), rounding_mode="floor")
+    cell = keys - frame_of * terrain.hf.numel()
+    ij = torch.stack([torch.div(cell, Y, rounding_mode="floor"), cell % Y], dim=-1)
+    counts = torch.bincount(frame_of, minlength=T).tolist()
+    return list(torch.split(ij, counts)), lowest.reshape(terrain.hf.shape)
+
+
+def compute_hf_mask_from_inds(terrain, mask_grid_inds):
+    mask = torch.zeros_like(terrain.hf_mask)
+    if len(mask_grid_inds) > 0:
+        ij = torch.cat(list(mask_grid_inds), dim=0)
+        mask[ij[:, 0], ij[:, 1]] = True
+    return mask
+
+
+def compute_hf_mask(motion_frames, terrain, char_model, char_body_points):
+    inds, _ = compute_hf_mask_inds(motion_frames, terrain, char_model, char_body_points)
+    return compute_hf_mask_from_inds(terrain, inds)
+
+
+def compute_hf_extra_vals(motion_frames, terrain, char_model, char_body_points, z_buf=3.0, jump_buf=0.8):
+    """Dataset preprocessing of one clip (util/terrain_util.py:2017-2052): hf_mask = cells the character passes over;
+    hf_maxmin = allowed height band per cell - pinned to the terrain under the character, [lowest terrain - z_buf, highest root +
+    z_buf] elsewhere, and capped at (lowest body point - jump_buf) where the character flies at least jump_buf above the ground.
+    Returns the per-frame cell lists; terrain is updated in place."""
+    inds, lowest = compute_hf_mask_inds(motion_frames, terrain, char_model, char_body_points)
+    terrain.hf_mask = compute_hf_mask_from_inds(terrain, inds)
+    top = torch.max(motion_frames[:, 2]).item() + z_buf
+    bottom = torch.min(terrain.hf).item() - z_buf
+    under = terrain.hf_mask
+    airborne = torch.logical_and(lowest - terrain.hf >= jump_buf, under)
+    hi = torch.where(under, terrain.hf, torch.full_like(terrain.hf, top))
+    lo = torch.where(under, terrain.hf, torch.full_like(terrain.hf, bottom))
+    terrain.hf_maxmin[..., 0] = torch.where(airborne, lowest - jump_buf, hi)
+    terrain.hf_maxmin[..., 1] = torch.where(airborne, torch.full_like(terrain.hf, bottom), lo)
+    return inds

@@ -560,7 +560,58 @@ def gen_procgen():
     save("g12_procgen", **out)
 
 
+def gen_terrain_geometry():
+    """G13: the terrain / body-geometry functions either side of the tracker, outputs of the reference's
+    util/geom_util.get_char_point_samples, util/terrain_util.points_hf_sdf (:1835), motion_frames_hf_sdf_loss (:1895),
+    compute_hf_extra_vals (:2017) and slice_terrain_around_motion (:1675).  trimesh is absent, so the character's sphere
+    geoms (which the reference samples through trimesh.creation.icosphere) are removed from the reference model's geom lists
+    before sampling: the point sets cover its capsules and boxes."""
+    rng = np.random.default_rng(13)
+    km = load_char()
+    for b in range(km.get_num_joints()):
+        km._geoms[b] = [g for g in km._geoms[b] if g._shape_type != kin_char_model.GeomType.SPHERE]
+    pts = geom_util.get_char_point_samples(km)
+    out = {"pts_count": np.array([p.shape[0] for p in pts]), "pts": torch.cat(pts, dim=0)}
+    out["box_pts"] = geom_util.get_box_point_surface_samples(t([0.0885, 0.045, 0.0275]), "cpu", num_slices=3, dim_x=4, dim_y=5)
+    out["capsule_pts"] = geom_util.get_capsule_point_surface_samples(0.31, 0.055, "cpu", num_cylinder_slices=5, num_circle_points=6)
+    # points_hf_sdf on random fields
+    B, N, X, Y = 3, 700, 9, 7
+    hf = (rng.integers(-3, 4, size=(B, X, Y)) * 0.35).astype(np.float32)
+    mbc = rng.uniform(-1, 1, size=(B, 2)).astype(np.float32)
+    dxdy = np.array([0.4, 0.3], np.float32)
+    p = np.concatenate([rng.uniform(-1.5, 4.5, size=(B, N, 1)), rng.uniform(-1.5, 3.0, size=(B, N, 1)), rng.uniform(-2.0, 2.0, size=(B, N, 1))],
+                       axis=-1).astype(np.float32)
+    out.update(sdf_points=p, sdf_hf=hf, sdf_mbc=mbc, sdf_dxdy=dxdy)
+    out["sdf_inverted"] = terrain_util.points_hf_sdf(t(p), t(hf), t(mbc), t(dxdy))
+    out["sdf_plain"] = terrain_util.points_hf_sdf(t(p), t(hf), t(mbc), t(dxdy), base_z=-5.0, inverted=False)
+    out["sdf_round"] = terrain_util.points_hf_sdf(t(p), t(hf), t(mbc), t(dxdy), inverted=False, radius=0.07)
+    # penetration loss of two clips' worth of frames on the civilization terrain (lowered into the ground to get hits)
+    civ = load_motion_file_safe(os.path.join(REF, "data/terrains/civilization.pkl"))
+    frames = np.asarray(civ["frames"], np.float32)
+    ter = ref_terrain_from_dict(civ["terrain"])
+    mf = np.stack([frames[0:24], frames[100:124]], axis=0).copy()
+    mf[1, :, 2] -= 0.25
+    mbc2 = np.stack([npy(ter.min_point)] * 2, axis=0)
+    hf2 = np.stack([npy(ter.hf)] * 2, axis=0)
+    loss, lp, lsdf = terrain_util.motion_frames_hf_sdf_loss(t(mf), pts, t(hf2), t(mbc2), ter.dxdy, km, ret_vis_info=True)
+    out.update(loss_frames=mf, loss=loss, loss_points=lp, loss_sdf=lsdf, civ_hf=npy(ter.hf), civ_min_point=npy(ter.min_point), civ_dxdy=npy(ter.dxdy))
+    # compute_hf_extra_vals on the first 60 frames (lifted over part of the clip so the jump branch fires)
+    clip = frames[0:60].copy()
+    clip[20:40, 2] += 1.0
+    inds = terrain_util.compute_hf_extra_vals(t(clip), ter, km, pts)
+    out.update(extra_frames=clip, extra_mask=ter.hf_mask, extra_maxmin=ter.hf_maxmin, extra_inds_count=np.array([i.shape[0] for i in inds]),
+               extra_inds=torch.cat(inds, dim=0))
+    # slice_terrain_around_motion
+    ter2 = ref_terrain_from_dict(civ["terrain"])
+    sl, lf = terrain_util.slice_terrain_around_motion(t(frames[30:90]), ter2, padding=1.0)
+    out.update(slice_frames_in=frames[30:90], slice_hf=sl.hf, slice_min_point=sl.min_point, slice_dims=np.array(sl.hf.shape), slice_frames_out=lf)
+    save("g13_terrain_geometry", **out)
+
+
 def main():
+    if "--only-terrain-geometry" in sys.argv:
+        gen_terrain_geometry()
+        return
     if "--only-procgen" in sys.argv:
         gen_procgen()
         return
@@ -586,6 +637,7 @@ def main():
     gen_voxel_mesh(np.random.default_rng(10))
     gen_dataset_yaml()
     gen_procgen()
+    gen_terrain_geometry()
 
 
 if __name__ == "__main__":

@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import golden
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
@@ -326,3 +328,25 @@ def test_return_tracker_kernel_matches_torch_rule():
     assert torch.allclose(a._return_buf, b._return_buf, rtol=1e-6, atol=1e-6)
     assert torch.allclose(a._mean_return, b._mean_return, rtol=2e-5) and torch.allclose(a.get_mean_ep_len(), b.get_mean_ep_len(), rtol=2e-5)
     assert abs(a.summary()["mean_return"] - b.summary()["mean_return"]) < 1e-4
+
+
+def test_create_dataset_preprocessing_writes_mask_inds(tmp_path):
+    """compute_preprocessing_data: every motion file gains hf_mask_inds (one cell list per frame) and the updated terrain, and a
+    second run leaves the files alone (PARC/util/create_dataset.py:147-160)."""
+    import pickle
+    from parc_amd.util import create_dataset, safe_pickle, terrain_util
+    g = golden("g13_terrain_geometry")
+    cls_dir = tmp_path / "data" / "running"
+    cls_dir.mkdir(parents=True)
+    ter = terrain_util.SubTerrain.from_arrays(g["civ_hf"], g["civ_min_point"], g["civ_dxdy"])
+    for k in range(2):
+        with open(cls_dir / "clip_{}.pkl".format(k), "wb") as f:
+            pickle.dump({"fps": 30, "loop_mode": "CLAMP", "frames": g["extra_frames"][10 * k:10 * k + 30], "terrain": ter.numpy_copy()}, f)
+    out = tmp_path / "dataset.yaml"
+    create_dataset.create_dataset_yaml([tmp_path / "data"], out, compute_preprocessing_data=True, max_terrain_dim_x=64, max_terrain_dim_y=64)
+    d = safe_pickle.load_motion_file_safe(str(cls_dir / "clip_0.pkl"))
+    assert len(d["hf_mask_inds"]) == 30 and d["frames"].shape == (30, 34)
+    assert np.asarray(d["terrain"]["hf_mask"]).sum() > 0
+    before = (cls_dir / "clip_0.pkl").read_bytes()
+    create_dataset.create_dataset_yaml([tmp_path / "data"], out, compute_preprocessing_data=True, max_terrain_dim_x=64, max_terrain_dim_y=64)
+    assert (cls_dir / "clip_0.pkl").read_bytes() == before

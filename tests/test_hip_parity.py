@@ -520,3 +520,54 @@ def test_normalize_and_action_head_match_torch_expressions():
     assert torch.allclose(a, na * a_std + a_mean, rtol=1e-6, atol=1e-6)
     assert torch.allclose(logp, lp, rtol=1e-5, atol=1e-4)
     assert torch.all(logp[mask == 0] == logp[mask == 0][0])            # mode actions: z = 0, log-prob is the normalising constant
+
+
+def test_g13_points_hf_sdf_kernel(oracle):
+    from parc_amd.util import terrain_util
+    g = golden("g13_terrain_geometry")
+    a = (T(g["sdf_points"]), T(g["sdf_hf"]), T(g["sdf_mbc"]), T(g["sdf_dxdy"]))
+    n = (g["sdf_points"], g["sdf_hf"], g["sdf_mbc"], g["sdf_dxdy"])
+    for kw, key in (({}, "sdf_inverted"), (dict(base_z=-5.0, inverted=False), "sdf_plain"), (dict(inverted=False, radius=0.07), "sdf_round")):
+        out = terrain_util.points_hf_sdf(*a, **kw)
+        close(out, g[key], atol=5e-7, rtol=0)                       # the reference's output (2 ulp: its 3-term norm)
+        close(out, oracle.points_hf_sdf(*n, **kw), atol=5e-7, rtol=0)
+    # ragged sizes: more cells than one LDS tile, point count not a multiple of the workgroup, one-cell and one-point fields
+    rng = np.random.default_rng(5)
+    for B, N, X, Y in ((2, 1, 1, 1), (1, 257, 50, 47), (3, 513, 3, 90)):
+        p = rng.uniform(-2, 6, size=(B, N, 3)).astype(np.float32)
+        hf = rng.uniform(-1, 1, size=(B, X, Y)).astype(np.float32)
+        mbc = rng.uniform(-1, 1, size=(B, 2)).astype(np.float32)
+        dxdy = np.array([0.4, 0.25], np.float32)
+        close(terrain_util.points_hf_sdf(T(p), T(hf), T(mbc), T(dxdy)), oracle.points_hf_sdf(p, hf, mbc, dxdy), atol=1e-6, rtol=0)
+    assert terrain_util.points_hf_sdf(torch.zeros((2, 0, 3), device=DEV), T(hf[:2]), T(mbc[:2]), T(dxdy)).shape == (2, 0)
+
+
+def _capsule_box_points(km):
+    from parc_amd.anim import kin_char_model as kcm
+    from parc_amd.util import geom_util
+    saved = [list(x) for x in km._geoms]
+    for b in range(km.get_num_joints()):
+        km._geoms[b] = [x for x in km._geoms[b] if x._shape_type != kcm.GeomType.SPHERE]
+    pts = geom_util.get_char_point_samples(km)
+    km._geoms = saved
+    return pts
+
+
+def test_g13_penetration_loss_and_hf_preprocessing(km):
+    from parc_amd.util import terrain_util
+    g = golden("g13_terrain_geometry")
+    pts = _capsule_box_points(km)
+    close(torch.cat(pts), g["pts"], atol=0, rtol=0)
+    hf2 = T(np.stack([g["civ_hf"]] * 2)); mbc2 = T(np.stack([g["civ_min_point"]] * 2))
+    loss, lp, lsdf = terrain_util.motion_frames_hf_sdf_loss(T(g["loss_frames"]), pts, hf2, mbc2, T(g["civ_dxdy"]), km, ret_vis_info=True)
+    close(lp, g["loss_points"], atol=5e-6, rtol=0)
+    close(lsdf, g["loss_sdf"], atol=1e-5, rtol=0)
+    close(loss, g["loss"], atol=1e-5, rtol=1e-4)
+    assert float(g["loss"][1]) > 10 * float(g["loss"][0]) > 0            # the lowered clip is the one that penetrates
+    # dataset preprocessing: index / mask work is exact
+    ter = terrain_util.SubTerrain.from_arrays(g["civ_hf"], g["civ_min_point"], g["civ_dxdy"], device=DEV)
+    inds = terrain_util.compute_hf_extra_vals(T(g["extra_frames"]), ter, km, pts)
+    assert [int(i.shape[0]) for i in inds] == g["extra_inds_count"].tolist()
+    assert np.array_equal(torch.cat(inds).cpu().numpy(), g["extra_inds"])
+    assert np.array_equal(ter.hf_mask.cpu().numpy(), g["extra_mask"])
+    close(ter.hf_maxmin, g["extra_maxmin"], atol=5e-6, rtol=0)

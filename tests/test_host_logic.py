@@ -265,3 +265,37 @@ def test_procgen_terrains_match_reference_under_seeds():
     assert set(np.unique(z["course_hf"]).tolist()) == {-1.0, 0.0, 1.0}
     np.testing.assert_array_equal(v, z["course_verts"])
     np.testing.assert_array_equal(tr, z["course_tris"])
+
+
+def test_char_point_samples_match_reference():
+    """G13: body sample points of the capsule / box geoms (util/geom_util.py:725-869), bit for bit; the sphere points come
+    from trimesh in the reference and are only checked for their construction (parity unpinned)."""
+    from parc_amd.anim import kin_char_model as kcm
+    from parc_amd.util import geom_util
+    g = golden("g13_terrain_geometry")
+    m = kcm.KinCharModel("cpu")
+    m.load_char_file(kcm.default_char_file())
+    full = geom_util.get_char_point_samples(m)
+    for b in range(m.get_num_joints()):
+        m._geoms[b] = [x for x in m._geoms[b] if x._shape_type != kcm.GeomType.SPHERE]
+    pts = geom_util.get_char_point_samples(m)
+    assert [p.shape[0] for p in pts] == g["pts_count"].tolist()
+    assert np.array_equal(torch.cat(pts).numpy(), g["pts"])
+    assert np.array_equal(geom_util.get_box_point_surface_samples(torch.tensor([0.0885, 0.045, 0.0275]), "cpu", num_slices=3, dim_x=4, dim_y=5).numpy(),
+                          g["box_pts"])
+    assert np.array_equal(geom_util.get_capsule_point_surface_samples(0.31, 0.055, "cpu", num_cylinder_slices=5, num_circle_points=6).numpy(),
+                          g["capsule_pts"])
+    sph = geom_util.get_sphere_point_surface_samples(0.09, "cpu")
+    assert sph.shape == (12, 3) and np.allclose(sph.norm(dim=-1).numpy(), 0.09, atol=1e-7)
+    # 6 sphere geoms of 12 points; pelvis, head and the two hands have nothing else (their placeholder point goes away)
+    assert sum(p.shape[0] for p in full) == sum(p.shape[0] for p in pts) - 4 + 12 * 6
+
+
+def test_slice_terrain_around_motion_matches_reference():
+    from parc_amd.util import terrain_util
+    g, civ = golden("g13_terrain_geometry"), golden("g5_hf_civ")
+    ter = terrain_util.SubTerrain.from_arrays(torch.tensor(g["civ_hf"]), torch.tensor(g["civ_min_point"]), torch.tensor(g["civ_dxdy"]))
+    sl, lf = terrain_util.slice_terrain_around_motion(g["slice_frames_in"], ter, padding=1.0)
+    assert list(sl.hf.shape) == g["slice_dims"].tolist()
+    assert np.array_equal(sl.hf.numpy(), g["slice_hf"]) and np.allclose(sl.min_point.numpy(), g["slice_min_point"], atol=1e-6)
+    assert np.allclose(lf, g["slice_frames_out"], atol=1e-6)

@@ -206,3 +206,21 @@ def test_td_lambda_brute_force_definition(oracle):
                 cl *= lam
             brute[t0, i] = new_val
     np.testing.assert_allclose(ret, brute, atol=1e-4)
+
+
+def test_g13_points_hf_sdf(oracle):
+    # box SDF of point sets to heightfield columns (terrain_util.points_hf_sdf); exact ops except the 3-term norm, whose
+    # summation inside torch's CPU kernel is not specified: 2 fp32 ulp of a ~1 m distance
+    g = golden("g13_terrain_geometry")
+    args = (g["sdf_points"], g["sdf_hf"], g["sdf_mbc"], g["sdf_dxdy"])
+    close(oracle.points_hf_sdf(*args), g["sdf_inverted"], atol=5e-7, rtol=0)
+    close(oracle.points_hf_sdf(*args, base_z=-5.0, inverted=False), g["sdf_plain"], atol=5e-7, rtol=0)
+    close(oracle.points_hf_sdf(*args, inverted=False, radius=0.07), g["sdf_round"], atol=5e-7, rtol=0)
+    # hand-checked cases on a 1 m block (cell 2,2 of a flat 0.4 m grid): a point inside the block is 0.2 m from the free air of the
+    # neighbouring columns (nearer than the 0.25 m to its top); points in the air get the distance to the nearest face of their
+    # own air column - the cell walls count, so it saturates at half a cell (0.2 m)
+    hf = np.zeros((1, 5, 5), np.float32)
+    hf[0, 2, 2] = 1.0
+    pts = np.array([[[0.8, 0.8, 0.75], [0.8, 0.8, 1.5], [0.0, 0.0, 0.3], [0.0, 0.0, 0.05]]], np.float32)
+    d = oracle.points_hf_sdf(pts, hf, np.zeros((1, 2), np.float32), np.array([0.4, 0.4], np.float32))
+    close(d[0], [-0.2, 0.2, 0.2, 0.05], atol=1e-6)
