@@ -137,7 +137,36 @@ def bench_post_step(n, iters):
                       "done_frac": (core.done != 0).float().mean().item()}))
 
 
+def bench_sdf():
+    """points_hf_sdf: B clips x N body sample points against X x Y columns (one box SDF per pair)."""
+    import json
+    from parc_amd.util import terrain_util
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(0)
+    for B, N, X, Y in ((32, 304 * 20, 31, 31), (64, 304 * 60, 45, 45)):
+        pts = (torch.rand((B, N, 3), generator=g) * 12.0).to(dev)
+        hf = torch.rand((B, X, Y), generator=g).to(dev)
+        mbc = torch.zeros((B, 2), device=dev)
+        dxdy = torch.tensor([0.4, 0.4], device=dev)
+        for _ in range(3):
+            terrain_util.points_hf_sdf(pts, hf, mbc, dxdy)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(20):
+            terrain_util.points_hf_sdf(pts, hf, mbc, dxdy)
+        e.record()
+        torch.cuda.synchronize()
+        us = s.elapsed_time(e) * 1e3 / 20
+        pairs = B * N * X * Y
+        print(json.dumps({"kernel": "points_hf_sdf_kernel", "batch": B, "points": N, "cells": X * Y, "us_per_call": us,
+                          "G_point_cell_pairs_per_s": pairs / us / 1e3}))
+
+
 if __name__ == "__main__":
+    if "--sdf" in sys.argv:
+        bench_sdf()
+        sys.exit(0)
     if "--post" in sys.argv:
         ns = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--envs=")] or [4096]
         for nn in ns:
