@@ -585,6 +585,24 @@ extern "C" int parc_forward_kinematics(void *stream, parc_char_model_t model, in
 #define POST_MAX_THREADS 512  // 64 * (2 + PARC_MAX_TAR_STEPS)
 #define POST_MAX_ROW 1408
 #ifndef POST_MIN_WAVES
+// Kernel arguments passed by value are loaded by the compiler in the entry block, all of them, and then live in scalar registers
+// for the whole kernel: with ~2 KB of argument structs that is far more than the 102 SGPRs a wave has, and the overflow is kept in
+// VGPR lanes (v_writelane at entry, v_readlane at every use - vector-issue slots).  kernarg_late hands out a pointer to a struct
+// inside the kernel-argument segment that the optimiser cannot see through, so loads through it stay where they are written.
+// Offsets = the by-value parameters of track_post_kernel in order, each 8-byte aligned (checked against the code object's
+// metadata by tools/check_kernarg_offsets.py).
+#define KARG_ALIGN8(x) (((x) + 7) & ~(size_t)7)
+#define KARG_OFF_ML KARG_ALIGN8(sizeof(parc_char_model_t))
+#define KARG_OFF_TER KARG_ALIGN8(KARG_OFF_ML + sizeof(parc_motion_lib_t))
+#define KARG_OFF_CFG KARG_ALIGN8(KARG_OFF_TER + sizeof(parc_terrain_t))
+#define KARG_OFF_BUF KARG_ALIGN8(KARG_OFF_CFG + sizeof(parc_track_cfg_t))
+template <typename T>
+PARC_DEV const __attribute__((address_space(4))) T *kernarg_late(size_t off) {
+    const __attribute__((address_space(4))) char *p = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const __attribute__((address_space(4))) T *)(p + off);
+}
+
 #define POST_MIN_WAVES 8   // 64 VGPRs: all 1024 workgroups of a 4096-env launch resident in one round (needs -fno-slp-vectorize: 5 spills; with SLP packing 22 spills and slower)
 #endif
 
@@ -820,6 +838,11 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     // its own copies of the two barriers: it requests the simulator outputs it needs, writes the reference state, meets the
     // other waves at B1, passes B2 at once, and finishes reward / termination while they gather the heightmap and copy out.
     if (is_ref) {
+      // the reference wave is the only user of most output pointers and of the reward / termination parameters: it reads them from the
+      // kernel-argument block HERE (see kernarg_late) instead of having them loaded at kernel entry and kept in - or spilled from -
+      // scalar registers by every wave
+      const auto &rbuf = *kernarg_late<parc_env_buffers_t>(KARG_OFF_BUF);
+      const auto &rcfg = *kernarg_late<parc_track_cfg_t>(KARG_OFF_CFG);
       const v3 r_pos = p_root;
       const q4 r_rot = r_root;
       const q4 rq = jq;
@@ -832,36 +855,36 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         r_avel = ld3(fq.row0 + ml.off_root_ang_vel);
         if ((what & PARC_POST_REF) && live) {
             if (b == 0) {
-                st3(buf.ref_root_pos + 3 * (size_t)e, r_pos);
-                st4(buf.ref_root_rot + 4 * (size_t)e, r_rot);
-                st3(buf.ref_root_vel + 3 * (size_t)e, r_vel);
-                st3(buf.ref_root_ang_vel + 3 * (size_t)e, r_avel);
+                st3(rbuf.ref_root_pos + 3 * (size_t)e, r_pos);
+                st4(rbuf.ref_root_rot + 4 * (size_t)e, r_rot);
+                st3(rbuf.ref_root_vel + 3 * (size_t)e, r_vel);
+                st3(rbuf.ref_root_ang_vel + 3 * (size_t)e, r_avel);
             } else if (valid) {
-                st4(buf.ref_joint_rot + ((size_t)e * J + (b - 1)) * 4, rq);
-                joint_rot_to_dof(m, b, rq, buf.ref_dof_pos + (size_t)e * D);      // K4
+                st4(rbuf.ref_joint_rot + ((size_t)e * J + (b - 1)) * 4, rq);
+                joint_rot_to_dof(m, b, rq, rbuf.ref_dof_pos + (size_t)e * D);      // K4
             }
             if (valid) {
-                buf.ref_contacts[(size_t)e * B + b] = r_contact;
-                st3(buf.ref_body_pos + ((size_t)e * B + b) * 3, pos);
+                rbuf.ref_contacts[(size_t)e * B + b] = r_contact;
+                st3(rbuf.ref_body_pos + ((size_t)e * B + b) * 3, pos);
             }
 #pragma unroll 1
-            for (int d = b; d < D; d += GRP) buf.ref_dof_vel[(size_t)e * D + d] = fq.row0[ml.off_dof_vel + d];
+            for (int d = b; d < D; d += GRP) rbuf.ref_dof_vel[(size_t)e * D + d] = fq.row0[ml.off_dof_vel + d];
             if (what & PARC_POST_INIT_CHAR) {
                 // RefCharEnv._char_state_init_from_ref + add_noise_to_char_state  mgdm_dm_util.py:119-136
-                float *wrs = const_cast<float *>(buf.root_state) + (size_t)e * 13;
-                float *wds = const_cast<float *>(buf.dof_state) + (size_t)e * D * 2;
+                float *wrs = const_cast<float *>(rbuf.root_state) + (size_t)e * 13;
+                float *wds = const_cast<float *>(rbuf.dof_state) + (size_t)e * D * 2;
                 if (b == 0) {
                     v3 ip = r_pos;
-                    if (buf.init_noise_xy) {
-                        ip.x += buf.init_noise_xy[2 * e];
-                        ip.y += buf.init_noise_xy[2 * e + 1];
+                    if (rbuf.init_noise_xy) {
+                        ip.x += rbuf.init_noise_xy[2 * e];
+                        ip.y += rbuf.init_noise_xy[2 * e + 1];
                     }
                     st3(wrs, ip);
                     st4(wrs + 3, r_rot);
                     st3(wrs + 7, r_vel);
                     st3(wrs + 10, r_avel);
                 } else if (valid) {
-                    joint_rot_to_dof(m, b, rq, buf.ref_dof_pos + (size_t)e * D, wds);
+                    joint_rot_to_dof(m, b, rq, rbuf.ref_dof_pos + (size_t)e * D, wds);
                 }
 #pragma unroll 1
                 for (int d = b; d < D; d += GRP) wds[2 * d + 1] = fq.row0[ml.off_dof_vel + d];
@@ -874,19 +897,19 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 // compute_deepmimic_reward  mgdm_dm_util.py:327-390 (track_root, track_root_h)
                 float pose_e = 0.f, vel_e = 0.f, key_e = 0.f, cpen = 0.f;
                 int pose_fail = 0, fall_contact = 0, fall_height = 0;
-                const v3 sim_pos = ld3(buf.rigid_body_state + ((size_t)e * B + (valid ? b : 0)) * 13);
+                const v3 sim_pos = ld3(rbuf.rigid_body_state + ((size_t)e * B + (valid ? b : 0)) * 13);
                 const v3 sim_root = shfl16(sim_pos, 0);          // body 0 is the root
-                const v3 sim_f = ld3(buf.contact_forces + ((size_t)e * B + (valid ? b : 0)) * 3);
+                const v3 sim_f = ld3(rbuf.contact_forces + ((size_t)e * B + (valid ? b : 0)) * 3);
                 if (valid && b > 0) {
                     const float4 cq = *reinterpret_cast<const float4 *>(cjq[le][b]);    // from the character wave (before B1)
                     q4 cj = mk4(cq.x, cq.y, cq.z, cq.w);
                     float da = quat_diff_angle(cj, rq);
-                    pose_e = cfg.joint_err_w[b - 1] * da * da;
+                    pose_e = rcfg.joint_err_w[b - 1] * da * da;
                 }
                 #pragma unroll 1
                 for (int d = b; d < D; d += GRP) {
                     float dv = fq.row0[ml.off_dof_vel + d] - dofs[2 * d + 1];
-                    vel_e += cfg.dof_err_w[d] * dv * dv;
+                    vel_e += rcfg.dof_err_w[d] * dv * dv;
                 }
                 if (key_slot >= 0) {
                     v3 df = (pos - r_pos) - (sim_pos - c_pos);
@@ -898,16 +921,16 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                     float fn = fminf(fsqrt(dot3(f, f)), 1.0f);
                     float cr = -(1.0f - r_contact) * fn;
                     cr += r_contact * fn;
-                    cpen = cfg.contact_w[b] * cr;
+                    cpen = rcfg.contact_w[b] * cr;
                     // compute_done  mgdm_dm_util.py:392-460
                     if (b > 0) {
                         v3 df = (pos - r_pos) - (sim_pos - sim_root);
-                        float lim = cfg.pose_termination_dist[b - 1];
+                        float lim = rcfg.pose_termination_dist[b - 1];
                         pose_fail = dot3(df, df) > lim * lim;
                     }
-                    if (cfg.num_contact_bodies > 0 && !cfg.contact_body_mask[b]) {
+                    if (rcfg.num_contact_bodies > 0 && !rcfg.contact_body_mask[b]) {
                         fall_contact = fabsf(f.x) > 0.1f || fabsf(f.y) > 0.1f || fabsf(f.z) > 0.1f;
-                        float th = hf_lookup(ter, sim_pos.x + buf.env_offsets[3 * e], sim_pos.y + buf.env_offsets[3 * e + 1]) + cfg.termination_height;
+                        float th = hf_lookup(ter, sim_pos.x + rbuf.env_offsets[3 * e], sim_pos.y + rbuf.env_offsets[3 * e + 1]) + rcfg.termination_height;
                         fall_height = sim_pos.z < th;
                     }
                 }
@@ -931,17 +954,17 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                     float key_r = fexp(-10.0f * key_e);
                     float cp = cpen / (float)B;
                     // ig_parkour_env.py:1317-1339,1404
-                    float dm = cfg.reward_w[0] * pose_r + cfg.reward_w[1] * vel_r + cfg.reward_w[2] * root_pose_r +
-                               cfg.reward_w[3] * root_vel_r + cfg.reward_w[4] * key_r;
+                    float dm = rcfg.reward_w[0] * pose_r + rcfg.reward_w[1] * vel_r + rcfg.reward_w[2] * root_pose_r +
+                               rcfg.reward_w[3] * root_vel_r + rcfg.reward_w[4] * key_r;
                     dm += cp;
-                    buf.reward[e] = cfg.rel_deepmimic_w * dm;
-                    const int N = buf.num_envs;
-                    buf.reward_terms[0 * (size_t)N + e] = pose_r;
-                    buf.reward_terms[1 * (size_t)N + e] = vel_r;
-                    buf.reward_terms[2 * (size_t)N + e] = root_pose_r;
-                    buf.reward_terms[3 * (size_t)N + e] = root_vel_r;
-                    buf.reward_terms[4 * (size_t)N + e] = key_r;
-                    buf.reward_terms[5 * (size_t)N + e] = cp;
+                    rbuf.reward[e] = rcfg.rel_deepmimic_w * dm;
+                    const int N = rbuf.num_envs;
+                    rbuf.reward_terms[0 * (size_t)N + e] = pose_r;
+                    rbuf.reward_terms[1 * (size_t)N + e] = vel_r;
+                    rbuf.reward_terms[2 * (size_t)N + e] = root_pose_r;
+                    rbuf.reward_terms[3 * (size_t)N + e] = root_vel_r;
+                    rbuf.reward_terms[4 * (size_t)N + e] = key_r;
+                    rbuf.reward_terms[5 * (size_t)N + e] = cp;
                     {
                         // task terms  ig_parkour_env.py:1346-1393 (logged; they scale the reward only if rel_task_w > 0)
                         float tx = tgt_xy[le][0] - c_pos.x, ty = tgt_xy[le][1] - c_pos.y;
@@ -959,25 +982,25 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                         float chd = hn2 > 0.f ? ha * hir : 1.0f, shd = hn2 > 0.f ? hb * hir : 0.0f;
                         float he = fmaxf(1.0f - (dxn * chd + dyn * shd), 0.f);
                         float task2 = min_vel_r * fexp(-(he * he));
-                        float task_r = cfg.task1_w * task_r1 + cfg.task2_w * task2;
-                        if (terr < cfg.target_radius * cfg.target_radius) task_r = 1.0f;
-                        buf.reward_terms[6 * (size_t)N + e] = task_r1;
-                        buf.reward_terms[7 * (size_t)N + e] = task2;
-                        buf.reward_terms[8 * (size_t)N + e] = task_r;
+                        float task_r = rcfg.task1_w * task_r1 + rcfg.task2_w * task2;
+                        if (terr < rcfg.target_radius * rcfg.target_radius) task_r = 1.0f;
+                        rbuf.reward_terms[6 * (size_t)N + e] = task_r1;
+                        rbuf.reward_terms[7 * (size_t)N + e] = task2;
+                        rbuf.reward_terms[8 * (size_t)N + e] = task_r;
                     }
                     // done
                     const float tm = qryd[0][le][7];
                     int done = PARC_DONE_NULL;
-                    if (tm >= cfg.episode_length) done = PARC_DONE_TIME;
-                    if (cfg.enable_early_termination) {
+                    if (tm >= rcfg.episode_length) done = PARC_DONE_TIME;
+                    if (rcfg.enable_early_termination) {
                         int failed = 0;
-                        if (cfg.num_contact_bodies > 0) failed = fall_contact && fall_height;
-                        if (cfg.pose_termination) {
+                        if (rcfg.num_contact_bodies > 0) failed = fall_contact && fall_height;
+                        if (rcfg.pose_termination) {
                             int pf = pose_fail;
-                            if (cfg.track_root) {
+                            if (rcfg.track_root) {
                                 v3 dr = sim_root - r_pos;
-                                pf |= dot3(dr, dr) > cfg.root_pos_termination_dist * cfg.root_pos_termination_dist;
-                                pf |= fabsf(rre) > cfg.root_rot_termination_angle;
+                                pf |= dot3(dr, dr) > rcfg.root_pos_termination_dist * rcfg.root_pos_termination_dist;
+                                pf |= fabsf(rre) > rcfg.root_rot_termination_angle;
                             }
                             failed |= pf;
                         }
@@ -989,8 +1012,8 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                     int kind = 0;
                     if (done != PARC_DONE_NULL || motion_end) kind = (done == PARC_DONE_FAIL) ? 1 : 2;
                     if (motion_end) done = PARC_DONE_FAIL;
-                    buf.done[e] = done;
-                    buf.done_kind[e] = kind;
+                    rbuf.done[e] = done;
+                    rbuf.done_kind[e] = kind;
                 }
             }
         }

@@ -299,3 +299,17 @@ def test_slice_terrain_around_motion_matches_reference():
     assert list(sl.hf.shape) == g["slice_dims"].tolist()
     assert np.array_equal(sl.hf.numpy(), g["slice_hf"]) and np.allclose(sl.min_point.numpy(), g["slice_min_point"], atol=1e-6)
     assert np.allclose(lf, g["slice_frames_out"], atol=1e-6)
+
+
+def test_kernarg_offsets_of_post_step_kernel_match_code_object():
+    """track_post_kernel reads argument structs directly from the kernel-argument segment (kernarg_late); the offsets it derives
+    from the struct sizes must be the ones the compiler laid the arguments out at (and the ctypes mirrors must have the C sizes)."""
+    import shutil
+    import sys
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        import pytest
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import check_kernarg_offsets as cko
+    meta = [(o, s) for o, s, k in cko.metadata_offsets() if k == "by_value"][:5]
+    assert meta == cko.expected_offsets()
