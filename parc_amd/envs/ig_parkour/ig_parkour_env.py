@@ -196,6 +196,29 @@ class IGParkourEnv(base_env.BaseEnv):
     def apply_hard_reset(self):
         return
 
+    # ``_episode_length`` is written by callers (dm_ppo_agent.record_motions of the reference sets it to 1000 s): the value the
+    # kernels see lives in the config struct, so the attribute writes through
+    @property
+    def _episode_length(self):
+        return self._episode_length_value
+
+    @_episode_length.setter
+    def _episode_length(self, val):
+        self._episode_length_value = val
+        cfg = getattr(self, "_cfg", None)
+        if cfg is not None:
+            cfg.struct.episode_length = float(val)
+
+    def host_step_signature(self):
+        """The host-side parameters a step / reset bakes into its kernel launches (a captured hipGraph of the step is only valid
+        while they keep these values; learning/dm_ppo_agent keys its graphs by this tuple)."""
+        dm = self._dm_env
+
+        def sig(v):
+            return ("tensor", v.data_ptr()) if torch.is_tensor(v) else v        # device-resident values are read by the graph itself
+        return (float(self._cfg.struct.episode_length), dm._rand_reset, dm._demo_mode, sig(dm._rand_root_pos_offset_scale),
+                sig(dm._motion_start_time_fraction), sig(dm._root_pos_offset), sig(dm._root_rot_offset))
+
     def set_rand_reset(self, val=None):
         val = (not self._dm_env._rand_reset) if val is None else val
         self._dm_env._rand_reset = val

@@ -326,7 +326,8 @@ class DMPPOAgent(torch.nn.Module):
         experience buffer is the device scalar ``_head_t``."""
         eb = self._exp_buffer
         exp_prob = self._get_exp_prob()
-        key = (self._need_normalizer_update(), exp_prob >= 1.0, device_reset)
+        sig = self._env.host_step_signature() if hasattr(self._env, "host_step_signature") else ()
+        key = (self._need_normalizer_update(), exp_prob >= 1.0, device_reset) + tuple(sig)
         self._head_t.fill_(eb._buffer_head)
         g = self._graphs.get(key)
         if g is None:
@@ -654,7 +655,6 @@ class DMPPOAgent(torch.nn.Module):
         env.set_demo_mode(True)
         env.set_rand_root_pos_offset_scale(0.0)
         env._episode_length = 1000.0
-        env._cfg.struct.episode_length = 1000.0
         N = self.get_num_envs()
 
         def helper(prev_successful=None):

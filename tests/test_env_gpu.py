@@ -350,3 +350,21 @@ def test_create_dataset_preprocessing_writes_mask_inds(tmp_path):
     before = (cls_dir / "clip_0.pkl").read_bytes()
     create_dataset.create_dataset_yaml([tmp_path / "data"], out, compute_preprocessing_data=True, max_terrain_dim_x=64, max_terrain_dim_y=64)
     assert (cls_dir / "clip_0.pkl").read_bytes() == before
+
+
+def test_episode_length_attribute_reaches_the_kernels_and_rekeys_graphs():
+    """env._episode_length is written by callers (record_motions): the kernels' config follows, and the agent's captured rollout
+    graphs are keyed by the host-side step parameters so a stale graph is never replayed."""
+    from parc_amd import workloads
+    from parc_amd.envs.base_env import DoneFlags
+    torch.manual_seed(0)
+    e, _, _ = workloads.build_env("boxes_64clips", 64, DEV, seed=0)
+    sig0 = e.host_step_signature()
+    e.reset()
+    e._episode_length = 0.01
+    assert abs(e._cfg.struct.episode_length - 0.01) < 1e-9 and e.host_step_signature() != sig0
+    a = torch.zeros((64, 28), device=DEV)
+    _, _, done, _ = e.step(a)
+    assert bool((done != DoneFlags.NULL.value).all())             # 1/30 s of env time is already past the limit
+    e.set_rand_reset(False)
+    assert e.host_step_signature()[1] is False
