@@ -267,6 +267,12 @@ int parc_return_tracker_update(void *stream, int n_envs, int K, const float *rew
  * x, out [rows, dim] row-major, mean / std [dim]; dim a multiple of 4, 16-byte aligned pointers; out may alias x. */
 int parc_normalize_clamp(void *stream, int64_t rows, int dim, const float *x, const float *mean, const float *stdv, float clip, float *out);
 
+/* ---- K22: Normalizer.record  learning/normalizer.py:28-34: acc[0,:] += sum over rows of x, acc[1,:] += sum over rows of x*x
+ * in one pass with a fixed summation order.  x [rows, dim] row-major, acc [2, dim], dim a multiple of 4, 16-byte aligned;
+ * workspace: parc_moments_workspace_floats(rows, dim) floats of scratch (caller-owned). */
+int64_t parc_moments_workspace_floats(int64_t rows, int dim);
+int parc_moments_accumulate(void *stream, int64_t rows, int dim, const float *x, float *acc, float *workspace);
+
 /* ---- K14: the part of PPOAgent._decide_action (learning/ppo_agent.py:87-119) after the actor MLP: sample / mode by the
  * exploration mask, log-probability, un-normalised action.  mean, noise, action [n, A]; logstd, a_mean, a_std [A]; explore,
  * logp [n]. */

@@ -311,6 +311,70 @@ extern "C" int parc_normalize_clamp(void *stream, int64_t rows, int dim, const f
 }
 
 // =============================================================================================
+// K22 running-moment statistics: Normalizer.record (learning/normalizer.py:28-34)  acc[0] += sum_rows x, acc[1] += sum_rows x^2.
+// torch: two column reductions + a square + two adds (and their temporaries) per call; here one pass over x.  Stage 1: a
+// workgroup owns MOM_ROWS rows x 256 columns (64 float4 lanes x 4 row groups), sums in registers, folds the row groups through
+// LDS and writes one partial row; stage 2 adds the partial rows of a column in chunk order into acc.  Fixed summation order:
+// the result does not depend on scheduling.
+// =============================================================================================
+#define MOM_ROWS 64
+__global__ __launch_bounds__(256) void moments_partial_kernel(int rows, int dim4, const float4 *__restrict__ x, float4 *__restrict__ partial) {
+    __shared__ float4 red[2][4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * MOM_ROWS, r1 = min(r0 + MOM_ROWS, rows);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (c < dim4) {
+        for (int r = r0 + rg; r < r1; r += 4) {
+            const float4 v = x[(size_t)r * dim4 + c];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+        }
+    }
+    red[0][rg][lane] = s;
+    red[1][rg][lane] = q;
+    __syncthreads();
+    if (rg < 2 && c < dim4) {       // wave 0 folds the sums, wave 1 the sums of squares
+        const float4 a = red[rg][0][lane], b = red[rg][1][lane], d = red[rg][2][lane], e = red[rg][3][lane];
+        float4 o;
+        o.x = (a.x + b.x) + (d.x + e.x); o.y = (a.y + b.y) + (d.y + e.y); o.z = (a.z + b.z) + (d.z + e.z); o.w = (a.w + b.w) + (d.w + e.w);
+        partial[((size_t)blockIdx.y * 2 + rg) * dim4 + c] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void moments_final_kernel(int chunks, int dim4, const float4 *__restrict__ partial, float4 *acc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over [2, dim4]
+    if (i >= 2 * dim4) return;
+    const int which = i / dim4, c = i - which * dim4;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < chunks; ++k) {
+        const float4 v = partial[((size_t)k * 2 + which) * dim4 + c];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    float4 a = acc[i];
+    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    acc[i] = a;
+}
+
+extern "C" int64_t parc_moments_workspace_floats(int64_t rows, int dim) {
+    if (rows < 0 || dim <= 0) return -1;
+    return ((rows + MOM_ROWS - 1) / MOM_ROWS) * 2 * (int64_t)dim;
+}
+
+extern "C" int parc_moments_accumulate(void *stream, int64_t rows, int dim, const float *x, float *acc, float *workspace) {
+    if (rows < 0 || dim <= 0 || (dim & 3) || (((uintptr_t)x | (uintptr_t)acc | (uintptr_t)workspace) & 15)) return PARC_EINVAL;
+    if (rows == 0) return PARC_OK;
+    if (rows > (int64_t)MOM_ROWS * 65535) return PARC_EUNSUPPORTED;
+    const int dim4 = dim / 4, chunks = (int)((rows + MOM_ROWS - 1) / MOM_ROWS);
+    hipLaunchKernelGGL(moments_partial_kernel, dim3((dim4 + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, (int)rows, dim4, (const float4 *)x,
+                       (float4 *)workspace);
+    hipLaunchKernelGGL(moments_final_kernel, dim3((2 * dim4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, chunks, dim4,
+                       (const float4 *)workspace, (float4 *)acc);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}
+
+// =============================================================================================
 // K14 action head of the rollout: PPOAgent._decide_action (learning/ppo_agent.py:87-119) after the actor MLP.
 // norm_a = mean + std * noise where the env explores (mask 1), the mode otherwise; a_logp = log N(norm_a; mean, std);
 // action = a_mean + a_std * norm_a (Normalizer.unnormalize).  One thread per env.

@@ -43,6 +43,7 @@ class IGParkourEnv(base_env.BaseEnv):
         self._num_envs = num_envs
         self._device = device
         self._episode_length = env_config["episode_length"]
+        self._info_snapshots = True
         self._env_spacing = env_config.get("env_spacing", 5)
         self._global_obs = env_config["global_obs"]
         self._fraction_dm_envs = env_config["fraction_dm_envs"]
@@ -351,13 +352,16 @@ class IGParkourEnv(base_env.BaseEnv):
 
     def _update_info(self, step=False):
         info = self._info
-        info["timestep"] = self._timestep_buf.clone()
-        info["ep_num"] = self._ep_num_buf.clone()
+        # snapshots, as the reference hands out (ig_parkour_env.py:1428,1543-1547) - except inside a captured rollout step, whose only
+        # consumer (the agent's record / return-tracker kernels) reads the entries before anything overwrites the buffers
+        snap = (lambda t: t.clone()) if self._info_snapshots else (lambda t: t)
+        info["timestep"] = snap(self._timestep_buf)
+        info["ep_num"] = snap(self._ep_num_buf)
         info["compute_time"] = time.time() - self._start_compute_time
-        info["char_contact_forces"] = self._char_contact_forces.clone()
+        info["char_contact_forces"] = snap(self._char_contact_forces)
         if step:
             r = dict(self._reward_term_views)
-            r["total_r"] = self._reward_buf.clone()        # snapshots, as the reference hands out (ig_parkour_env.py:1428,1543-1547)
+            r["total_r"] = snap(self._reward_buf)
             info["rewards"] = r
             info["rewards_all"] = (self._reward_all_names, self._core.reward_all)     # same data as one [10, N] block
             if self._report_tracking_error:

@@ -336,6 +336,9 @@ class DMPPOAgent(torch.nn.Module):
                 return self._train_step_body(device_reset)
             eb.set_device_head(self._head_t)
             self._in_graph_step = True
+            snapshots = getattr(self._env, "_info_snapshots", None)
+            if snapshots is not None:
+                self._env._info_snapshots = False
             count0 = self._obs_norm._new_count
             captured = False
             try:
@@ -354,6 +357,8 @@ class DMPPOAgent(torch.nn.Module):
             finally:
                 eb.set_device_head(None)
                 self._in_graph_step = False
+                if snapshots is not None:
+                    self._env._info_snapshots = snapshots
             self._obs_norm._new_count = count0       # capture enqueues nothing; the replay below is this step
             if not captured:
                 torch.cuda.synchronize()

@@ -25,6 +25,7 @@ class Normalizer(torch.nn.Module):
         # reductions into adjacent rows and update() exchanges it between ranks in ONE all-reduce together with the count)
         self._new_count = 0
         self._acc = torch.zeros((2,) + tuple(self._mean.shape), device=device, dtype=dtype)
+        self._scratch = None
 
     @property
     def _new_sum(self):
@@ -39,6 +40,17 @@ class Normalizer(torch.nn.Module):
         assert lead > 0
         rows = x.reshape((-1,) + tuple(self._mean.shape))
         self._new_count += rows.shape[0]           # (host-side int: the graph rollout accounts for it itself)
+        if (rows.is_cuda and rows.dtype == torch.float32 and self.dtype == torch.float32 and rows.is_contiguous() and self._mean.dim() == 1
+                and self._mean.shape[0] % 4 == 0 and rows.data_ptr() % 16 == 0):
+            # one pass, fixed summation order (parc_moments_accumulate)
+            from .. import _hip
+            L = _hip.lib()
+            need = int(L.parc_moments_workspace_floats(rows.shape[0], rows.shape[1]))
+            if self._scratch is None or self._scratch.numel() < need:
+                self._scratch = torch.empty(need, dtype=torch.float32, device=rows.device)
+            _hip.check(L.parc_moments_accumulate(_hip.stream(), rows.shape[0], rows.shape[1], _hip.ptr(rows), _hip.ptr(self._acc),
+                                                 _hip.ptr(self._scratch)), "parc_moments_accumulate")
+            return
         self._acc[0] += rows.sum(dim=0)
         self._acc[1] += (rows * rows).sum(dim=0)
 

@@ -571,3 +571,22 @@ def test_g13_penetration_loss_and_hf_preprocessing(km):
     assert np.array_equal(torch.cat(inds).cpu().numpy(), g["extra_inds"])
     assert np.array_equal(ter.hf_mask.cpu().numpy(), g["extra_mask"])
     close(ter.hf_maxmin, g["extra_maxmin"], atol=5e-6, rtol=0)
+
+
+def test_moments_kernel_matches_column_sums():
+    """K22 (Normalizer.record): sum x and sum x^2 per column in one pass; fp32 with a fixed order, compared with float64 sums."""
+    from parc_amd.learning.normalizer import Normalizer
+    torch.manual_seed(3)
+    for rows, dim in ((4096, 1312), (61, 28), (1, 4), (200, 1312)):
+        x = torch.randn((rows, dim), device=DEV) * 3.0 + 0.5
+        nz = Normalizer((dim,), DEV, clip=10.0)
+        nz.record(x)
+        nz.record(x[: max(rows // 2, 1)].contiguous())
+        x2 = torch.cat([x, x[: max(rows // 2, 1)]]).double()
+        close(nz._new_sum, x2.sum(0).cpu().numpy(), atol=1e-3, rtol=2e-6)
+        close(nz._new_sum_sq, (x2 * x2).sum(0).cpu().numpy(), atol=1e-3, rtol=2e-6)
+        assert nz._new_count == rows + max(rows // 2, 1)
+        # and the update that follows reproduces the moments
+        nz.update()
+        close(nz._mean, x2.mean(0).cpu().numpy(), atol=1e-5, rtol=1e-5)
+        close(nz._std, x2.std(0, unbiased=False).clamp_min(1e-4).cpu().numpy(), atol=1e-4, rtol=1e-4)
