@@ -1136,43 +1136,60 @@ extern "C" int parc_reset_apply(void *stream, int n_envs, const int32_t *mask, c
 }
 
 // =============================================================================================
-// Fail-rate EMA: one thread per clip walks the envs in order (dm_env.py:758-772)
+// Fail-rate EMA (dm_env.py:758-772): for every env that finished this step, in env order,
+//     fail_rate[clip] = (1 - w) fail_rate[clip] + w [episode failed]
+// One 256-thread workgroup per clip.  Pass i reads the done flags of envs 256 i .. 256 i + 255 coalesced; a wave-wide ballot
+// turns "finished on this clip" / "and failed" into two 64-bit masks per (pass, wave), parked in LDS.  Thread 0 then walks the
+// set bits in env order and applies the updates one by one - the same fp32 operations in the same order as the reference's
+// loop over done envs, so the result is bit-identical to it.  Clips nobody finished on (almost all of them, every step) cost
+// the flag reads and nothing else.
 // =============================================================================================
-// One wave per clip.  The EMA update x -> (1-w) x + (failed ? w : 0) is an affine map; lane l composes the maps of its
-// contiguous chunk of envs in env order, then the 64 chunk maps are composed in lane order: the result equals the
-// reference's sequential loop over done envs (dm_env.py:758-772) up to fp32 reassociation.
-__global__ __launch_bounds__(64) void fail_rate_kernel(int n_envs, int n_motions, const int64_t *__restrict__ motion_ids,
-                                                       const int32_t *__restrict__ done_kind, float ema_w, float *fail_rates) {
+#define FR_THREADS 256
+#define FR_MAX_PASSES 64          // up to 16384 envs per launch segment; larger counts loop over segments
+__global__ __launch_bounds__(FR_THREADS) void fail_rate_kernel(int n_envs, int n_motions, const int64_t *__restrict__ motion_ids,
+                                                               const int32_t *__restrict__ done_kind, float ema_w, float *fail_rates) {
+    __shared__ unsigned long long hit[FR_MAX_PASSES][FR_THREADS / 64], fail[FR_MAX_PASSES][FR_THREADS / 64];
     const int mi = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int chunk = (n_envs + 63) / 64;
-    const int e0 = lane * chunk, e1 = min(e0 + chunk, n_envs);
-    float A = 1.f, Bc = 0.f;
-    const float keep = 1.0f - ema_w;
-    for (int e = e0; e < e1; ++e) {
-        int k = done_kind[e];
-        if (k != 0 && motion_ids[e] == mi) {
-            A *= keep;
-            Bc = Bc * keep + (k == 1 ? ema_w : 0.f);
-        }
-    }
-    // ordered composition over lanes: f_total = f_63 o ... o f_0
-    float fr = fail_rates[mi];
+    const int wv = threadIdx.x >> 6;
+    const float keep = (float)(1.0 - (double)ema_w);       // the reference multiplies by the python double (1.0 - w), cast to fp32
+    float fr = 0.f;
     bool touched = false;
-    for (int l = 0; l < 64; ++l) {
-        float a = __shfl(A, l, 64), b = __shfl(Bc, l, 64);
-        if (a != 1.f || b != 0.f) {
-            fr = a * fr + b;
-            touched = true;
+    if (threadIdx.x == 0) fr = fail_rates[mi];
+    for (int seg = 0; seg < n_envs; seg += FR_MAX_PASSES * FR_THREADS) {
+        const int passes = min(FR_MAX_PASSES, (n_envs - seg + FR_THREADS - 1) / FR_THREADS);
+        for (int i = 0; i < passes; ++i) {
+            const int e = seg + i * FR_THREADS + threadIdx.x;
+            const int k = e < n_envs ? done_kind[e] : 0;
+            const bool h = k != 0 && motion_ids[e] == mi;
+            const unsigned long long hm = __ballot(h), fm = __ballot(h && k == 1);
+            if ((threadIdx.x & 63) == 0) {
+                hit[i][wv] = hm;
+                fail[i][wv] = fm;
+            }
         }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < passes; ++i)
+                for (int w = 0; w < FR_THREADS / 64; ++w) {
+                    unsigned long long hm = hit[i][w];
+                    const unsigned long long fm = fail[i][w];
+                    while (hm) {
+                        const int bit = __ffsll((long long)hm) - 1;
+                        hm &= hm - 1;
+                        fr = mul_add_unfused(fr, keep, ((fm >> bit) & 1ull) ? ema_w : 0.f);     // two roundings, like fr * keep + w in torch
+                        touched = true;
+                    }
+                }
+        }
+        __syncthreads();
     }
-    if (lane == 0 && touched) fail_rates[mi] = fr;
+    if (threadIdx.x == 0 && touched) fail_rates[mi] = fr;
 }
 
 extern "C" int parc_update_fail_rates(void *stream, int n_envs, int n_motions, const int64_t *motion_ids, const int32_t *done_kind,
                                       float ema_w, float *fail_rates) {
     if (n_envs < 0 || n_motions <= 0) return PARC_EINVAL;
-    hipLaunchKernelGGL(fail_rate_kernel, dim3(n_motions), dim3(64), 0, (hipStream_t)stream, n_envs, n_motions, motion_ids, done_kind,
+    hipLaunchKernelGGL(fail_rate_kernel, dim3(n_motions), dim3(FR_THREADS), 0, (hipStream_t)stream, n_envs, n_motions, motion_ids, done_kind,
                        ema_w, fail_rates);
     PARC_CHECK_LAUNCH();
     return PARC_OK;

@@ -220,6 +220,13 @@ PARC_DEV float one_minus_sq_unfused(float c) {
     return 1.0f - cc;
 }
 
+// a * b + c with the product rounded before the sum (two roundings, the way torch evaluates `x * k + c` on tensors)
+PARC_DEV float mul_add_unfused(float a, float b, float c) {
+#pragma clang fp contract(off)
+    float p = a * b;
+    return p + c;
+}
+
 // util/torch_util.py:443-468
 PARC_DEV q4 slerp(q4 q0, q4 q1, float t) {
     float c = dot4_unfused(q0, q1);

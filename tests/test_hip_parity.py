@@ -590,3 +590,26 @@ def test_moments_kernel_matches_column_sums():
         nz.update()
         close(nz._mean, x2.mean(0).cpu().numpy(), atol=1e-5, rtol=1e-5)
         close(nz._std, x2.std(0, unbiased=False).clamp_min(1e-4).cpu().numpy(), atol=1e-4, rtol=1e-4)
+
+
+def test_fail_rate_kernel_is_the_sequential_loop_bit_for_bit():
+    """dm_env.py:758-772: per finished env, in env order, fr[clip] = fr[clip] * (1 - w) (+ w if it failed).  The kernel walks the
+    ballot masks in env order with the same two roundings, so it equals the loop exactly - also with many finishers per clip,
+    env counts that are not multiples of the workgroup and more than one 16384-env segment."""
+    from parc_amd import _hip
+    rng = np.random.default_rng(11)
+    for n, M, p_done in ((4096, 64, 0.02), (8192, 7, 0.5), (61, 3, 1.0), (20000, 5, 0.3)):
+        mids = rng.integers(0, M, size=n)
+        kind = np.where(rng.random(n) < p_done, rng.integers(1, 3, size=n), 0).astype(np.int32)
+        fr0 = rng.random(M).astype(np.float32)
+        w = np.float32(0.01)
+        keep = np.float32(1.0 - 0.01)
+        exp = fr0.copy()
+        for e in range(n):
+            if kind[e] != 0:
+                v = np.float32(exp[mids[e]] * keep)
+                exp[mids[e]] = np.float32(v + w) if kind[e] == 1 else v
+        fr, d_mids, d_kind = T(fr0), T(mids, torch.int64), T(kind, torch.int32)
+        _hip.check(_hip.lib().parc_update_fail_rates(_hip.stream(), n, M, _hip.ptr(d_mids), _hip.ptr(d_kind), 0.01, _hip.ptr(fr)),
+                   "parc_update_fail_rates")
+        assert np.array_equal(fr.cpu().numpy(), exp)
