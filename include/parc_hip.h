@@ -214,6 +214,18 @@ int parc_reset_apply(void *stream, int n_envs, const int32_t *mask, const int64_
                      int64_t *motion_terrain_ids, float *motion_time_offsets, float *motion_xy_offset, int32_t *timestep_buf,
                      float *time_buf, int32_t *done, float *next_target_time, int64_t *ep_num);
 
+/* The same reset with the sampling inside (DeepMimicEnv._reset_ref_motion dm_env.py:517-568, MotionLib.sample_motions /
+ * sample_time anim/motion_lib.py:48-63, add_noise_to_char_state mgdm_dm_util.py:128-136): envs with done_flags[e] != 0 restart;
+ * mask[e] (out) = that condition.  uniforms [5, n_envs] in [0,1): row 0 picks the clip (probability ~ motion_weights[m] *
+ * max(fail_rates[m], min_weight); fail_rates NULL = weights alone), row 1 the tile copy, row 2 the start phase (time = u * clip
+ * length), rows 3-4 the xy start noise (2u-1) * noise_scale written to init_noise_xy.  cdf_workspace: n_motions floats. */
+int parc_reset_sample_apply(void *stream, int n_envs, const int32_t *done_flags, int32_t *mask, const float *uniforms, int n_motions,
+                            const float *motion_weights, const float *fail_rates, float min_weight, const float *motion_lengths,
+                            const float *motion_offsets, int terrains_per_motion, float noise_scale, float *cdf_workspace,
+                            int64_t *motion_ids, int64_t *motion_terrain_ids, float *motion_time_offsets, float *motion_xy_offset,
+                            int32_t *timestep_buf, float *time_buf, int32_t *done, float *next_target_time, int64_t *ep_num,
+                            float *init_noise_xy);
+
 /* DeepMimicEnv.update_done's per-done-env Python loop (dm_env.py:758-772): EMA of per-clip failure rates,
  * applied in increasing env order exactly as the reference's loop does. */
 int parc_update_fail_rates(void *stream, int n_envs, int n_motions, const int64_t *motion_ids, const int32_t *done_kind,

@@ -171,6 +171,8 @@ def _declare(L):
     L.parc_record_step.restype = c_int
     L.parc_reset_apply.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int] + [c_vp] * 9
     L.parc_reset_apply.restype = c_int
+    L.parc_reset_sample_apply.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_f, c_vp, c_vp, c_int, c_f] + [c_vp] * 11
+    L.parc_reset_sample_apply.restype = c_int
     for name in ("parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
                  "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step", "parc_reset_apply",
                  "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize"):
@@ -183,7 +185,7 @@ def _declare(L):
 EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
             "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step",
             "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize", "parc_reset_apply", "parc_ppo_loss", "parc_ppo_workspace_floats", "parc_record_step", "parc_return_tracker_update", "parc_normalize_clamp",
-            "parc_action_head", "parc_points_hf_sdf", "parc_moments_workspace_floats", "parc_moments_accumulate"]
+            "parc_action_head", "parc_points_hf_sdf", "parc_moments_workspace_floats", "parc_moments_accumulate", "parc_reset_sample_apply"]
 
 
 def check(rc, what):

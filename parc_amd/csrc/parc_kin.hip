@@ -1136,6 +1136,89 @@ extern "C" int parc_reset_apply(void *stream, int n_envs, const int32_t *mask, c
 }
 
 // =============================================================================================
+// Device-side reset, sampling included (dm_env.py:517-568 + MotionLib.sample_motions / sample_time  anim/motion_lib.py:48-63):
+// which envs restart (done != NULL), on which clip (probability ~ weight * max(fail rate, floor)), on which tile copy of the
+// clip's terrain (uniform), from which phase (uniform in [0, clip length)), with which xy start noise (uniform in +-scale) -
+// all from five uniforms per env that the caller drew in one launch.  Kernel 1 (one workgroup) builds the cumulative weights,
+// kernel 2 (one thread per env) inverts them by bisection and does the bookkeeping of reset_apply_kernel.
+// =============================================================================================
+__global__ __launch_bounds__(256) void reset_cdf_kernel(int M, const float *__restrict__ weights, const float *__restrict__ fail_rates, float min_w,
+                                                        float *cdf) {
+    __shared__ float part[256];
+    const int chunk = (M + 255) / 256;
+    const int i0 = min((int)threadIdx.x * chunk, M), i1 = min(i0 + chunk, M);
+    float s = 0.f;
+    for (int i = i0; i < i1; ++i) s += (fail_rates ? fmaxf(fail_rates[i], min_w) : 1.0f) * weights[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float run = 0.f;
+        for (int t = 0; t < 256; ++t) {
+            const float v = part[t];
+            part[t] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    float run = part[threadIdx.x];
+    for (int i = i0; i < i1; ++i) {
+        run += (fail_rates ? fmaxf(fail_rates[i], min_w) : 1.0f) * weights[i];
+        cdf[i] = run;
+    }
+}
+
+__global__ __launch_bounds__(256) void reset_sample_apply_kernel(int n, const int32_t *__restrict__ done_in, int32_t *mask, const float *__restrict__ u,
+                                                                 int M, const float *__restrict__ cdf, const float *__restrict__ lengths,
+                                                                 const float *__restrict__ offs, int R, float noise_scale, int64_t *mid, int64_t *tid,
+                                                                 float *toff, float *xyoff, int32_t *timestep, float *time_buf, int32_t *done,
+                                                                 float *next_target_time, int64_t *ep_num, float *init_noise_xy) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int finished = done_in[e] != PARC_DONE_NULL;
+    mask[e] = finished;
+    if (!finished) return;
+    // clip: first index whose cumulative weight exceeds u * total (searchsorted(..., right=True)), kept inside the table
+    const float x = u[e] * cdf[M - 1];
+    int lo = 0, hi = M;
+    while (lo < hi) {
+        const int m = (lo + hi) >> 1;
+        if (cdf[m] > x) hi = m; else lo = m + 1;
+    }
+    const int64_t mi = min(lo, M - 1);
+    const int64_t ti = min((int)(u[n + e] * (float)R), R - 1);
+    mid[e] = mi;
+    tid[e] = ti;
+    toff[e] = u[2 * n + e] * lengths[mi];
+    xyoff[2 * e] = offs[(mi * R + ti) * 2];
+    xyoff[2 * e + 1] = offs[(mi * R + ti) * 2 + 1];
+    init_noise_xy[2 * e] = (2.0f * u[3 * n + e] - 1.0f) * noise_scale;
+    init_noise_xy[2 * e + 1] = (2.0f * u[4 * n + e] - 1.0f) * noise_scale;
+    timestep[e] = 0;
+    time_buf[e] = 0.f;
+    done[e] = PARC_DONE_NULL;
+    next_target_time[e] = 0.f;
+    ep_num[e] += 1;
+}
+
+extern "C" int parc_reset_sample_apply(void *stream, int n_envs, const int32_t *done_flags, int32_t *mask, const float *uniforms, int n_motions,
+                                       const float *motion_weights, const float *fail_rates, float min_weight, const float *motion_lengths,
+                                       const float *motion_offsets, int terrains_per_motion, float noise_scale, float *cdf_workspace,
+                                       int64_t *motion_ids, int64_t *motion_terrain_ids, float *motion_time_offsets, float *motion_xy_offset,
+                                       int32_t *timestep_buf, float *time_buf, int32_t *done, float *next_target_time, int64_t *ep_num,
+                                       float *init_noise_xy) {
+    if (n_envs < 0 || n_motions < 1 || terrains_per_motion < 1 || !done_flags || !mask || !uniforms || !motion_weights || !motion_lengths ||
+        !cdf_workspace || !init_noise_xy)
+        return PARC_EINVAL;
+    if (n_envs == 0) return PARC_OK;
+    hipLaunchKernelGGL(reset_cdf_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_motions, motion_weights, fail_rates, min_weight, cdf_workspace);
+    hipLaunchKernelGGL(reset_sample_apply_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_envs, done_flags, mask, uniforms,
+                       n_motions, cdf_workspace, motion_lengths, motion_offsets, terrains_per_motion, noise_scale, motion_ids, motion_terrain_ids,
+                       motion_time_offsets, motion_xy_offset, timestep_buf, time_buf, done, next_target_time, ep_num, init_noise_xy);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+// =============================================================================================
 // Fail-rate EMA (dm_env.py:758-772): for every env that finished this step, in env order,
 //     fail_rate[clip] = (1 - w) fail_rate[clip] + w [episode failed]
 // One 256-thread workgroup per clip.  Pass i reads the done flags of envs 256 i .. 256 i + 255 coalesced; a wave-wide ballot

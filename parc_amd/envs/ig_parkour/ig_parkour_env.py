@@ -287,6 +287,32 @@ class IGParkourEnv(base_env.BaseEnv):
         c, dm, N = self._core, self._dm_env, self._num_envs
         L = _hip.lib()
         done = self._done_buf if done is None else done
+        ml = dm._motion_lib
+        if not (dm._demo_mode or dm._one_motion_mode) and dm._rand_reset and done.dtype == torch.int32 and done.is_contiguous():
+            # the training configuration: sampling + bookkeeping in two launches from the step's uniform pool (no torch ops at all)
+            if not c.rand_pool_fresh:
+                c.rand_pool.uniform_()             # reset_done outside a step (tests, tools)
+            c.rand_pool_fresh = False
+            M = ml.num_motions()
+            if c.reset_cdf is None or c.reset_cdf.numel() < M:
+                c.reset_cdf = torch.empty(M, dtype=torch.float32, device=self._device)
+            offs = dm._dm_motion_offsets
+            assert offs.is_contiguous() and offs.dim() == 3
+            fr = None if dm._ignore_fail_rates else dm._motion_id_fail_rates
+            _hip.check(L.parc_reset_sample_apply(_hip.stream(), N, _hip.ptr(done), _hip.ptr(c.reset_mask), _hip.ptr(c.reset_uniforms), M,
+                                                 _hip.ptr(ml._motion_weights), _hip.ptr(fr), float(dm._min_motion_weight),
+                                                 _hip.ptr(ml._motion_lengths), _hip.ptr(offs), int(offs.shape[1]),
+                                                 float(dm._rand_root_pos_offset_scale), _hip.ptr(c.reset_cdf), _hip.ptr(c.motion_ids),
+                                                 _hip.ptr(c.motion_terrain_ids), _hip.ptr(c.motion_time_offsets), _hip.ptr(c.motion_xy_offset),
+                                                 _hip.ptr(c.timestep_buf), _hip.ptr(c.time_buf), _hip.ptr(c.done), _hip.ptr(c.next_target_xy_time),
+                                                 _hip.ptr(self._ep_num_buf), _hip.ptr(c.init_noise_xy)), "parc_reset_sample_apply")
+            c.post_step(_hip.POST_REF | _hip.POST_INIT_CHAR | _hip.POST_MASKED)
+            _hip.check(L.parc_sim_refresh_bodies_masked(_hip.stream(), self._sim_model.device_ptr(self._device), N, _hip.ptr(c.reset_mask),
+                                                        _hip.ptr(c.root_state), _hip.ptr(c.dof_state), _hip.ptr(c.rigid_body_state),
+                                                        _hip.ptr(c.contact_forces)), "parc_sim_refresh_bodies_masked")
+            c.post_step(_hip.POST_OBS | _hip.POST_HF | _hip.POST_MASKED | _hip.POST_TARGETS, reset_rand=True)
+            self._update_info()
+            return self._obs_buf, self._info
         c.reset_mask.copy_(done != base_env.DoneFlags.NULL.value)
         new_mid, new_tid, new_t = dm.sample_reset_all()
         offs = dm._dm_motion_offsets
@@ -324,7 +350,8 @@ class IGParkourEnv(base_env.BaseEnv):
         self._timestep_buf += 1
         torch.mul(self._timestep_buf, self._timestep, out=self._time_buf)
         # _update_misc (incl. the xy target resample) / _update_observations / _update_reward / _update_done in one launch
-        c.target_rand.uniform_()
+        c.rand_pool.uniform_()          # all uniforms of this step and of the restarts that follow it (tracker_core.rand_pool)
+        c.rand_pool_fresh = True
         c.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS)
         c.update_fail_rates(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight)
         if self._never_done:

@@ -154,7 +154,14 @@ class TrackerCore:
         # device-side reset (PARC_POST_MASKED / PARC_POST_INIT_CHAR)
         self.reset_mask = z((N,), dtype=torch.int, device=device)
         self.init_noise_xy = z((N, 2), **f32)
-        self.target_rand = z((N, 3), **f32)          # PARC_POST_TARGETS: per-env uniforms, refilled by the env before the launch
+        # every uniform an env step consumes, drawn by ONE launch per step (IGParkourEnv.step): [N,3] xy-target resample of the step
+        # (PARC_POST_TARGETS), [N,3] the same for the envs that restart, [5,N] reset sampling (clip, tile, phase, xy noise)
+        self.rand_pool = z((11 * N,), **f32)
+        self.target_rand = self.rand_pool[0:3 * N].view(N, 3)
+        self.target_rand_reset = self.rand_pool[3 * N:6 * N].view(N, 3)
+        self.reset_uniforms = self.rand_pool[6 * N:11 * N].view(5, N)
+        self.rand_pool_fresh = False
+        self.reset_cdf = None
         self.ray_xy_points = ray_xy_points.to(device=device, dtype=torch.float32).contiguous()
         P = self.ray_xy_points.shape[0]
         assert P == cfg.struct.num_ray_points
@@ -163,6 +170,7 @@ class TrackerCore:
         self.terrain = None
         self._terrain_struct = None
         self._buf_struct = None
+        self._buf_struct_reset = None
         self.timing_events = None      # bench.py: list of (start, end) torch.cuda.Event pairs around full post-step launches
 
     def set_terrain(self, terrain):
@@ -171,7 +179,13 @@ class TrackerCore:
         self._hf = hf
         self._terrain_struct = _hip.terrain_struct(hf, terrain.min_point.tolist(), terrain.dxdy.tolist())
 
-    def buffers(self):
+    def buffers(self, reset=False):
+        """parc_env_buffers_t of this core; reset=True: the variant whose target uniforms are the restart slice of the pool"""
+        if reset:
+            if self._buf_struct_reset is None:
+                self._buf_struct_reset = _hip.EnvBuffersS.from_buffer_copy(self.buffers())
+                self._buf_struct_reset.target_rand = _hip.ptr(self.target_rand_reset)
+            return self._buf_struct_reset
         if self._buf_struct is None:
             p = _hip.ptr
             self._buf_struct = _hip.EnvBuffersS(
@@ -194,7 +208,7 @@ class TrackerCore:
                                                   self.cfg.obs_dim), "parc_refresh_obs_hfs")
 
     # ---- fused K3/K2/K4/K6-K10
-    def post_step(self, what, env_ids=None):
+    def post_step(self, what, env_ids=None, reset_rand=False):
         if env_ids is not None:
             env_ids = env_ids.to(torch.int64).contiguous()
             n = int(env_ids.shape[0])
@@ -208,7 +222,7 @@ class TrackerCore:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         _hip.check(_hip.lib().parc_track_post_step(_hip.stream(), self.km.c_struct(), self.mlib.c_struct(), self._terrain_struct,
-                                                   self.cfg.struct, self.buffers(), ids, n, what, _hip.ptr(self.ray_xy_points)),
+                                                   self.cfg.struct, self.buffers(reset_rand), ids, n, what, _hip.ptr(self.ray_xy_points)),
                    "parc_track_post_step")
         if timed:
             ev1.record()

@@ -368,3 +368,46 @@ def test_episode_length_attribute_reaches_the_kernels_and_rekeys_graphs():
     assert bool((done != DoneFlags.NULL.value).all())             # 1/30 s of env time is already past the limit
     e.set_rand_reset(False)
     assert e.host_step_signature()[1] is False
+
+
+def test_fused_reset_sampler_distribution_and_bookkeeping():
+    """parc_reset_sample_apply: only finished envs change; the clip draw follows weight * max(fail rate, floor), the tile draw is
+    uniform, the start time lies inside the clip, the xy noise inside +-scale; counters are reset like reset(env_ids) does."""
+    from parc_amd import workloads
+    torch.manual_seed(1)
+    e, _, _ = workloads.build_env("boxes_64clips", 4096, DEV, seed=0)
+    e.reset()
+    dm, c = e._dm_env, e._core
+    M = dm._motion_lib.num_motions()
+    fr = torch.rand(M, device=DEV)
+    fr[:8] = 0.0                                   # floored at min_motion_weight
+    dm._motion_id_fail_rates.copy_(fr)
+    a = torch.zeros((4096, 28), device=DEV)
+    e.step(a)
+    done = torch.zeros(4096, dtype=torch.int32, device=DEV)
+    done[::2] = 1
+    before = {k: getattr(c, k).clone() for k in ("motion_ids", "motion_time_offsets", "root_state", "obs")}
+    ep0 = e._ep_num_buf.clone()
+    counts = torch.zeros(M, device=DEV)
+    for it in range(30):
+        e._done_buf.copy_(done)
+        c.rand_pool_fresh = False
+        e.reset_done(e._done_buf)
+        counts += torch.bincount(c.motion_ids[::2], minlength=M).float()
+        if it == 0:
+            keep = done == 0
+            for k, v in before.items():
+                assert torch.equal(getattr(c, k)[keep], v[keep]), k
+            assert torch.equal(e._ep_num_buf[keep], ep0[keep]) and torch.equal(e._ep_num_buf[~keep], ep0[~keep] + 1)
+            assert torch.all(c.timestep_buf[~keep] == 0) and torch.all(c.done == 0) and torch.all(c.reset_mask == done)
+            lens = dm._motion_lib._motion_lengths[c.motion_ids]
+            assert torch.all(c.motion_time_offsets[~keep] >= 0) and torch.all(c.motion_time_offsets[~keep] < lens[~keep] + 1e-6)
+            assert torch.all(c.init_noise_xy[~keep].abs() <= dm._rand_root_pos_offset_scale + 1e-7)
+            assert torch.all((c.motion_terrain_ids >= 0) & (c.motion_terrain_ids < dm._terrains_per_motion))
+            assert torch.isfinite(c.obs).all()
+    w = torch.clamp(fr, min=dm._min_motion_weight) * dm._motion_lib._motion_weights
+    p = (w / w.sum()).cpu().numpy()
+    n = float(counts.sum())
+    obs_p = counts.cpu().numpy() / n
+    sigma = np.sqrt(p * (1 - p) / n)
+    assert np.all(np.abs(obs_p - p) < 5 * sigma + 1e-4), float(np.max(np.abs(obs_p - p) / (sigma + 1e-9)))
