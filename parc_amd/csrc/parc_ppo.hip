@@ -165,7 +165,7 @@ extern "C" int parc_ppo_workspace_floats(int B) { return ((B + PPO_THREADS - 1) 
 // launch: field f copies its [N, row] source into row `*head` of its time-major [T, N, row] buffer.  head is a DEVICE scalar
 // so the launch can sit inside the captured rollout graph.
 // =============================================================================================
-#define PARC_RECORD_MAX_FIELDS 8
+#define PARC_RECORD_MAX_FIELDS 12
 struct record_fields_t {
     parc_record_field_t f[PARC_RECORD_MAX_FIELDS];
 };
@@ -347,7 +347,8 @@ __global__ __launch_bounds__(256) void moments_final_kernel(int chunks, int dim4
     if (i >= 2 * dim4) return;
     const int which = i / dim4, c = i - which * dim4;
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < chunks; ++k) {
+#pragma unroll 16
+    for (int k = 0; k < chunks; ++k) {          // (unrolled: the loads of 16 chunks are in flight together; the adds stay in chunk order)
         const float4 v = partial[((size_t)k * 2 + which) * dim4 + c];
         t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }

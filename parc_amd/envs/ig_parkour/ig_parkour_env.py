@@ -188,11 +188,16 @@ class IGParkourEnv(base_env.BaseEnv):
     def get_dm_env(self):
         return self._dm_env
 
+    # (replanning belongs to the motion-generator sub-env; a pure tracker reports zeros - persistent tensors, not a fill per call)
     def get_replan_time_buf(self):
-        return torch.zeros(1, dtype=torch.float32, device=self._device)
+        if getattr(self, "_replan_time_zero", None) is None:
+            self._replan_time_zero = torch.zeros(1, dtype=torch.float32, device=self._device)
+        return self._replan_time_zero
 
     def get_replan_counter(self):
-        return torch.zeros(self._num_envs, dtype=torch.int64, device=self._device)
+        if getattr(self, "_replan_counter_zero", None) is None:
+            self._replan_counter_zero = torch.zeros(self._num_envs, dtype=torch.int64, device=self._device)
+        return self._replan_counter_zero
 
     def apply_hard_reset(self):
         return

@@ -86,6 +86,8 @@ class DMPPOAgent(torch.nn.Module):
         self._graph_warm = 0
         self._exp_prob_t = torch.ones([1, 1], dtype=torch.float32, device=self._device)
         self._head_t = torch.zeros([1], dtype=torch.int64, device=self._device)
+        self._replan_time_rows, self._replan_time_src = None, None
+        self._ones_mask = None
         if getattr(self._env, "_report_tracking_error", False):
             self._test_tracking_error_tracker = TrackingErrorTracker(self.get_num_envs(), self._device)
 
@@ -232,7 +234,9 @@ class DMPPOAgent(torch.nn.Module):
         if self._mode == AgentMode.TRAIN:
             exp_prob = self._get_exp_prob()
             if exp_prob >= 1.0:
-                mask = torch.ones(n, dtype=torch.float32, device=mean.device)
+                if self._ones_mask is None or self._ones_mask.shape[0] != n:
+                    self._ones_mask = torch.ones(n, dtype=torch.float32, device=mean.device)
+                mask = self._ones_mask                     # read-only downstream (action head, record): one persistent tensor
             else:
                 self._exp_prob_t.fill_(exp_prob)
                 mask = torch.bernoulli(self._exp_prob_t.expand(n, 1)).squeeze(-1).contiguous()
@@ -276,12 +280,15 @@ class DMPPOAgent(torch.nn.Module):
     def _record_data_post_step(self, next_obs, r, done, next_info):
         eb = self._exp_buffer
         if getattr(self, "_in_graph_step", False):
-            eb.record_group([("next_obs", next_obs), ("reward", r), ("done", done), ("timestep", next_info["timestep"]),
-                             ("ep_num", next_info["ep_num"]), ("next_char_contact_forces", next_info["char_contact_forces"]),
-                             ("env_id", self._env_ids)])
+            items = [("next_obs", next_obs), ("reward", r), ("done", done), ("timestep", next_info["timestep"]),
+                     ("ep_num", next_info["ep_num"]), ("next_char_contact_forces", next_info["char_contact_forces"]),
+                     ("env_id", self._env_ids)]
             if self._is_terrain_runner:
-                eb.record("replan_timer", self._env.get_replan_time_buf().expand(self.get_num_envs()))
-                eb.record("replan_counter", self._env.get_replan_counter())
+                rt = self._env.get_replan_time_buf()
+                if self._replan_time_src is not rt:   # (a tracker env hands out one persistent zero: expand it once, not per step)
+                    self._replan_time_src, self._replan_time_rows = rt, rt.expand(self.get_num_envs()).contiguous()
+                items += [("replan_timer", self._replan_time_rows), ("replan_counter", self._env.get_replan_counter())]
+            eb.record_group(items)
             return
         eb.record("next_obs", next_obs)
         eb.record("reward", r)

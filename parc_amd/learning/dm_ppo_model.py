@@ -19,8 +19,14 @@ class DistributionGaussianDiag:
     def __init__(self, mean, logstd):
         self._mean = mean
         self._logstd = logstd
-        self._std = torch.exp(logstd)
+        self._std_cache = None          # exp(logstd) on first use (the fused action head never needs it)
         self._dim = mean.shape[-1]
+
+    @property
+    def _std(self):
+        if self._std_cache is None:
+            self._std_cache = torch.exp(self._logstd)
+        return self._std_cache
 
     @property
     def stddev(self):
