@@ -296,10 +296,11 @@ int parc_action_head(void *stream, int n, int A, const float *mean, const float 
  * util/geom_util.py:113-143): signed distance of points [batch, n_points, 3] to the columns of hf [batch, dim_x, dim_y].
  * Cell (i, j) of batch b is the box centred at (x_points[i] + min_box_center[b,0], y_points[j] + min_box_center[b,1]) with
  * half extents (half_x, half_y); vertically [base_z, hf] or, inverted != 0, [hf, -base_z] with the result negated.
- * radius > 0 = rounded boxes (sd - radius), <= 0 = plain boxes.  out [batch, n_points]. */
+ * radius > 0 = rounded boxes (sd - radius), <= 0 = plain boxes.  out [batch, n_points]; out_cell (may be NULL) [batch, n_points]:
+ * flat index i * dim_y + j of the first column attaining the minimum (what a caller needs to differentiate the distance). */
 int parc_points_hf_sdf(void *stream, int batch, int n_points, int dim_x, int dim_y, const float *points, const float *hf,
                        const float *min_box_center, const float *x_points, const float *y_points, float half_x, float half_y,
-                       float base_z, int inverted, float radius, float *out);
+                       float base_z, int inverted, float radius, float *out, int32_t *out_cell);
 
 /* ---- measurement knobs (exported for tools/bench_kernels.py; not part of the stable ABI, defaults are the product path) ----
  * parc_tune_hf_envs_per_block(1|2|4|8): envs per workgroup of the standalone heightmap kernel;

@@ -159,7 +159,7 @@ def _declare(L):
     L.parc_normalize_clamp.restype = c_int
     L.parc_action_head.argtypes = [c_vp, c_int, c_int] + [c_vp] * 8
     L.parc_action_head.restype = c_int
-    L.parc_points_hf_sdf.argtypes = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 5 + [c_f, c_f, c_f, c_int, c_f, c_vp]
+    L.parc_points_hf_sdf.argtypes = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 5 + [c_f, c_f, c_f, c_int, c_f, c_vp, c_vp]
     L.parc_points_hf_sdf.restype = c_int
     L.parc_moments_workspace_floats.argtypes = [c_i64, c_int]
     L.parc_moments_workspace_floats.restype = c_i64

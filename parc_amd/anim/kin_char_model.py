@@ -321,6 +321,101 @@ class KinCharModel:
                                                       _hip.ptr(bp), _hip.ptr(br)), "parc_forward_kinematics")
         return bp.reshape(lead + [B, 3]), br.reshape(lead + [B, 4])
 
+    # ------------------------------------------------------------------ batch math (torch, differentiable)
+    # The same maps as the kernels above, written with torch ops for callers that need gradients with respect to the pose (the
+    # terrain-penetration loss of the motion optimiser).  Level-batched: bodies of one tree depth are composed in one shot.
+    def _torch_tables(self):
+        if getattr(self, "_tt", None) is None:
+            J = self.get_num_joints() - 1
+            kind = torch.zeros(J, dtype=torch.long)                 # 0 fixed, 1 hinge, 3 spherical (= dof count)
+            first = torch.zeros(J, dtype=torch.long)
+            axis = torch.zeros((J, 3), dtype=torch.float32)
+            for j in range(1, J + 1):
+                jt = self._joints[j]
+                n = jt.get_dof_dim()
+                kind[j - 1], first[j - 1] = n, jt.dof_idx
+                if n == 1:
+                    ax = jt.axis.detach().cpu().numpy() if torch.is_tensor(jt.axis) else np.asarray(jt.axis)
+                    axis[j - 1] = torch.as_tensor(np.asarray(ax, dtype=np.float32).reshape(3))
+            par = self._parent_indices.cpu().tolist()
+            depth = [0] * (J + 1)
+            for b in range(1, J + 1):
+                depth[b] = depth[par[b]] + 1
+            levels = [[b for b in range(1, J + 1) if depth[b] == d] for d in range(1, max(depth) + 1)]
+            dev = self._device
+            self._tt = {"hinge": (kind == 1).nonzero().flatten().to(dev), "sph": (kind == 3).nonzero().flatten().to(dev),
+                        "first": first.to(dev), "axis": axis.to(dev),
+                        "levels": [(torch.tensor(l, device=dev), torch.tensor([par[b] for b in l], device=dev)) for l in levels]}
+        return self._tt
+
+    def dof_to_rot_torch(self, dof):
+        """[..., D] -> [..., J, 4] with autograd (hinge: axis-angle, spherical: exponential map, fixed: identity)"""
+        t = self._torch_tables()
+        J = self.get_num_joints() - 1
+        rot = torch.zeros(dof.shape[:-1] + (J, 4), dtype=dof.dtype, device=dof.device)
+        ident = torch.zeros_like(rot)
+        ident[..., 3] = 1.0
+        parts = []
+        if t["hinge"].numel():
+            ang = dof[..., t["first"][t["hinge"]]] / 2                       # [..., H]
+            ax = t["axis"][t["hinge"]]
+            ax = ax / torch.linalg.vector_norm(ax, dim=-1, keepdim=True).clamp(min=1e-9)
+            q = torch.cat([ax * ang.sin().unsqueeze(-1), ang.cos().unsqueeze(-1)], dim=-1)
+            parts.append((t["hinge"], q / torch.linalg.vector_norm(q, dim=-1, keepdim=True).clamp(min=1e-9)))
+        if t["sph"].numel():
+            idx = t["first"][t["sph"]].unsqueeze(-1) + torch.arange(3, device=dof.device)          # [S, 3]
+            parts.append((t["sph"], self._exp_map_to_quat_torch(dof[..., idx])))
+        out = ident
+        for where, q in parts:
+            out = out.index_copy(-2, where, q)
+        return out
+
+    @staticmethod
+    def _exp_map_to_quat_torch(e):
+        ang = torch.linalg.vector_norm(e, dim=-1)
+        safe = ang.clamp(min=1e-20)
+        axis = e / safe.unsqueeze(-1)
+        ang = torch.atan2(torch.sin(ang), torch.cos(ang))
+        big = ang.abs() > 1e-5
+        zaxis = torch.zeros_like(e)
+        zaxis[..., 2] = 1
+        axis = torch.where(big.unsqueeze(-1), axis, zaxis)
+        half = (torch.where(big, ang, torch.zeros_like(ang)) / 2).unsqueeze(-1)
+        q = torch.cat([axis / torch.linalg.vector_norm(axis, dim=-1, keepdim=True).clamp(min=1e-9) * half.sin(), half.cos()], dim=-1)
+        return q / torch.linalg.vector_norm(q, dim=-1, keepdim=True).clamp(min=1e-9)
+
+    @staticmethod
+    def _quat_mul_torch(a, b):
+        ax, ay, az, aw = a.unbind(-1)
+        bx, by, bz, bw = b.unbind(-1)
+        return torch.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                            aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], dim=-1)
+
+    @staticmethod
+    def _quat_rotate_torch(q, v):
+        qv, qw = q[..., :3], q[..., 3:]
+        t = 2 * torch.cross(qv, v, dim=-1)
+        return v + qw * t + torch.cross(qv, t, dim=-1)
+
+    def forward_kinematics_torch(self, root_pos, root_rot, joint_rot):
+        """-> body_pos [..., B, 3], body_rot [..., B, 4] with autograd; one composition per tree level"""
+        t = self._torch_tables()
+        B = self.get_num_joints()
+        lead = root_pos.shape[:-1]
+        local = self._quat_mul_torch(self._local_rotation[1:].expand(lead + (B - 1, 4)), joint_rot)       # local_rot * joint_rot
+        pos = [None] * B
+        rot = [None] * B
+        pos[0], rot[0] = root_pos, root_rot
+        for bodies, parents in t["levels"]:
+            ppos = torch.stack([pos[p] for p in parents.tolist()], dim=-2)
+            prot = torch.stack([rot[p] for p in parents.tolist()], dim=-2)
+            lt = self._local_translation[bodies].expand(ppos.shape)
+            npos = ppos + self._quat_rotate_torch(prot, lt)
+            nrot = self._quat_mul_torch(prot, local[..., bodies - 1, :])
+            for k, b in enumerate(bodies.tolist()):
+                pos[b], rot[b] = npos[..., k, :], nrot[..., k, :]
+        return torch.stack(pos, dim=-2), torch.stack(rot, dim=-2)
+
     def apply_joint_dof_limits(self, joint_dofs):
         return torch.minimum(torch.maximum(joint_dofs, self._lower_dof_limits), self._upper_dof_limits)
 

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(SDF_THREADS) void points_hf_sdf_kernel(int n_points
                                                                     const float *__restrict__ hf, const float *__restrict__ min_box_center,
                                                                     const float *__restrict__ x_points, const float *__restrict__ y_points,
                                                                     float half_x, float half_y, float base_z, int inverted, float radius,
-                                                                    float *__restrict__ out) {
+                                                                    float *__restrict__ out, int32_t *__restrict__ out_cell) {
     __shared__ float4 cells[SDF_TILE];
     const int bi = blockIdx.y;
     const int p = blockIdx.x * SDF_THREADS + threadIdx.x;
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(SDF_THREADS) void points_hf_sdf_kernel(int n_points
     const float ox = min_box_center[2 * bi], oy = min_box_center[2 * bi + 1];
     const float top_z = -base_z;
     float best = INFINITY;
+    int best_cell = 0;
     for (int t0 = 0; t0 < M; t0 += SDF_TILE) {
         const int cnt = min(SDF_TILE, M - t0);
         for (int c = threadIdx.x; c < cnt; c += SDF_THREADS) {
@@ -51,24 +52,31 @@ __global__ __launch_bounds__(SDF_THREADS) void points_hf_sdf_kernel(int n_points
             const float ax = fmaxf(qx, 0.f), ay = fmaxf(qy, 0.f), az = fmaxf(qz, 0.f);
             const float outside = __fsqrt_rn(ax * ax + ay * ay + az * az);
             const float inside = fminf(fmaxf(qx, fmaxf(qy, qz)), 0.f);
-            best = fminf(best, outside + inside);
+            const float sd = outside + inside;
+            if (sd < best) {             // first column that attains the minimum
+                best = sd;
+                best_cell = t0 + c;
+            }
         }
         __syncthreads();
     }
     if (radius > 0.f) best -= radius;           // sdRoundBox: x - r is monotone, so it commutes with the min
     if (inverted) best = -best;
-    if (p < n_points) out[(size_t)bi * n_points + p] = best;
+    if (p < n_points) {
+        out[(size_t)bi * n_points + p] = best;
+        if (out_cell) out_cell[(size_t)bi * n_points + p] = best_cell;
+    }
 }
 
 extern "C" int parc_points_hf_sdf(void *stream, int batch, int n_points, int dim_x, int dim_y, const float *points, const float *hf,
                                   const float *min_box_center, const float *x_points, const float *y_points, float half_x, float half_y,
-                                  float base_z, int inverted, float radius, float *out) {
+                                  float base_z, int inverted, float radius, float *out, int32_t *out_cell) {
     if (batch < 0 || n_points < 0 || dim_x <= 0 || dim_y <= 0 || (int64_t)dim_x * dim_y > (int64_t)1 << 30) return PARC_EINVAL;
     if (batch == 0 || n_points == 0) return PARC_OK;
     if (batch > 65535) return PARC_EUNSUPPORTED;
     if (!points || !hf || !min_box_center || !x_points || !y_points || !out) return PARC_EINVAL;
     hipLaunchKernelGGL(points_hf_sdf_kernel, dim3((n_points + SDF_THREADS - 1) / SDF_THREADS, batch), dim3(SDF_THREADS), 0, (hipStream_t)stream,
-                       n_points, dim_x, dim_y, points, hf, min_box_center, x_points, y_points, half_x, half_y, base_z, inverted, radius, out);
+                       n_points, dim_x, dim_y, points, hf, min_box_center, x_points, y_points, half_x, half_y, base_z, inverted, radius, out, out_cell);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }

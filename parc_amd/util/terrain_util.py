@@ -216,12 +216,17 @@ from .terrain_procgen import (add_boxes_to_hf2, add_stairs_to_hf, draw_box, gen_
 # Terrain / body-geometry queries around the tracker ("next" rows): penetration distance of point
 # sets into a heightfield (HIP kernel parc_points_hf_sdf) and the per-clip heightfield preprocessing of the dataset
 # builder.  The character's pose comes from the same FK kernels the tracker uses (KinCharModel.dof_to_rot /
-# forward_kinematics); everything here is forward-only (no autograd graph is recorded through the kernels).
+# forward_kinematics); `points_hf_sdf` / `motion_frames_hf_sdf_loss` are differentiable (kernel for the arg-min column, torch ops for the selected
+# branch and for the pose), the preprocessing functions are forward-only.
 # ---------------------------------------------------------------------------------------------------------------------
 def points_hf_sdf(points, hf, hf_min_box_center, hf_dxdy, base_z=-10.0, inverted=True, radius=None):
     """Signed distance of points [B, N, 3] to heightfields hf [B, X, Y] made of dx x dy columns whose cell (0, 0) is centred at
     hf_min_box_center [B, 2]; inverted (default) = negative depth below the surface for points in the ground.
-    Reference: util/terrain_util.py:1835-1893.  One launch, no [B, N, X*Y, 3] temporaries."""
+    Reference: util/terrain_util.py:1835-1893.  One launch, no [B, N, X*Y, 3] temporaries.
+
+    Differentiable in ``points``: the kernel also reports WHICH column attains the minimum; when ``points`` requires grad the distance
+    to that one column is re-evaluated with torch ops (N box distances instead of N * X * Y), so autograd sees exactly the branch
+    torch.min would have routed the gradient through."""
     from .. import _hip
     assert points.dim() == 3 and hf.dim() == 3 and hf_min_box_center.dim() == 2 and hf_dxdy.dim() == 1
     B, N = int(points.shape[0]), int(points.shape[1])
@@ -231,17 +236,37 @@ def points_hf_sdf(points, hf, hf_min_box_center, hf_dxdy, base_z=-10.0, inverted
     # cell-centre coordinates relative to cell (0, 0): torch's own linspace, evaluated on the host (X + Y values)
     xs = torch.linspace(0.0, (X - 1.0) * hf_dxdy[0].item(), X).to(dev)
     ys = torch.linspace(0.0, (Y - 1.0) * hf_dxdy[1].item(), Y).to(dev)
-    half = (hf_dxdy.to(torch.float32) / 2.0).cpu()
+    half = (hf_dxdy.detach().to(torch.float32) / 2.0).cpu()
     if radius is not None:
         assert isinstance(radius, float) and radius > 0.0
+    want_grad = torch.is_grad_enabled() and (points.requires_grad or hf.requires_grad)
     out = torch.empty((B, N), dtype=torch.float32, device=dev)
-    pts = points.to(torch.float32).contiguous()
-    hfc = hf.to(torch.float32).contiguous()
-    mbc = hf_min_box_center.to(torch.float32).contiguous()
+    cell = torch.empty((B, N), dtype=torch.int32, device=dev) if want_grad else None
+    pts = points.detach().to(torch.float32).contiguous()
+    hfc = hf.detach().to(torch.float32).contiguous()
+    mbc = hf_min_box_center.detach().to(torch.float32).contiguous()
     _hip.check(_hip.lib().parc_points_hf_sdf(_hip.stream(), B, N, X, Y, _hip.ptr(pts), _hip.ptr(hfc), _hip.ptr(mbc), _hip.ptr(xs), _hip.ptr(ys),
                                              float(half[0]), float(half[1]), float(base_z), 1 if inverted else 0,
-                                             float(radius) if radius is not None else 0.0, _hip.ptr(out)), "parc_points_hf_sdf")
-    return out
+                                             float(radius) if radius is not None else 0.0, _hip.ptr(out), _hip.ptr(cell)), "parc_points_hf_sdf")
+    if not want_grad:
+        return out
+    # the selected column per point, through autograd (same expressions as the kernel / the reference)
+    ci = cell.long()
+    i, j = torch.div(ci, Y, rounding_mode="floor"), ci % Y
+    h = torch.gather(hf.reshape(B, -1), 1, ci)
+    cx = xs[i] + hf_min_box_center[:, 0:1]
+    cy = ys[j] + hf_min_box_center[:, 1:2]
+    if inverted:
+        top = -base_z
+        cz, hz = (h + top) / 2.0, (top - h) / 2.0
+    else:
+        cz, hz = (h + base_z) / 2.0, (h - base_z) / 2.0
+    q = torch.stack([(points[..., 0] - cx).abs() - float(half[0]), (points[..., 1] - cy).abs() - float(half[1]), (points[..., 2] - cz).abs() - hz],
+                    dim=-1)
+    sd = torch.linalg.vector_norm(q.clamp(min=0.0), dim=-1) + q.max(dim=-1)[0].clamp(max=0.0)
+    if radius is not None:
+        sd = sd - radius
+    return -sd if inverted else sd
 
 
 def _exp_map_to_quat(e):
@@ -270,8 +295,13 @@ def _body_points_world(motion_frames, char_model, char_point_samples):
     """frames [..., 34] -> (world positions [..., P, 3] of every sample point, owning body [P]); bodies in order, a body's
     points in the order of its sample tensor."""
     root_rot = _exp_map_to_quat(motion_frames[..., 3:6])
-    joint_rot = char_model.dof_to_rot(motion_frames[..., 6:])
-    body_pos, body_rot = char_model.forward_kinematics(motion_frames[..., 0:3], root_rot, joint_rot)
+    if torch.is_grad_enabled() and motion_frames.requires_grad:
+        # pose through torch ops so that autograd reaches the frames (KinCharModel.*_torch); values agree with the kernels to fp32 rounding
+        joint_rot = char_model.dof_to_rot_torch(motion_frames[..., 6:])
+        body_pos, body_rot = char_model.forward_kinematics_torch(motion_frames[..., 0:3], root_rot, joint_rot)
+    else:
+        joint_rot = char_model.dof_to_rot(motion_frames[..., 6:])
+        body_pos, body_rot = char_model.forward_kinematics(motion_frames[..., 0:3], root_rot, joint_rot)
     dev = motion_frames.device
     owner = torch.cat([torch.full((p.shape[0],), b, dtype=torch.int64, device=dev) for b, p in enumerate(char_point_samples)])
     local = torch.cat([p.to(dev) for p in char_point_samples], dim=0)

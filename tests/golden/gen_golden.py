@@ -595,6 +595,14 @@ def gen_terrain_geometry():
     hf2 = np.stack([npy(ter.hf)] * 2, axis=0)
     loss, lp, lsdf = terrain_util.motion_frames_hf_sdf_loss(t(mf), pts, t(hf2), t(mbc2), ter.dxdy, km, ret_vis_info=True)
     out.update(loss_frames=mf, loss=loss, loss_points=lp, loss_sdf=lsdf, civ_hf=npy(ter.hf), civ_min_point=npy(ter.min_point), civ_dxdy=npy(ter.dxdy))
+    # gradient of the summed loss with respect to the frames (what the motion optimiser descends along), by the reference's autograd
+    mf_g = t(mf).requires_grad_(True)
+    terrain_util.motion_frames_hf_sdf_loss(mf_g, pts, t(hf2), t(mbc2), ter.dxdy, km).sum().backward()
+    out["loss_grad"] = mf_g.grad
+    # ... and of points_hf_sdf itself with respect to the points
+    p_g = t(p).requires_grad_(True)
+    terrain_util.points_hf_sdf(p_g, t(hf), t(mbc), t(dxdy)).sum().backward()
+    out["sdf_inverted_grad"] = p_g.grad
     # compute_hf_extra_vals on the first 60 frames (lifted over part of the clip so the jump branch fires)
     clip = frames[0:60].copy()
     clip[20:40, 2] += 1.0
