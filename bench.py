@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 torch.backends.cuda.matmul.allow_tf32 = False
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_FP32_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32 matrix peak (spec; 155 measured)
 # algorithmic bytes per env of the fused post-step kernel: K5 heightmap gather 3544 (16 in + 441*4 gathered +
 # 441*4 stored) + K3 7 queries x 760 + simulator state read 456 + observation columns [0,871) 3484 + body states 780 + 8 out
 POST_STEP_BYTES_PER_ENV = 3544 + 7 * 760 + 456 + 3484 + 780 + 8
@@ -253,6 +254,17 @@ def main():
         extra.append({"kernel": "sim_step_bpl_kernel (articulated-body step, {} substeps)".format(env._sim_steps * env._substeps), "envs": N,
                       "us_per_launch": us, "bound": "instruction latency (serial tree sweeps); state traffic 1624 B/env",
                       "achieved_GBps": N * 1624 / us / 1e3})
+        # the update phase is fp32 GEMMs (81 % of the iteration): the two largest shapes of a PPO minibatch against the dense fp32 MFMA peak
+        mb = agent._batch_size * N
+        for (m_, k_, n_, what) in ((mb, c.cfg.obs_dim, 2048, "layer-1 forward"), (mb, 2048, 1024, "layer-2 forward")):
+            a_ = torch.randn((m_, k_), device=dev)
+            w_ = torch.randn((n_, k_), device=dev)
+            b_ = torch.zeros(n_, device=dev)
+            us_g = time_launches(lambda: torch._addmm_activation(b_, a_, w_.t(), use_gelu=False), 10)
+            tf = 2.0 * m_ * k_ * n_ / us_g / 1e6
+            extra.append({"kernel": "policy / value MLP {} GEMM + bias + ReLU, {}x{}x{} (hipBLASLt fp32)".format(what, m_, k_, n_), "us_per_launch": us_g,
+                          "bound": "mfma", "achieved_TFLOPs": tf, "peak_TFLOPs": MFMA_FP32_PEAK_TFLOPS, "frac_of_peak": tf / MFMA_FP32_PEAK_TFLOPS})
+            del a_, w_, b_
 
     if rank == 0:
         total_env_steps = world * N * T * args.steps
