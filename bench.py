@@ -215,15 +215,31 @@ def main():
                     "frac_of_valu_issue_peak": issue_us / kern_graph_us}
 
     def time_launches(fn, iters):
+        """us per launch: `iters` launches captured in one hipGraph and replayed between two events (kernel time without the host's
+        dispatch gaps, like the roofline figure above); eager back-to-back launches if the capture is refused"""
         for _ in range(5):
             fn()
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(iters):
-            fn()
-        b.record()
-        torch.cuda.synchronize()
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                for _ in range(iters):
+                    fn()
+            g.replay()
+            torch.cuda.synchronize()
+            a.record()
+            g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            del g
+        except Exception:
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
         return a.elapsed_time(b) * 1e3 / iters
 
     extra = []
