@@ -215,6 +215,7 @@ extern "C" int parc_record_step(void *stream, int n_envs, const int64_t *head, i
 // =============================================================================================
 #define TRK_THREADS 1024
 #define TRK_MAX_K 12
+#define TRK_EPT 4
 
 __device__ __forceinline__ float lerp_torch(float a, float b, float w) { return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.0f - w); }
 
@@ -227,21 +228,38 @@ __global__ __launch_bounds__(TRK_THREADS) void return_tracker_kernel(int n_envs,
     float acc[TRK_MAX_K + 2];
 #pragma unroll
     for (int k = 0; k < TRK_MAX_K + 2; ++k) acc[k] = 0.f;
-    for (int e = tid; e < n_envs; e += TRK_THREADS) {
-        const bool fin = done[e] != 0;
-        const int64_t len = ep_len[e] + 1;
-        if (fin) {
-            acc[TRK_MAX_K] += (float)len;
-            acc[TRK_MAX_K + 1] += 1.0f;
-            eps_per_env[e] += 1;
-        }
-        ep_len[e] = fin ? 0 : len;
+    // TRK_EPT envs per thread and pass: all loads of a pass are issued before the first store (one workgroup has to cover every
+    // env, so what it can hide is memory latency, by keeping ~2 (K + 1) TRK_EPT loads in flight per thread)
+    for (int base = 0; base < n_envs; base += TRK_THREADS * TRK_EPT) {
+        int fin[TRK_EPT];
+        int64_t len[TRK_EPT];
+        float rb[TRK_EPT][TRK_MAX_K];
 #pragma unroll
-        for (int k = 0; k < TRK_MAX_K; ++k) {
-            if (k < K) {
-                float v = return_buf[(size_t)k * n_envs + e] + rewards[(size_t)k * reward_stride + e];
-                if (fin) acc[k] += v;
-                return_buf[(size_t)k * n_envs + e] = fin ? 0.f : v;
+        for (int j = 0; j < TRK_EPT; ++j) {
+            const int e = base + j * TRK_THREADS + tid;
+            const bool in = e < n_envs;
+            fin[j] = in ? (done[e] != 0) : 0;
+            len[j] = in ? ep_len[e] + 1 : 0;
+#pragma unroll
+            for (int k = 0; k < TRK_MAX_K; ++k)
+                rb[j][k] = (k < K && in) ? return_buf[(size_t)k * n_envs + e] + rewards[(size_t)k * reward_stride + e] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < TRK_EPT; ++j) {
+            const int e = base + j * TRK_THREADS + tid;
+            if (e >= n_envs) continue;
+            if (fin[j]) {
+                acc[TRK_MAX_K] += (float)len[j];
+                acc[TRK_MAX_K + 1] += 1.0f;
+                eps_per_env[e] += 1;
+            }
+            ep_len[e] = fin[j] ? 0 : len[j];
+#pragma unroll
+            for (int k = 0; k < TRK_MAX_K; ++k) {
+                if (k < K) {
+                    if (fin[j]) acc[k] += rb[j][k];
+                    return_buf[(size_t)k * n_envs + e] = fin[j] ? 0.f : rb[j][k];
+                }
             }
         }
     }
@@ -400,9 +418,43 @@ __global__ __launch_bounds__(256) void action_head_kernel(int n, int A, const fl
     logp[i] = -0.5f * acc + (-0.5f * (float)A * 1.8378770664093453f - sum_ls);
 }
 
+// A <= 32 (the humanoid has 28 actuated dofs): 32 lanes per env, lane j = action dimension j - coalesced reads of the [n, A] rows and
+// 512 workgroups at 4096 envs instead of 16; the two sums over j are 5-step xor-shuffle reductions inside the 32-lane group.
+__global__ __launch_bounds__(256) void action_head32_kernel(int n, int A, const float *__restrict__ mean, const float *__restrict__ logstd,
+                                                            const float *__restrict__ noise, const float *__restrict__ explore,
+                                                            const float *__restrict__ a_mean, const float *__restrict__ a_std, float *action,
+                                                            float *logp) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = min(gid >> 5, n - 1), j = gid & 31;           // (tail groups redo the last env; they skip the stores)
+    const bool live = (gid >> 5) < n, valid = j < A;
+    float zz = 0.f, ls = 0.f;
+    if (valid) {
+        ls = logstd[j];
+        const float sd = __expf(ls);
+        const float mu = mean[(size_t)i * A + j];
+        const float na = explore[i] == 1.0f ? mu + sd * noise[(size_t)i * A + j] : mu;
+        const float z = (na - mu) / sd;
+        zz = z * z;
+        if (live) action[(size_t)i * A + j] = na * a_std[j] + a_mean[j];
+    }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) {
+        zz += __shfl_xor(zz, o, 32);
+        ls += __shfl_xor(ls, o, 32);
+    }
+    if (live && j == 0) logp[i] = -0.5f * zz + (-0.5f * (float)A * 1.8378770664093453f - ls);
+}
+
 extern "C" int parc_action_head(void *stream, int n, int A, const float *mean, const float *logstd, const float *noise, const float *explore,
                                 const float *a_mean, const float *a_std, float *action, float *logp) {
     if (n <= 0 || A <= 0) return PARC_EINVAL;
+    if (A <= 32) {
+        const long long threads = (long long)n * 32;
+        hipLaunchKernelGGL(action_head32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, A, mean, logstd, noise,
+                           explore, a_mean, a_std, action, logp);
+        hipError_t e32 = hipGetLastError();
+        return e32 == hipSuccess ? PARC_OK : (int)e32;
+    }
     hipLaunchKernelGGL(action_head_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, A, mean, logstd, noise, explore, a_mean,
                        a_std, action, logp);
     hipError_t e = hipGetLastError();
