@@ -1240,14 +1240,24 @@ __global__ __launch_bounds__(FR_THREADS) void fail_rate_kernel(int n_envs, int n
     if (threadIdx.x == 0) fr = fail_rates[mi];
     for (int seg = 0; seg < n_envs; seg += FR_MAX_PASSES * FR_THREADS) {
         const int passes = min(FR_MAX_PASSES, (n_envs - seg + FR_THREADS - 1) / FR_THREADS);
-        for (int i = 0; i < passes; ++i) {
-            const int e = seg + i * FR_THREADS + threadIdx.x;
-            const int k = e < n_envs ? done_kind[e] : 0;
-            const bool h = k != 0 && motion_ids[e] == mi;
-            const unsigned long long hm = __ballot(h), fm = __ballot(h && k == 1);
-            if ((threadIdx.x & 63) == 0) {
-                hit[i][wv] = hm;
-                fail[i][wv] = fm;
+        for (int i0 = 0; i0 < passes; i0 += 8) {          // 8 passes at a time: their flag loads are in flight together
+            int ks[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = seg + (i0 + u) * FR_THREADS + threadIdx.x;
+                ks[u] = (i0 + u < passes && e < n_envs) ? done_kind[e] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u >= passes) break;
+                const int e = seg + (i0 + u) * FR_THREADS + threadIdx.x;
+                const int k = ks[u];
+                const bool h = k != 0 && motion_ids[e] == mi;
+                const unsigned long long hm = __ballot(h), fm = __ballot(h && k == 1);
+                if ((threadIdx.x & 63) == 0) {
+                    hit[i0 + u][wv] = hm;
+                    fail[i0 + u][wv] = fm;
+                }
             }
         }
         __syncthreads();
