@@ -53,6 +53,13 @@ int parc_sim_step(void *stream, const parc_sim_model_t *model, parc_terrain_t te
                   float *dof_state, float *rigid_body_state, float *contact_forces, const float *env_offsets,
                   const float *action, const float *action_low, const float *action_high, int n_substeps, float h);
 
+/* The same step, followed by IGEnv._update_time (envs/ig_env.py:862-865) inside the launch: timestep_buf[e] += 1 (int32),
+ * time_buf[e] = timestep_buf[e] * step_dt.  Body-per-lane kernel only (PARC_EUNSUPPORTED for the reference kernel). */
+int parc_sim_step_tick(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,
+                       float *dof_state, float *rigid_body_state, float *contact_forces, const float *env_offsets,
+                       const float *action, const float *action_low, const float *action_high, int n_substeps, float h,
+                       int32_t *timestep_buf, float *time_buf, float step_dt);
+
 /* Recompute rigid_body_state (poses, velocities) from root_state / dof_state for the listed envs and zero
  * their contact forces: what the reference gets from refresh_rigid_body_state_tensor after a reset
  * (envs/ig_env.py:850-860).  env_ids int64 device pointer, NULL = all. */

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(64) void sim_step_bpl_kernel(const parc_sim_model_t
                                                           float *root_state, float *dof_state, float *rigid_body_state,
                                                           float *contact_forces, const float *__restrict__ env_offsets,
                                                           const float *__restrict__ action, const float *__restrict__ act_lo,
-                                                          const float *__restrict__ act_hi, int n_sub, float h) {
+                                                          const float *__restrict__ act_hi, int n_sub, float h, int32_t *timestep,
+                                                          float *time_buf, float step_dt) {
     using namespace parc_sim_bpl;
     __shared__ float lds[BPL_EPB][BPL_G * BPL_CONTRIB];
     __shared__ float ccache[64][BPL_CC_SLOTS * BPL_CC_FLOATS + 1];     // +1: odd row stride against bank conflicts
@@ -45,6 +46,12 @@ __global__ __launch_bounds__(64) void sim_step_bpl_kernel(const parc_sim_model_t
     for (int s = 0; s < n_sub; ++s) substep(m, ter, off, L, b, maxd, x, h, w, lds[g], ccache[threadIdx.x]);
     store_lane_state(L, b, maxd, x, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e, rigid_body_state + 13 * (size_t)B * e,
                      contact_forces + 3 * (size_t)B * e);
+    // IGEnv._update_time (ig_env.py:862-865) for callers that ask for it: the env's step counter and clock advance with the simulator
+    if (timestep && b == 0 && (int)blockIdx.x * BPL_EPB + g < n_envs) {
+        const int ts = timestep[e] + 1;
+        timestep[e] = ts;
+        time_buf[e] = (float)ts * step_dt;
+    }
 }
 
 // body-per-lane refresh: body poses / velocities from the state rows, for a list of envs (env_ids, n = list length), for
@@ -96,23 +103,42 @@ extern "C" int parc_tune_sim_threads(int t) {
     return PARC_OK;
 }
 
-extern "C" int parc_sim_step(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,
-                             float *dof_state, float *rigid_body_state, float *contact_forces, const float *env_offsets,
-                             const float *action, const float *action_low, const float *action_high, int n_substeps, float h) {
+static int sim_step_impl(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,
+                         float *dof_state, float *rigid_body_state, float *contact_forces, const float *env_offsets, const float *action,
+                         const float *action_low, const float *action_high, int n_substeps, float h, int32_t *timestep, float *time_buf,
+                         float step_dt) {
     if (!model || n_envs < 0 || n_substeps <= 0 || !(h > 0.f) || !terrain.hf) return PARC_EINVAL;
     if (n_envs == 0) return PARC_OK;
     if (g_sim_variant == 1 && model_bodies_hint <= BPL_G) {
         hipLaunchKernelGGL(sim_step_bpl_kernel, dim3((n_envs + BPL_EPB - 1) / BPL_EPB), dim3(64), 0, (hipStream_t)stream, model, terrain, n_envs,
-                           root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low, action_high, n_substeps, h);
+                           root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low, action_high, n_substeps, h,
+                           timestep, time_buf, step_dt);
         hipError_t e1 = hipGetLastError();
         return e1 == hipSuccess ? PARC_OK : (int)e1;
     }
+    if (timestep) return PARC_EUNSUPPORTED;          // the one-env-per-lane reference kernel does not carry the clock
     const int th = g_sim_threads;
     hipLaunchKernelGGL(sim_step_kernel, dim3((n_envs + th - 1) / th), dim3(th), 0, (hipStream_t)stream, model,
                        terrain, n_envs, root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low,
                        action_high, n_substeps, h);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
+}
+
+extern "C" int parc_sim_step(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,
+                             float *dof_state, float *rigid_body_state, float *contact_forces, const float *env_offsets,
+                             const float *action, const float *action_low, const float *action_high, int n_substeps, float h) {
+    return sim_step_impl(stream, model, terrain, n_envs, root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low,
+                         action_high, n_substeps, h, nullptr, nullptr, 0.f);
+}
+
+extern "C" int parc_sim_step_tick(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,
+                                  float *dof_state, float *rigid_body_state, float *contact_forces, const float *env_offsets,
+                                  const float *action, const float *action_low, const float *action_high, int n_substeps, float h,
+                                  int32_t *timestep_buf, float *time_buf, float step_dt) {
+    if (!timestep_buf || !time_buf) return PARC_EINVAL;
+    return sim_step_impl(stream, model, terrain, n_envs, root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low,
+                         action_high, n_substeps, h, timestep_buf, time_buf, step_dt);
 }
 
 extern "C" int parc_sim_refresh_bodies(void *stream, const parc_sim_model_t *model, int n_envs, const int64_t *env_ids, int n_sel,

@@ -411,3 +411,23 @@ def test_fused_reset_sampler_distribution_and_bookkeeping():
     obs_p = counts.cpu().numpy() / n
     sigma = np.sqrt(p * (1 - p) / n)
     assert np.all(np.abs(obs_p - p) < 5 * sigma + 1e-4), float(np.max(np.abs(obs_p - p) / (sigma + 1e-9)))
+
+
+def test_step_clock_rides_in_the_simulator_launch(env):
+    """IGEnv._update_time inside parc_sim_step_tick: timestep += 1, time = timestep * dt (fp32), same values with the torch fallback
+    of the one-env-per-lane kernel."""
+    from parc_amd import _hip
+    env.reset()
+    a = torch.zeros((96, 28), device=DEV)
+    ts0 = env._timestep_buf.clone()
+    env.step(a)
+    assert torch.equal(env._timestep_buf, ts0 + 1)
+    assert torch.equal(env._time_buf, env._timestep_buf.to(torch.float32) * torch.tensor(env._timestep, dtype=torch.float32, device=DEV))
+    _hip.lib().parc_tune_sim_variant(0)
+    try:
+        ts1 = env._timestep_buf.clone()
+        env.step(a)
+        assert torch.equal(env._timestep_buf, ts1 + 1)
+        assert torch.equal(env._time_buf, env._timestep_buf.to(torch.float32) * torch.tensor(env._timestep, dtype=torch.float32, device=DEV))
+    finally:
+        _hip.lib().parc_tune_sim_variant(1)
