@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Offline GEMM solution selection (PyTorch TunableOp over hipBLASLt / rocBLAS) for the shapes of one training iteration.
-Run on the GPU box; writes gpurun_out/tunableop_results.csv (copy to parc_amd/tunableop_results.csv to ship it).
+Run on the GPU box; writes gpurun_out/tunableop_results_<envs>.csv (merge its Gemm lines into parc_amd/tunableop_results.csv to ship them).
 Prints the iteration time before (default heuristics) and after (tuned selections)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,8 @@ from parc_amd.util import mp_util
 dev = "cuda:0"
 mp_util.init(0, 1, dev)
 torch.manual_seed(0)
-env, _, _ = workloads.build_env("boxes_64clips", 4096, dev, seed=0)
+N_ENVS = int(sys.argv[1]) if len(sys.argv) > 1 else 4096          # python3 tools/tune_gemms.py [envs per GPU]
+env, _, _ = workloads.build_env("boxes_64clips", N_ENVS, dev, seed=0)
 agent = workloads.build_agent(env, dev, mp_scale_rollout=False, tuned_gemms=False)
 agent._curr_obs, agent._curr_info = env.reset()
 agent._init_train()
@@ -29,7 +30,7 @@ def timed(n):
 
 agent._train_iter()
 print("default heuristics: %.1f ms / iteration" % timed(3), flush=True)
-out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tunableop_results.csv")
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "tunableop_results_{}.csv".format(N_ENVS))
 os.makedirs(os.path.dirname(out), exist_ok=True)
 tunable.enable(True)
 tunable.tuning_enable(True)
