@@ -270,10 +270,12 @@ int parc_record_step(void *stream, int n_envs, const int64_t *head, int n_fields
 
 /* ---- K21 episodic return tracker: DMPPOReturnTracker.update  learning/dm_ppo_return_tracker.py:6-99 in one launch.
  * rewards [K, reward_stride] (row k = term k, first n_envs entries), done [N] i32; state: return_buf [K,N], ep_len [N] i64,
- * eps_per_env [N] i64, mean_return [K], mean_ep_len [1], episodes [1] f64.  K <= 12. */
+ * eps_per_env [N] i64, mean_return [K], mean_ep_len [1], episodes [1] f64.  K <= 12.  workspace: caller-owned,
+ * parc_return_tracker_workspace_floats(n_envs) floats, zero-filled once before the first call (the kernel keeps its ticket at zero). */
+int64_t parc_return_tracker_workspace_floats(int n_envs);
 int parc_return_tracker_update(void *stream, int n_envs, int K, const float *rewards, int64_t reward_stride, const int32_t *done,
                                float *return_buf, int64_t *ep_len, int64_t *eps_per_env, float *mean_return, float *mean_ep_len,
-                               double *episodes);
+                               double *episodes, float *workspace);
 
 /* ---- K12: Normalizer.normalize  learning/normalizer.py:60-63 in one pass: out = clamp((x - mean) / std, -clip, clip).
  * x, out [rows, dim] row-major, mean / std [dim]; dim a multiple of 4, 16-byte aligned pointers; out may alias x. */

@@ -165,7 +165,9 @@ def _declare(L):
     L.parc_moments_workspace_floats.restype = c_i64
     L.parc_moments_accumulate.argtypes = [c_vp, c_i64, c_int, c_vp, c_vp, c_vp]
     L.parc_moments_accumulate.restype = c_int
-    L.parc_return_tracker_update.argtypes = [c_vp, c_int, c_int, c_vp, c_i64] + [c_vp] * 7
+    L.parc_return_tracker_update.argtypes = [c_vp, c_int, c_int, c_vp, c_i64] + [c_vp] * 8
+    L.parc_return_tracker_workspace_floats.argtypes = [c_int]
+    L.parc_return_tracker_workspace_floats.restype = c_i64
     L.parc_return_tracker_update.restype = c_int
     L.parc_record_step.argtypes = [c_vp, c_int, c_vp, c_int, c_vp]
     L.parc_record_step.restype = c_int
@@ -185,7 +187,7 @@ def _declare(L):
 EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
             "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step",
             "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize", "parc_reset_apply", "parc_ppo_loss", "parc_ppo_workspace_floats", "parc_record_step", "parc_return_tracker_update", "parc_normalize_clamp",
-            "parc_action_head", "parc_points_hf_sdf", "parc_moments_workspace_floats", "parc_moments_accumulate", "parc_reset_sample_apply"]
+            "parc_action_head", "parc_points_hf_sdf", "parc_moments_workspace_floats", "parc_moments_accumulate", "parc_reset_sample_apply", "parc_return_tracker_workspace_floats"]
 
 
 def check(rc, what):

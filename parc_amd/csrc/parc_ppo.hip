@@ -210,71 +210,75 @@ extern "C" int parc_record_step(void *stream, int n_envs, const int64_t *head, i
 
 // =============================================================================================
 // K21 episodic return tracker: DMPPOReturnTracker.update (learning/dm_ppo_return_tracker.py:6-99) in one launch.
-// One workgroup walks all envs: accumulate the K reward terms and the episode length, fold the envs that finished into the
-// running means (weights by episode count, as the reference), clear them.  Reductions in a fixed order (deterministic).
+// Accumulate the K reward terms and the episode length per env, fold the envs that finished into the running means (weights by
+// episode count, as the reference), clear them.  Reductions in a fixed order (deterministic).
 // =============================================================================================
-#define TRK_THREADS 1024
+#define TRK_THREADS 256
 #define TRK_MAX_K 12
-#define TRK_EPT 4
+#define TRK_SLOTS (TRK_MAX_K + 2)          // K term sums | summed episode length | finished count
 
 __device__ __forceinline__ float lerp_torch(float a, float b, float w) { return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.0f - w); }
 
+// One env per thread, ceil(N / 256) workgroups.  Each workgroup folds its envs' finished-episode sums in a fixed order and parks
+// them in the workspace; the LAST workgroup to arrive (atomic ticket) adds the partial rows in workgroup order and updates the
+// running means, so the result does not depend on scheduling.  workspace: gridDim.x * TRK_SLOTS floats + one int32 ticket (zero
+// before the first launch; the kernel leaves it zero).
 __global__ __launch_bounds__(TRK_THREADS) void return_tracker_kernel(int n_envs, int K, const float *__restrict__ rewards, int64_t reward_stride,
                                                                      const int32_t *__restrict__ done, float *return_buf, int64_t *ep_len,
-                                                                     int64_t *eps_per_env, float *mean_return, float *mean_ep_len, double *episodes) {
-    __shared__ float s_part[TRK_THREADS / 64][TRK_MAX_K + 2];
-    __shared__ float s_tot[TRK_MAX_K + 2];
+                                                                     int64_t *eps_per_env, float *mean_return, float *mean_ep_len, double *episodes,
+                                                                     float *workspace) {
+    __shared__ float s_part[TRK_THREADS / 64][TRK_SLOTS];
+    __shared__ float s_tot[TRK_SLOTS];
+    __shared__ int s_last;
     const int tid = threadIdx.x;
-    float acc[TRK_MAX_K + 2];
+    const int e = blockIdx.x * TRK_THREADS + tid;
+    float acc[TRK_SLOTS];
 #pragma unroll
-    for (int k = 0; k < TRK_MAX_K + 2; ++k) acc[k] = 0.f;
-    // TRK_EPT envs per thread and pass: all loads of a pass are issued before the first store (one workgroup has to cover every
-    // env, so what it can hide is memory latency, by keeping ~2 (K + 1) TRK_EPT loads in flight per thread)
-    for (int base = 0; base < n_envs; base += TRK_THREADS * TRK_EPT) {
-        int fin[TRK_EPT];
-        int64_t len[TRK_EPT];
-        float rb[TRK_EPT][TRK_MAX_K];
-#pragma unroll
-        for (int j = 0; j < TRK_EPT; ++j) {
-            const int e = base + j * TRK_THREADS + tid;
-            const bool in = e < n_envs;
-            fin[j] = in ? (done[e] != 0) : 0;
-            len[j] = in ? ep_len[e] + 1 : 0;
-#pragma unroll
-            for (int k = 0; k < TRK_MAX_K; ++k)
-                rb[j][k] = (k < K && in) ? return_buf[(size_t)k * n_envs + e] + rewards[(size_t)k * reward_stride + e] : 0.f;
+    for (int k = 0; k < TRK_SLOTS; ++k) acc[k] = 0.f;
+    if (e < n_envs) {
+        const bool fin = done[e] != 0;
+        const int64_t len = ep_len[e] + 1;
+        if (fin) {
+            acc[TRK_MAX_K] = (float)len;
+            acc[TRK_MAX_K + 1] = 1.0f;
+            eps_per_env[e] += 1;
         }
+        ep_len[e] = fin ? 0 : len;
 #pragma unroll
-        for (int j = 0; j < TRK_EPT; ++j) {
-            const int e = base + j * TRK_THREADS + tid;
-            if (e >= n_envs) continue;
-            if (fin[j]) {
-                acc[TRK_MAX_K] += (float)len[j];
-                acc[TRK_MAX_K + 1] += 1.0f;
-                eps_per_env[e] += 1;
-            }
-            ep_len[e] = fin[j] ? 0 : len[j];
-#pragma unroll
-            for (int k = 0; k < TRK_MAX_K; ++k) {
-                if (k < K) {
-                    if (fin[j]) acc[k] += rb[j][k];
-                    return_buf[(size_t)k * n_envs + e] = fin[j] ? 0.f : rb[j][k];
-                }
+        for (int k = 0; k < TRK_MAX_K; ++k) {
+            if (k < K) {
+                const float v = return_buf[(size_t)k * n_envs + e] + rewards[(size_t)k * reward_stride + e];
+                if (fin) acc[k] = v;
+                return_buf[(size_t)k * n_envs + e] = fin ? 0.f : v;
             }
         }
     }
     const int wv = tid >> 6, ln = tid & 63;
 #pragma unroll
-    for (int k = 0; k < TRK_MAX_K + 2; ++k) {
-        float v = wave_sum(acc[k]);
+    for (int k = 0; k < TRK_SLOTS; ++k) {
+        const float v = wave_sum(acc[k]);
         if (ln == 0) s_part[wv][k] = v;
     }
     __syncthreads();
-    if (tid < TRK_MAX_K + 2) {
+    float *part = workspace;
+    int *ticket = reinterpret_cast<int *>(workspace + (size_t)gridDim.x * TRK_SLOTS);
+    if (tid < TRK_SLOTS) {
         float v = 0.f;
         for (int w = 0; w < TRK_THREADS / 64; ++w) v += s_part[w][tid];
+        part[(size_t)blockIdx.x * TRK_SLOTS + tid] = v;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid < TRK_SLOTS) {
+        float v = 0.f;
+        for (unsigned g = 0; g < gridDim.x; ++g) v += part[(size_t)g * TRK_SLOTS + tid];
         s_tot[tid] = v;
     }
+    if (tid == 0) *ticket = 0;
     __syncthreads();
     const float n_new = s_tot[TRK_MAX_K + 1];
     if (n_new > 0.f) {
@@ -287,12 +291,17 @@ __global__ __launch_bounds__(TRK_THREADS) void return_tracker_kernel(int n_envs,
     }
 }
 
+extern "C" int64_t parc_return_tracker_workspace_floats(int n_envs) {
+    if (n_envs <= 0) return -1;
+    return (int64_t)((n_envs + TRK_THREADS - 1) / TRK_THREADS) * TRK_SLOTS + 4;
+}
+
 extern "C" int parc_return_tracker_update(void *stream, int n_envs, int K, const float *rewards, int64_t reward_stride, const int32_t *done,
                                           float *return_buf, int64_t *ep_len, int64_t *eps_per_env, float *mean_return, float *mean_ep_len,
-                                          double *episodes) {
-    if (n_envs <= 0 || K <= 0 || K > TRK_MAX_K || reward_stride < n_envs) return PARC_EINVAL;
-    hipLaunchKernelGGL(return_tracker_kernel, dim3(1), dim3(TRK_THREADS), 0, (hipStream_t)stream, n_envs, K, rewards, reward_stride, done, return_buf,
-                       ep_len, eps_per_env, mean_return, mean_ep_len, episodes);
+                                          double *episodes, float *workspace) {
+    if (n_envs <= 0 || K <= 0 || K > TRK_MAX_K || reward_stride < n_envs || !workspace) return PARC_EINVAL;
+    hipLaunchKernelGGL(return_tracker_kernel, dim3((n_envs + TRK_THREADS - 1) / TRK_THREADS), dim3(TRK_THREADS), 0, (hipStream_t)stream, n_envs, K,
+                       rewards, reward_stride, done, return_buf, ep_len, eps_per_env, mean_return, mean_ep_len, episodes, workspace);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }

@@ -22,6 +22,7 @@ class DMPPOReturnTracker:
         self._return_buf = torch.zeros([K, num_envs], device=device, dtype=torch.float32)
         self._mean_return = torch.zeros([K], device=device, dtype=torch.float32)
         self._use_kernel = True
+        self._workspace = None
 
     def get_mean_return(self):
         return self._mean_return[0:1]
@@ -73,9 +74,12 @@ class DMPPOReturnTracker:
             # K21 in one launch (parc_return_tracker_update); the torch expression below is the same rule
             from .. import _hip
             p = _hip.ptr
+            if self._workspace is None:
+                n_ws = int(_hip.lib().parc_return_tracker_workspace_floats(int(done.shape[0])))
+                self._workspace = torch.zeros(n_ws, dtype=torch.float32, device=block.device)
             _hip.check(_hip.lib().parc_return_tracker_update(_hip.stream(), int(done.shape[0]), len(self._keys), p(block), int(block.stride(0)),
                                                              p(done), p(self._return_buf), p(self._ep_len_buf), p(self._eps_per_env_buf),
-                                                             p(self._mean_return), p(self._mean_ep_len), p(self._episodes_t)),
+                                                             p(self._mean_return), p(self._mean_ep_len), p(self._episodes_t), p(self._workspace)),
                        "parc_return_tracker_update")
             return
         self._return_buf += block
