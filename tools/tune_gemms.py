@@ -35,8 +35,9 @@ os.makedirs(os.path.dirname(out), exist_ok=True)
 tunable.enable(True)
 tunable.tuning_enable(True)
 tunable.set_filename(out, False)
-tunable.set_max_tuning_duration(30)        # ms per candidate solution
-tunable.set_max_tuning_iterations(10)
+THOROUGH = len(sys.argv) > 2 and sys.argv[2] == "thorough"      # python3 tools/tune_gemms.py 4096 thorough
+tunable.set_max_tuning_duration(120 if THOROUGH else 30)        # ms per candidate solution
+tunable.set_max_tuning_iterations(60 if THOROUGH else 10)
 agent._use_hip_graph = False               # tuning launches candidates eagerly
 agent._graphs.clear()
 agent._graph_pool = None
