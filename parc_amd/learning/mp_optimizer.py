@@ -22,10 +22,12 @@ class MPOptimizer:
         assert self._cadence in ("minibatch", "epoch")
         lr = float(config["learning_rate"])
         wd = float(config.get("weight_decay", 0.0))
+        # one multi-tensor launch per step where torch offers it (device parameters): same update rule, 1 kernel instead of 3
+        fused = {"fused": True} if (param_list[0].is_cuda and config.get("fused_optimizer", True)) else {}
         if config["type"] == "SGD":
-            self._optimizer = torch.optim.SGD(param_list, lr, momentum=0.9, weight_decay=wd)
+            self._optimizer = torch.optim.SGD(param_list, lr, momentum=0.9, weight_decay=wd, **fused)
         elif config["type"] == "Adam":
-            self._optimizer = torch.optim.AdamW(param_list, lr, weight_decay=wd)
+            self._optimizer = torch.optim.AdamW(param_list, lr, weight_decay=wd, **fused)
         else:
             raise AssertionError("Unsupported optimizer type: " + config["type"])
         n = sum(p.numel() for p in param_list)
