@@ -277,6 +277,10 @@ int parc_return_tracker_update(void *stream, int n_envs, int K, const float *rew
                                float *return_buf, int64_t *ep_len, int64_t *eps_per_env, float *mean_return, float *mean_ep_len,
                                double *episodes, float *workspace);
 
+/* ---- gradient clipping by global norm over a flat buffer (MPOptimizer.step, learning/mp_optimizer.py:24-40 with
+ * torch.nn.utils.clip_grad_norm_): x[0..n) *= min(max_norm / (norm[0] + 1e-6), 1); norm is a device scalar. */
+int parc_scale_by_clipped_norm(void *stream, int64_t n, float *x, const float *norm, float max_norm);
+
 /* ---- K12: Normalizer.normalize  learning/normalizer.py:60-63 in one pass: out = clamp((x - mean) / std, -clip, clip).
  * x, out [rows, dim] row-major, mean / std [dim]; dim a multiple of 4, 16-byte aligned pointers; out may alias x. */
 int parc_normalize_clamp(void *stream, int64_t rows, int dim, const float *x, const float *mean, const float *stdv, float clip, float *out);

@@ -161,6 +161,8 @@ def _declare(L):
     L.parc_action_head.restype = c_int
     L.parc_points_hf_sdf.argtypes = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 5 + [c_f, c_f, c_f, c_int, c_f, c_vp, c_vp]
     L.parc_points_hf_sdf.restype = c_int
+    L.parc_scale_by_clipped_norm.argtypes = [c_vp, c_i64, c_vp, c_vp, c_f]
+    L.parc_scale_by_clipped_norm.restype = c_int
     L.parc_moments_workspace_floats.argtypes = [c_i64, c_int]
     L.parc_moments_workspace_floats.restype = c_i64
     L.parc_moments_accumulate.argtypes = [c_vp, c_i64, c_int, c_vp, c_vp, c_vp]
@@ -187,7 +189,7 @@ def _declare(L):
 EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hfs", "parc_dof_to_rot", "parc_rot_to_dof",
             "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step",
             "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize", "parc_reset_apply", "parc_ppo_loss", "parc_ppo_workspace_floats", "parc_record_step", "parc_return_tracker_update", "parc_normalize_clamp",
-            "parc_action_head", "parc_points_hf_sdf", "parc_moments_workspace_floats", "parc_moments_accumulate", "parc_reset_sample_apply", "parc_return_tracker_workspace_floats"]
+            "parc_action_head", "parc_points_hf_sdf", "parc_moments_workspace_floats", "parc_moments_accumulate", "parc_reset_sample_apply", "parc_return_tracker_workspace_floats", "parc_scale_by_clipped_norm"]
 
 
 def check(rc, what):

@@ -307,6 +307,25 @@ extern "C" int parc_return_tracker_update(void *stream, int n_envs, int K, const
 }
 
 // =============================================================================================
+// Gradient clipping by global norm (torch.nn.utils.clip_grad_norm_ as MPOptimizer applies it to its flat gradient buffer):
+// x *= min(max_norm / (norm + 1e-6), 1) with norm read from device memory - one launch instead of add, reciprocal, mul, clamp, mul.
+// =============================================================================================
+__global__ __launch_bounds__(256) void scale_by_clipped_norm_kernel(size_t n, float *x, const float *__restrict__ norm, float max_norm) {
+    const float s = fminf(max_norm / (norm[0] + 1e-6f), 1.0f);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= s;
+}
+
+extern "C" int parc_scale_by_clipped_norm(void *stream, int64_t n, float *x, const float *norm, float max_norm) {
+    if (n < 0 || !x || !norm || !(max_norm > 0.f)) return PARC_EINVAL;
+    if (n == 0) return PARC_OK;
+    size_t blocks = ((size_t)n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(scale_by_clipped_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (size_t)n, x, norm, max_norm);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}
+
+// =============================================================================================
 // K12 observation normalisation: Normalizer.normalize (learning/normalizer.py:60-63)  out = clamp((x - mean) / std, -clip, clip)
 // in one pass (torch: subtract, divide, clamp = three passes).  Same fp32 operations, so the result is bit-identical.
 // =============================================================================================

@@ -108,7 +108,12 @@ class MPOptimizer:
             # the gradient norm of the flat buffer == norm over model parameters (all trainable params are in it)
             max_norm = kwargs["max_norm"]
             norm = torch.linalg.vector_norm(self._flat_grad)
-            self._flat_grad *= torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+            if self._flat_grad.is_cuda and self._flat_grad.dtype == torch.float32:
+                from .. import _hip
+                _hip.check(_hip.lib().parc_scale_by_clipped_norm(_hip.stream(), self._flat_grad.numel(), _hip.ptr(self._flat_grad),
+                                                                 _hip.ptr(norm.reshape(1)), float(max_norm)), "parc_scale_by_clipped_norm")
+            else:
+                self._flat_grad *= torch.clamp(max_norm / (norm + 1e-6), max=1.0)
         self._optimizer.step()
         if mp_util.enable_mp() and self._cadence == "minibatch" and self._steps % self.CHECK_SYNC_STEPS == 0:
             assert self._check_synced(), "Network parameters desynchronized"

@@ -642,3 +642,14 @@ def test_g13_penetration_loss_gradients(km):
     # without requires_grad the pose goes through the FK kernels and gives the same value
     loss_k = terrain_util.motion_frames_hf_sdf_loss(T(g["loss_frames"]), pts, hf2, mbc2, T(g["civ_dxdy"]), km)
     close(loss_k, loss.detach().cpu().numpy(), atol=1e-5, rtol=1e-4)
+
+
+def test_clipped_norm_scale_matches_torch_expression():
+    from parc_amd import _hip
+    torch.manual_seed(2)
+    for scale in (0.01, 100.0):
+        x = torch.randn(100003, device=DEV) * scale
+        ref = x * torch.clamp(1.0 / (torch.linalg.vector_norm(x) + 1e-6), max=1.0)
+        nrm = torch.linalg.vector_norm(x).reshape(1)
+        _hip.check(_hip.lib().parc_scale_by_clipped_norm(_hip.stream(), x.numel(), _hip.ptr(x), _hip.ptr(nrm), 1.0), "scale")
+        assert torch.equal(x, ref)
