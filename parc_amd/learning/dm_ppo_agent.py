@@ -534,16 +534,17 @@ class DMPPOAgent(torch.nn.Module):
         loss, out = rl_util.ppo_loss(a_dist.mean, logstd[0], pred, norm_a, batch["a_logp"], batch["adv"], batch["rand_action_mask"],
                                      batch["tar_val"], self._ppo_clip_ratio, self._action_bound_weight, self._action_entropy_weight,
                                      self._action_reg_weight, self._critic_loss_weight, 20.0, self._critic_loss_type != "L2")
-        info = {"critic_loss": out[1], "clip_frac": out[3], "imp_ratio": out[4], "actor_loss": out[2]}
+        # the logged scalars are slots of ONE device vector: _update_model accumulates that vector (one add per minibatch instead of
+        # one per scalar) and names the slots at the end
+        slots = {"loss": 0, "critic_loss": 1, "actor_loss": 2, "clip_frac": 3, "imp_ratio": 4}
         if self._action_bound_weight != 0:
-            info["action_bound_loss"] = out[5]
+            slots["action_bound_loss"] = 5
         if self._action_entropy_weight != 0:
-            info["action_entropy"] = out[6]
+            slots["action_entropy"] = 6
         if self._action_reg_weight != 0:
-            info["action_reg_loss"] = out[7]
+            slots["action_reg_loss"] = 7
         self._nan_flag |= torch.isnan(out[0]).to(torch.int32)      # NaN trap, checked once per iteration
-        info["loss"] = loss
-        return info
+        return {"loss": loss, "_packed": out, "_slots": slots}
 
     def _update_model(self):
         self.train()
@@ -560,11 +561,19 @@ class DMPPOAgent(torch.nn.Module):
                     self._optimizer.step(info["loss"], model=self._model, max_norm=self._max_grad_norm)
                 else:
                     self._optimizer.step(info["loss"])
-                for k, v in info.items():
-                    v = v.detach()
-                    acc[k] = acc[k] + v if k in acc else v.clone()
+                if "_packed" in info:
+                    slots = info["_slots"]
+                    v = info["_packed"].detach()
+                    acc["_packed"] = acc["_packed"] + v if "_packed" in acc else v.clone()
+                else:
+                    for k, v in info.items():
+                        v = v.detach()
+                        acc[k] = acc[k] + v if k in acc else v.clone()
             self._optimizer.end_epoch()          # exchange point of the per-epoch cadence (optimizer: grad_allreduce "epoch")
         steps = self._update_epochs * num_batches
+        if "_packed" in acc:
+            packed = acc.pop("_packed") / steps
+            return {k: packed[i] for k, i in slots.items()}
         return {k: v / steps for k, v in acc.items()}
 
     def _train_iter(self):
