@@ -285,7 +285,7 @@ def main():
     if rank == 0:
         total_env_steps = world * N * T * args.steps
         out = {
-            "metric": "env-steps/sec (whole node), humanoid tracker training loop",
+            "metric": "env-steps/sec (whole node), {} envs/GPU humanoid tracker at 1/2/4/8 MI355X".format(N),      # BASELINE.json's metric
             "value": total_env_steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
