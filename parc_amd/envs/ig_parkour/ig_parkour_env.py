@@ -10,6 +10,7 @@ per step (include/parc_hip.h parc_track_post_step).
 Only the DeepMimic sub-environment (``fraction_dm_envs: 1.0``, the tracker default) is implemented; the
 motion-generator sub-env (mgdm) is outside the hot path.
 """
+import math
 import os
 import pickle
 import time
@@ -454,6 +455,7 @@ class IGParkourEnv(base_env.BaseEnv):
 
     def set_writing_env_state(self, env_id, val):
         self._writing_env_state[env_id] = val
+        self._writing_dirty = True                # the device mask is refreshed once, at the next write_agent_states
 
     def set_env_success_state(self, env_id, val):
         self._env_success_state[env_id] = val
@@ -461,13 +463,15 @@ class IGParkourEnv(base_env.BaseEnv):
     def get_env_success_states(self):
         return self._env_success_state
 
+    # ---- motion recording (ig_parkour_env.py:895-995,1594-1620 of the reference).  The reference appends every env's state to
+    # Python lists on every step (a loop over all envs with device reads); here the states are scattered into device buffers
+    # [steps, env, ...] with a per-env write row, and the host only touches the envs that finish (one small transfer per step).
     def build_agent_states_dict(self, name_suffix="", record_obs=False):
         obs_shapes = self._compute_obs(ret_obs_shapes=True) if record_obs else None
         self._dm_agent_motion = []
         for _ in range(self._num_envs):
-            d = {"fps": int(self._control_freq), "loop_mode": "CLAMP", "frames": [], "contacts": []}
+            d = {"fps": int(self._control_freq), "loop_mode": "CLAMP"}
             if record_obs:
-                d["obs"] = []
                 d["obs_shapes"] = OrderedDict((k, {"use_normalizer": v["use_normalizer"], "shape": tuple(v["shape"])})
                                               for k, v in obs_shapes.items())
             self._dm_agent_motion.append(d)
@@ -477,6 +481,19 @@ class IGParkourEnv(base_env.BaseEnv):
         self._env_success_state = [False] * self._num_envs
         self._save_motion_name_suffix = name_suffix
         os.makedirs(self._output_motion_dir, exist_ok=True)
+        N, dev = self._num_envs, self._device
+        # rows: the longest clip at the control rate + the frame written at reset + slack; row `cap` is a dump row for envs that
+        # are not recording (so the scatter needs no compaction)
+        cap = int(math.ceil(float(self._dm_env._motion_lib._motion_lengths.max().item()) * self._control_freq)) + 8
+        if getattr(self, "_rec_cap", -1) != cap or self._rec_has_obs != record_obs:
+            self._rec_frames = torch.empty((cap + 1, N, 34), dtype=torch.float32, device=dev)
+            self._rec_contacts = torch.empty((cap + 1, N, self._char_contact_forces.shape[1]), dtype=torch.float32, device=dev)
+            self._rec_obs = torch.empty((cap + 1, N, self._obs_buf.shape[1]), dtype=torch.float32, device=dev) if record_obs else None
+            self._rec_cap, self._rec_has_obs = cap, record_obs
+        self._rec_len = torch.zeros(N, dtype=torch.long, device=dev)
+        self._rec_arange = torch.arange(N, device=dev)
+        self._writing_dev = torch.ones(N, dtype=torch.bool, device=dev)
+        self._writing_dirty = False
 
     def _get_char_state_all(self):
         """[N, 34] frames (root pos | root exp map | dofs) and [N, 15] binary contacts of every env in one go."""
@@ -493,41 +510,45 @@ class IGParkourEnv(base_env.BaseEnv):
     def write_agent_states(self):
         if not self.is_writing_agent_states():
             return
+        if self._writing_dirty:
+            self._writing_dev = torch.tensor(self._writing_env_state, dtype=torch.bool, device=self._device)
+            self._writing_dirty = False
         frames, contacts = self._get_char_state_all()
-        frames, contacts = frames.cpu().numpy(), contacts.cpu().numpy()
-        obs = self._obs_buf.cpu().numpy() if self._record_obs else None
-        done = self._done_buf.cpu().numpy()
-        dm = self._dm_env
-        mlen = dm._motion_lib._motion_lengths[dm._motion_ids].cpu().numpy()
-        mtime = dm._get_motion_times().cpu().numpy()
-        any_writing = False
-        for e in range(self._num_envs):
-            if not self._writing_env_state[e]:
-                continue
-            any_writing = True
-            rec = self._dm_agent_motion[e]
-            rec["frames"].append(frames[e].copy())
-            rec["contacts"].append(contacts[e].copy())
-            if self._record_obs:
-                rec["obs"].append(obs[e].copy())
-            if done[e] == base_env.DoneFlags.FAIL.value:
+        w = self._writing_dev
+        row = torch.where(w & (self._rec_len < self._rec_cap), self._rec_len, torch.full_like(self._rec_len, self._rec_cap))
+        ar = self._rec_arange
+        self._rec_frames[row, ar] = frames
+        self._rec_contacts[row, ar] = contacts
+        if self._record_obs:
+            self._rec_obs[row, ar] = self._obs_buf
+        self._rec_len += w
+        fin = w & (self._done_buf == base_env.DoneFlags.FAIL.value)
+        self._writing_dev = w & ~fin
+        n_fin, n_writing = torch.stack([fin.sum(), self._writing_dev.sum()]).tolist()      # the step's one host read
+        if n_fin > 0:
+            dm = self._dm_env
+            ids = fin.nonzero().flatten()
+            mlen = dm._motion_lib._motion_lengths[dm._motion_ids[ids]].tolist()
+            mtime = dm._get_motion_times()[ids].tolist()
+            for k, e in enumerate(ids.tolist()):
                 self._writing_env_state[e] = False
                 name = dm.get_env_motion_name(e)
-                if not self._bypass_record_fail and mtime[e] < mlen[e] - self._timestep * 2.0:
+                if not self._bypass_record_fail and mtime[k] < mlen[k] - self._timestep * 2.0:
                     print("env", e, "failed to track motion", name)
                     continue
                 self._env_success_state[e] = True
                 self.save_agent_states_to_file(e, name + self._save_motion_name_suffix)
-        self.set_write_agent_states_flag(any_writing)
+        self.set_write_agent_states_flag(n_writing > 0)
 
     def save_agent_states_to_file(self, env_id, output_motion_name=None):
         rec = self._dm_agent_motion[env_id]
-        frames = np.stack(rec["frames"]).astype(np.float32)
+        T = min(int(self._rec_len[env_id].item()), self._rec_cap)
+        frames = self._rec_frames[:T, env_id].cpu().numpy().astype(np.float32)
         frames[:, 0:2] += self._env_offsets[env_id, 0:2].cpu().numpy()
         out = dict(rec)
-        out["contacts"] = np.stack(rec["contacts"]).astype(np.float32)
+        out["contacts"] = self._rec_contacts[:T, env_id].cpu().numpy().astype(np.float32)
         if self._record_obs:
-            out["obs"] = np.stack(rec["obs"]).astype(np.float32)
+            out["obs"] = self._rec_obs[:T, env_id].cpu().numpy().astype(np.float32)
         ter = self._dm_env._terrain
         pad = round(1.0 // ter.dxdy[0].item()) * ter.dxdy[0].item()
         sliced, frames = terrain_util.slice_terrain_around_motion(frames, ter, padding=pad)

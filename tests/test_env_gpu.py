@@ -431,3 +431,48 @@ def test_step_clock_rides_in_the_simulator_launch(env):
         assert torch.equal(env._time_buf, env._timestep_buf.to(torch.float32) * torch.tensor(env._timestep, dtype=torch.float32, device=DEV))
     finally:
         _hip.lib().parc_tune_sim_variant(1)
+
+
+def test_device_recorder_equals_per_step_host_lists(env, tmp_path):
+    """IGParkourEnv.write_agent_states keeps the recorded clips in device buffers with a per-env write row; the result must be
+    what the reference's scheme produces: per env, the state of every step up to and including the one on which it failed."""
+    from parc_amd.envs.base_env import DoneFlags
+    env._output_motion_dir = str(tmp_path)
+    old_bypass = env._bypass_record_fail
+    env._bypass_record_fail = False
+    try:
+        torch.manual_seed(4)
+        env.reset()
+        env.build_agent_states_dict("_t", record_obs=True)
+        ref = [{"frames": [], "contacts": [], "obs": [], "on": True} for _ in range(96)]
+
+        def host_side():
+            f, c = env._get_char_state_all()
+            f, c, o, d = f.cpu().numpy(), c.cpu().numpy(), env._obs_buf.cpu().numpy(), env._done_buf.cpu().numpy()
+            for e in range(96):
+                if ref[e]["on"]:
+                    ref[e]["frames"].append(f[e].copy()); ref[e]["contacts"].append(c[e].copy()); ref[e]["obs"].append(o[e].copy())
+                    if d[e] == DoneFlags.FAIL.value:
+                        ref[e]["on"] = False
+        host_side()
+        env.write_agent_states()
+        act = torch.randn((96, 28), device=DEV) * 0.5
+        for _ in range(30):
+            if not env.is_writing_agent_states():
+                break
+            # step() records by itself while the flag is set; take the host-side copy of the same state right after
+            _, _, done, _ = env.step(act)
+            host_side()
+            env.reset(done.nonzero().flatten())
+        lens = env._rec_len.cpu().numpy()
+        assert any(not r["on"] for r in ref)                                   # some envs did fail within the window
+        for e in range(96):
+            T = len(ref[e]["frames"])
+            assert lens[e] == T, (e, lens[e], T)
+            assert np.array_equal(env._rec_frames[:T, e].cpu().numpy(), np.stack(ref[e]["frames"]))
+            assert np.array_equal(env._rec_contacts[:T, e].cpu().numpy(), np.stack(ref[e]["contacts"]))
+            assert np.array_equal(env._rec_obs[:T, e].cpu().numpy(), np.stack(ref[e]["obs"]))
+            assert env.is_writing_env_state(e) == ref[e]["on"]
+    finally:
+        env._bypass_record_fail = old_bypass
+        env.set_write_agent_states_flag(False)
