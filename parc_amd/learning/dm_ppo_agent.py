@@ -696,12 +696,13 @@ class DMPPOAgent(torch.nn.Module):
         successful = list(env.get_env_success_states())
         counts = [sum(successful)]
         dm = env.get_dm_env()
+        clip_len = dm._motion_lib._motion_lengths.cpu().numpy()            # one transfer, not one per env and retry
+        M = dm._motion_lib.num_motions()
         for frac in [0.1, 0.2, 0.3, 0.4, 0.5]:
             if all(successful):
                 break
             for e in range(N):
-                mid = e % dm._motion_lib.num_motions()
-                if (1.0 - frac) * dm._motion_lib._motion_lengths[mid].item() < 2.0:
+                if (1.0 - frac) * float(clip_len[e % M]) < 2.0:
                     successful[e] = True
             dm.set_motion_start_time_fraction(torch.full([N], frac, dtype=torch.float32, device=self._device))
             helper(prev_successful=successful)
