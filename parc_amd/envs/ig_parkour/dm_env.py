@@ -331,9 +331,13 @@ class DeepMimicEnv:
         fr = self._motion_id_fail_rates
         top, _ = torch.sort(fr, descending=True)
         q = torch.quantile(top, self._fail_rate_quantiles)
-        info = {"MOTION_FAIL_RATES": {names[i]: fr[i].item() * 100.0 for i in range(len(names))},
-                "Misc": {"top fail rate": top[0].item() * 100.0}}
-        for i in range(self._fail_rate_quantiles.shape[0]):
-            key = "Fail Rate at " + str(round(self._fail_rate_quantiles[i].item() * 100.0)) + "% Quantile"
-            info["Misc"][key] = q[i].item() * 100.0
+        # one transfer for everything (the reference reads a scalar per clip)
+        nq = int(self._fail_rate_quantiles.shape[0])
+        vals = torch.cat([fr.to(torch.float32), top[0:1], q.to(torch.float32), self._fail_rate_quantiles.to(torch.float32)]).tolist()
+        M = len(names)
+        info = {"MOTION_FAIL_RATES": {names[i]: vals[i] * 100.0 for i in range(M)},
+                "Misc": {"top fail rate": vals[M] * 100.0}}
+        for i in range(nq):
+            key = "Fail Rate at " + str(round(vals[M + 1 + nq + i] * 100.0)) + "% Quantile"
+            info["Misc"][key] = vals[M + 1 + i] * 100.0
         return info
