@@ -39,3 +39,24 @@ for _ in range(5):
             pass
 old_ms = (time.time() - t0) / 5 * 1e3
 print("envs %d: recorder %.2f ms / step (device buffers, one host read), per-env host lists %.1f ms / step" % (N, new_ms, old_ms))
+
+# the record-mode loop of DMPPOAgent.record_motions (deterministic policy -> step -> record -> reset of finished envs), episodes kept
+# alive so that no file is written inside the timed region
+agent = workloads.build_agent(env, dev, mp_scale_rollout=False)
+agent.eval()
+from parc_amd.learning.dm_ppo_agent import AgentMode
+agent.set_mode(AgentMode.TEST)
+env._never_done = True
+agent._curr_obs, agent._curr_info = env.reset()
+env.build_agent_states_dict("_probe", record_obs=True)
+env.write_agent_states()
+for timed in (False, True):
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(30):
+        action, _ = agent._decide_action(agent._curr_obs, agent._curr_info)
+        _, _, done, _ = env.step(action)
+        agent._curr_obs, agent._curr_info = agent._reset_done_envs(done)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / 30
+print("record-mode loop: %.2f ms / step = %.2f M env-steps/s (policy + simulator + observation + recording + reset check)" % (dt * 1e3, N / dt / 1e6))
