@@ -78,6 +78,63 @@ def cpu_baseline(env, clips, tiled, budget_s=12.0):
                       "no physics, no policy: the reference's physics is the GPU-only Isaac Gym binary".format(k, n)}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a child torch.distributed.run job and
+    relay rank 0's JSON line.  The parent makes no GPU call (device_count() does not initialise the GPU on this image), and it
+    starts a child rather than replacing itself."""
+    import socket
+    import subprocess
+    backend = os.environ.get("PARC_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and not args.launch_check and n_dev < args.gpus:
+        sys.stderr.write("bench.py: --gpus {} needs {} visible GPUs, found {} (refusing to report a {}-GPU number from fewer)\n".format(
+            args.gpus, args.gpus, n_dev, args.gpus))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"n_gpus"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc != 0 or line is None:
+        sys.stderr.write("bench.py: the {}-rank job failed (exit code {})\n".format(args.gpus, rc))
+        return rc or 1
+    print(line)
+    return 0
+
+
+def launch_check(rank, world, backend):
+    """The launcher's plumbing without the workload: rendezvous, barrier, MAX over ranks of a timer, one line on rank 0."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+        torch.distributed.barrier()
+    t0 = time.time()
+    time.sleep(0.01 * (rank + 1))
+    tt = torch.tensor([time.time() - t0], dtype=torch.float64)
+    ranks = torch.ones(1, dtype=torch.float64)
+    if world > 1:
+        if torch.distributed.get_backend() == "nccl":
+            tt, ranks = tt.cuda(), ranks.cuda()
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(ranks)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": int(ranks.item()), "max_rank_seconds": tt.item(),
+                          "backend": torch.distributed.get_backend() if world > 1 else None}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,20 +145,31 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grad-allreduce", default="minibatch", choices=["minibatch", "epoch"],
                     help="minibatch = the reference's cadence (default); epoch = one parameter exchange per PPO epoch (north-star)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, rendezvous, barrier and MAX-reduce a timer (no GPU work, no metric): checks the launcher")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))          # `python bench.py --gpus N`: this process only starts the N ranks (no GPU call here)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus {} but WORLD_SIZE={}: launch with torch.distributed.run --nproc-per-node {}".format(
+            args.gpus, world, args.gpus))
+    backend = os.environ.get("PARC_DIST_BACKEND", "nccl")
+    if args.launch_check:
+        return launch_check(rank, world, backend)
     n_dev = torch.cuda.device_count()
-    dev = "cuda:{}".format(local_rank % max(n_dev, 1))     # (rehearsal on a 1-GPU box: ranks share the device, gloo backend)
+    if n_dev < world and backend == "nccl":
+        sys.exit("bench.py: --gpus {} needs {} visible GPUs, found {}".format(args.gpus, world, n_dev))
+    dev = "cuda:{}".format(local_rank % max(n_dev, 1))     # (gloo rehearsal on a 1-GPU box: ranks share the device)
     torch.cuda.set_device(dev)
     from parc_amd import _hip, workloads
     from parc_amd.util import mp_util
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(os.environ.get("PARC_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     mp_util.init(rank, world, dev)
     torch.manual_seed(0 + 41 * rank)       # run.py:90 of the reference
     np.random.seed(41 * rank)

@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from .. import _hip
+from ..util import torch_util
 
 
 class JointType(enum.Enum):
@@ -384,25 +385,12 @@ class KinCharModel:
         q = torch.cat([axis / torch.linalg.vector_norm(axis, dim=-1, keepdim=True).clamp(min=1e-9) * half.sin(), half.cos()], dim=-1)
         return q / torch.linalg.vector_norm(q, dim=-1, keepdim=True).clamp(min=1e-9)
 
-    @staticmethod
-    def _quat_mul_torch(a, b):
-        ax, ay, az, aw = a.unbind(-1)
-        bx, by, bz, bw = b.unbind(-1)
-        return torch.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
-                            aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz], dim=-1)
-
-    @staticmethod
-    def _quat_rotate_torch(q, v):
-        qv, qw = q[..., :3], q[..., 3:]
-        t = 2 * torch.cross(qv, v, dim=-1)
-        return v + qw * t + torch.cross(qv, t, dim=-1)
-
     def forward_kinematics_torch(self, root_pos, root_rot, joint_rot):
         """-> body_pos [..., B, 3], body_rot [..., B, 4] with autograd; one composition per tree level"""
         t = self._torch_tables()
         B = self.get_num_joints()
         lead = root_pos.shape[:-1]
-        local = self._quat_mul_torch(self._local_rotation[1:].expand(lead + (B - 1, 4)), joint_rot)       # local_rot * joint_rot
+        local = torch_util.quat_mul(self._local_rotation[1:].expand(lead + (B - 1, 4)), joint_rot)       # local_rot * joint_rot
         pos = [None] * B
         rot = [None] * B
         pos[0], rot[0] = root_pos, root_rot
@@ -410,8 +398,8 @@ class KinCharModel:
             ppos = torch.stack([pos[p] for p in parents.tolist()], dim=-2)
             prot = torch.stack([rot[p] for p in parents.tolist()], dim=-2)
             lt = self._local_translation[bodies].expand(ppos.shape)
-            npos = ppos + self._quat_rotate_torch(prot, lt)
-            nrot = self._quat_mul_torch(prot, local[..., bodies - 1, :])
+            npos = ppos + torch_util.quat_rotate(prot, lt)
+            nrot = torch_util.quat_mul(prot, local[..., bodies - 1, :])
             for k, b in enumerate(bodies.tolist()):
                 pos[b], rot[b] = npos[..., k, :], nrot[..., k, :]
         return torch.stack(pos, dim=-2), torch.stack(rot, dim=-2)

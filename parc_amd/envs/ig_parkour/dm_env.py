@@ -107,12 +107,14 @@ class DeepMimicEnv:
         if not terrain_save_path:
             return
         os.makedirs(os.path.dirname(terrain_save_path) or ".", exist_ok=True)
+        # reference format (dm_env.py:344-354): the SubTerrain and the offsets as torch tensors (its load_terrain calls
+        # set_device / .to on them), the per-clip meshes as numpy arrays; written from the CPU so any host can open it
         cpu_t = self._terrain.torch_copy()
         cpu_t.set_device("cpu")
-        with open(terrain_save_path, "wb") as f:
-            pickle.dump({"terrain": cpu_t.numpy_copy(), "terrains_per_motion": self._terrains_per_motion,
-                         "motion_offsets": self._dm_motion_offsets.cpu().numpy(), "all_terrain_verts": self._all_terrain_verts,
-                         "all_terrain_tris": self._all_terrain_tris}, f)
+        terrain_util.dump_reference_pickle({"terrain": cpu_t, "terrains_per_motion": self._terrains_per_motion,
+                                            "motion_offsets": self._dm_motion_offsets.detach().cpu(),
+                                            "all_terrain_verts": self._all_terrain_verts, "all_terrain_tris": self._all_terrain_tris},
+                                           terrain_save_path)
 
     def load_motion_terrain_file(self, env_config, terrain_save_path):
         """terrain_build_mode "file" (reference :128-186): ONE shared terrain named by the motion YAML's `terrain:` key,
@@ -222,17 +224,21 @@ class DeepMimicEnv:
         return self._all_terrain_verts, self._all_terrain_tris
 
     def load_terrain(self, terrain_save_path):
+        """reference :493-507.  Read with the non-executing reader, so a cache written by the reference itself (device
+        tensors inside) opens too."""
         from ...util import safe_pickle
         data = safe_pickle.load_motion_file_safe(terrain_save_path)
-        t = data["terrain"]
-        if not isinstance(t, dict) or not isinstance(data.get("motion_offsets"), np.ndarray):
+        t, offs = data["terrain"], data.get("motion_offsets")
+        if not isinstance(t, dict) or not isinstance(offs, (np.ndarray, torch.Tensor)):
             raise RuntimeError("{} is not a terrain cache this reader can open without executing it; delete it to "
                                "rebuild".format(terrain_save_path))
         self._terrain = terrain_util.SubTerrain.from_arrays(t["hf"], t["min_point"], t["dxdy"], t.get("hf_mask"), t.get("hf_maxmin"),
                                                             device=self._device)
         self._terrains_per_motion = int(data["terrains_per_motion"])
-        self._dm_motion_offsets = torch.tensor(data["motion_offsets"], dtype=torch.float32, device=self._device)
-        return [], []
+        self._dm_motion_offsets = torch.as_tensor(offs, dtype=torch.float32).to(self._device)
+        self._all_terrain_verts = data.get("all_terrain_verts", [])
+        self._all_terrain_tris = data.get("all_terrain_tris", [])
+        return self._all_terrain_verts, self._all_terrain_tris
 
     def set_tiled(self, hf, min_point, dxdy, motion_offsets):
         """Install an already tiled global heightfield (parc_amd.synthetic.tile_square)."""

@@ -557,6 +557,5 @@ class IGParkourEnv(base_env.BaseEnv):
         if output_motion_name is None:
             output_motion_name = "dm_motion_" + str(env_id).zfill(3)
         path = os.path.join(self._output_motion_dir, output_motion_name + ".pkl")
-        with open(path, "wb") as f:
-            pickle.dump(out, f)
+        terrain_util.dump_reference_pickle(out, path)
         print("wrote motion data to", path, "num frames =", frames.shape[0])

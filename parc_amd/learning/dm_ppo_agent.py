@@ -198,6 +198,13 @@ class DMPPOAgent(torch.nn.Module):
             return (1.0 - l) * self._exp_prob_beg + l * self._exp_prob_end
         return self._exp_prob_beg
 
+    def _set_exp_prob(self, exp_prob):
+        """The annealed exploration probability (ppo_agent.py:97-99) lives in a device scalar that the Bernoulli draw reads.
+        A fill_ with a Python float inside a captured step would bake the capture-time value into the graph, so inside a
+        captured step nothing is written here: _train_step_graph fills the scalar eagerly before every replay."""
+        if not getattr(self, "_in_graph_step", False):
+            self._exp_prob_t.fill_(exp_prob)
+
     def _need_normalizer_update(self):
         return self._sample_count < self._normalizer_samples
 
@@ -214,7 +221,7 @@ class DMPPOAgent(torch.nn.Module):
                 norm_a = dist.sample()
                 mask = torch.ones_like(norm_a[..., 0])
             else:
-                self._exp_prob_t.fill_(exp_prob)                       # device scalar: value changes do not stale a captured graph
+                self._set_exp_prob(exp_prob)
                 mask = torch.bernoulli(self._exp_prob_t.expand(obs.shape[0], 1))
                 norm_a = torch.where(mask == 1.0, dist.sample(), dist.mode)
                 mask = mask.squeeze(-1)
@@ -238,7 +245,7 @@ class DMPPOAgent(torch.nn.Module):
                     self._ones_mask = torch.ones(n, dtype=torch.float32, device=mean.device)
                 mask = self._ones_mask                     # read-only downstream (action head, record): one persistent tensor
             else:
-                self._exp_prob_t.fill_(exp_prob)
+                self._set_exp_prob(exp_prob)
                 mask = torch.bernoulli(self._exp_prob_t.expand(n, 1)).squeeze(-1).contiguous()
             noise = torch.randn_like(mean)
         else:
@@ -336,6 +343,7 @@ class DMPPOAgent(torch.nn.Module):
         sig = self._env.host_step_signature() if hasattr(self._env, "host_step_signature") else ()
         key = (self._need_normalizer_update(), exp_prob >= 1.0, device_reset) + tuple(sig)
         self._head_t.fill_(eb._buffer_head)
+        self._exp_prob_t.fill_(exp_prob)             # read by the captured Bernoulli draw: the value of THIS step, not of the capture
         g = self._graphs.get(key)
         if g is None:
             if self._graph_warm < 2:                 # library handles / workspaces are created by eager steps first
@@ -712,3 +720,8 @@ class DMPPOAgent(torch.nn.Module):
         Logger.print("Successful motions at 0 percent start time: {} / {}".format(counts[0], N))
         Logger.print("Total successful motions: {}".format(sum(counts)))
         return successful
+
+
+# the reference's class hierarchy base_agent.BaseAgent -> ppo_agent.PPOAgent -> dm_ppo_agent.DMPPOAgent is one class here;
+# parc_amd.install_reference_aliases() maps the three module names to this module
+BaseAgent = PPOAgent = DMPPOAgent

@@ -42,8 +42,6 @@ class _Preprocessor:
         self._points = geom_util.get_char_point_samples(self._char)
 
     def run(self, path):
-        import pickle
-
         import numpy as np
         import torch
 
@@ -59,8 +57,7 @@ class _Preprocessor:
         out = {k: v for k, v in d.items() if isinstance(v, (np.ndarray, int, float, str, bool))}
         out["terrain"] = ter.numpy_copy()
         out["hf_mask_inds"] = [i.cpu() for i in inds]
-        with open(str(path), "wb") as f:
-            pickle.dump(out, f)
+        terrain_util.dump_reference_pickle(out, str(path))
         return True
 
 

@@ -5,7 +5,8 @@ README.md:90-111) is a pickle dict ``{fps, loop_mode, frames, contacts, terrain:
 whose leaves are numpy arrays.  ``pickle.load`` executes whatever the file names; this reader
 never does.  It walks the opcode stream with ``pickletools.genops`` (a pure disassembler), keeps an
 inert stack of records (``Global``, ``Call``, ``Obj``) and afterwards materialises ONLY numpy arrays /
-dtypes / scalars from the raw bytes it finds.  Anything else stays an inert record.
+dtypes / scalars from the raw bytes it finds, and torch tensors through ``torch.load(weights_only=True)``
+of their storage blob.  Anything else stays an inert record.
 
 Use it for files you did not write (e.g. the clips that ship with the reference); files this
 package wrote itself can go through ``pickle`` as the reference does.
@@ -192,6 +193,28 @@ class Unresolved:
         return "Unresolved({})".format(self.what)
 
 
+def _torch_tensor_from(rec):
+    """A tensor written by a plain ``pickle.dump`` (the reference's terrain.pkl cache, dm_env.py:344-354, holds device tensors):
+    ``_rebuild_tensor_v2(_load_from_bytes(blob), offset, size, stride, ...)``.  The blob is a legacy ``torch.save`` stream
+    holding one storage; it is decoded by ``torch.load(weights_only=True)`` (restricted unpickler, data only) onto the CPU,
+    and the view is rebuilt from the recorded offset / size / stride after a bounds check."""
+    import io
+
+    import torch
+    st_rec, offset, size, stride = rec.args[0], rec.args[1], rec.args[2], rec.args[3]
+    if not (isinstance(st_rec, Call) and _is_global(st_rec.func, ("torch.storage",), "_load_from_bytes")
+            and isinstance(st_rec.args[0], (bytes, bytearray))):
+        raise ValueError("unsupported tensor storage record")
+    st = torch.load(io.BytesIO(bytes(st_rec.args[0])), weights_only=True, map_location="cpu")
+    dtype = st.dtype
+    ust = st._untyped_storage if hasattr(st, "_untyped_storage") else st
+    size, stride = tuple(int(v) for v in size), tuple(int(v) for v in stride)
+    last = int(offset) + sum((n - 1) * k for n, k in zip(size, stride)) if all(n > 0 for n in size) else -1
+    if int(offset) < 0 or any(k < 0 for k in stride) or (last + 1) * torch.empty(0, dtype=dtype).element_size() > ust.nbytes():
+        raise ValueError("tensor view outside its storage")
+    return torch.empty(0, dtype=dtype).set_(ust, int(offset), size, stride).clone()
+
+
 def materialize(rec, strict=False):
     """Turn the inert tree into plain python: numpy arrays/scalars, dicts, lists.
 
@@ -211,6 +234,10 @@ def materialize(rec, strict=False):
         if _is_global(rec.func, ("numpy.core.multiarray", "numpy._core.multiarray"), "scalar"):
             dtype = _dtype_from(rec.args[0])
             return np.frombuffer(bytes(rec.args[1]), dtype=dtype)[0]
+        if _is_global(rec.func, ("torch._utils",), "_rebuild_tensor_v2"):
+            return _torch_tensor_from(rec)
+        if _is_global(rec.func, ("torch._utils",), "_rebuild_parameter"):
+            return materialize(rec.args[0], strict)
         if strict:
             raise ValueError("refusing to evaluate {!r}".format(rec.func))
         return Unresolved(repr(rec.func))

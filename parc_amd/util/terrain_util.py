@@ -5,10 +5,15 @@ same field names -- motion pickles embed instances of it, so it must unpickle un
 ``util.terrain_util`` (parc_amd.install_reference_aliases) -- and ``get_local_hf_from_terrain``
 (:1329-1346).  Procedural generators and the voxel-mesh export are "next" rows.
 """
+import contextlib
 import copy
+import pickle
+import sys
 
 import numpy as np
 import torch
+
+from . import torch_util
 
 
 class SubTerrain:
@@ -107,6 +112,40 @@ class SubTerrain:
         self.hf_maxmin = torch.stack([new_max, new_min], dim=-1)
         self.min_point = self.min_point - self.dxdy * p
         self.dims = self.dims + 2 * p
+
+
+# Motion files and the terrain.pkl cache embed SubTerrain instances, and the reference reads them with a plain
+# pickle.load (anim/motion_lib.py:240, envs/ig_parkour/dm_env.py:136,161,496), which resolves the class by the module path
+# stored in the file.  The class therefore names the reference's path, and that path resolves to this module.
+REFERENCE_MODULE = "util.terrain_util"
+SubTerrain.__module__ = REFERENCE_MODULE
+sys.modules.setdefault("util", sys.modules[__name__.rpartition(".")[0]])
+sys.modules.setdefault(REFERENCE_MODULE, sys.modules[__name__])
+
+
+@contextlib.contextmanager
+def reference_pickle_path():
+    """Inside this context ``pickle.dump`` of a SubTerrain always succeeds and writes ``util.terrain_util SubTerrain``,
+    even in a process where another ``util.terrain_util`` (e.g. the reference's own) is already imported."""
+    prev = {k: sys.modules.get(k) for k in ("util", REFERENCE_MODULE)}
+    sys.modules[REFERENCE_MODULE] = sys.modules[__name__]
+    if prev["util"] is None:
+        sys.modules["util"] = sys.modules[__name__.rpartition(".")[0]]
+    try:
+        yield
+    finally:
+        for k, v in prev.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def dump_reference_pickle(obj, path):
+    """Write ``obj`` (a motion dict / terrain cache holding SubTerrain instances) the way the reference does:
+    ``pickle.dump`` with the default protocol, classes under the reference's module names."""
+    with reference_pickle_path(), open(path, "wb") as f:
+        pickle.dump(obj, f)
 
 
 def get_local_hf_from_terrain(xy_points, terrain):
@@ -269,32 +308,10 @@ def points_hf_sdf(points, hf, hf_min_box_center, hf_dxdy, base_z=-10.0, inverted
     return -sd if inverted else sd
 
 
-def _exp_map_to_quat(e):
-    """[..., 3] rotation vectors -> unit quaternions (x, y, z, w); angles below 1e-5 map to the identity
-    (torch_util.exp_map_to_quat of the reference, util/torch_util.py:394-419)."""
-    ang = torch.linalg.vector_norm(e, dim=-1)
-    axis = e / ang.unsqueeze(-1)
-    ang = torch.atan2(torch.sin(ang), torch.cos(ang))
-    big = ang.abs() > 1e-5
-    ang = torch.where(big, ang, torch.zeros_like(ang))
-    zaxis = torch.zeros_like(e)
-    zaxis[..., 2] = 1
-    axis = torch.where(big.unsqueeze(-1), axis, zaxis)
-    half = (ang / 2).unsqueeze(-1)
-    q = torch.cat([axis / torch.linalg.vector_norm(axis, dim=-1).clamp(min=1e-9).unsqueeze(-1) * half.sin(), half.cos()], dim=-1)
-    return q / torch.linalg.vector_norm(q, dim=-1).clamp(min=1e-9).unsqueeze(-1)
-
-
-def _quat_rotate(q, v):
-    qv, qw = q[..., :3], q[..., 3:]
-    t = 2 * torch.cross(qv.expand_as(v), v, dim=-1)
-    return v + qw * t + torch.cross(qv.expand_as(v), t, dim=-1)
-
-
 def _body_points_world(motion_frames, char_model, char_point_samples):
     """frames [..., 34] -> (world positions [..., P, 3] of every sample point, owning body [P]); bodies in order, a body's
     points in the order of its sample tensor."""
-    root_rot = _exp_map_to_quat(motion_frames[..., 3:6])
+    root_rot = torch_util.exp_map_to_quat(motion_frames[..., 3:6])
     if torch.is_grad_enabled() and motion_frames.requires_grad:
         # pose through torch ops so that autograd reaches the frames (KinCharModel.*_torch); values agree with the kernels to fp32 rounding
         joint_rot = char_model.dof_to_rot_torch(motion_frames[..., 6:])
@@ -305,7 +322,7 @@ def _body_points_world(motion_frames, char_model, char_point_samples):
     dev = motion_frames.device
     owner = torch.cat([torch.full((p.shape[0],), b, dtype=torch.int64, device=dev) for b, p in enumerate(char_point_samples)])
     local = torch.cat([p.to(dev) for p in char_point_samples], dim=0)
-    return _quat_rotate(body_rot[..., owner, :], local.expand(body_rot.shape[:-2] + local.shape)) + body_pos[..., owner, :], owner
+    return torch_util.quat_rotate(body_rot[..., owner, :], local.expand(body_rot.shape[:-2] + local.shape)) + body_pos[..., owner, :], owner
 
 
 def motion_frames_hf_sdf_loss(motion_frames, char_point_samples, hf, hf_min_box_center, hf_dxdy, char_model, ret_vis_info=False,

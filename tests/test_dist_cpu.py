@@ -113,3 +113,23 @@ def test_dp_optimizer_and_normalizer_gloo_world2():
         assert torch.allclose(p.detach() - 0.1 * p.grad, w, atol=1e-6)
     assert c0 == 10 and c1 == 10 and torch.allclose(m0, torch.tensor([1.5, 1.5, 0.0])) and torch.equal(m0, m1)
     assert s0 == 3 and s1 == 3
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus N` (how the driver calls it) must run N ranks, not silently one: the launcher path is exercised
+    without GPU work (--launch-check), and a request for more GPUs than are visible fails instead of reporting fewer."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, PARC_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True,
+                         env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    env.pop("PARC_DIST_BACKEND")
+    if not torch.cuda.is_available():
+        bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env, timeout=300)
+        assert bad.returncode != 0 and "needs 8 visible GPUs" in bad.stderr and bad.stdout.strip() == ""

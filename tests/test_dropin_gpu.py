@@ -74,7 +74,36 @@ def test_train_checkpoint_record_through_run_main(tmp_path):
     assert rec["obs"].shape == (T, 1312) and rec["terrain"]["hf"].ndim == 2
     assert list(rec["obs_shapes"].keys()) == ["char_obs", "tar_obs", "tar_contacts", "char_contacts", "hf"]
     assert np.allclose(rec["frames"][0, 0:2], 0.0, atol=1e-5)          # localized on the first frame
+    # both written files are in the REFERENCE's format: the only class they name is util.terrain_util.SubTerrain
+    # (reference readers: anim/motion_lib.py:240 for the clip, envs/ig_parkour/dm_env.py:493-507 for the terrain cache)
+    from test_host_logic import NUMPY_GLOBALS, TORCH_GLOBALS, pickle_globals
+    sub = {("util.terrain_util", "SubTerrain")}
+    assert pickle_globals(os.path.join(env._output_motion_dir, files[0])) - NUMPY_GLOBALS - {("collections", "OrderedDict")} == sub
+    assert pickle_globals(os.path.join(tmp, "terrain.pkl")) - NUMPY_GLOBALS - TORCH_GLOBALS == sub
     # the recorded clip is itself a valid motion file: it loads back into a MotionLib
     from parc_amd.anim.motion_lib import MotionLib
     ml = MotionLib(os.path.join(env._output_motion_dir, files[0]), env._kin_char_model, "cuda:0", contact_info=True)
     assert ml.num_motions() == 1 and abs(ml._motion_lengths[0].item() - (T - 1) / 30.0) < 1e-5
+
+
+def test_bench_two_ranks_from_a_plain_invocation():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's call): the script starts the two ranks itself and rank 0
+    reports n_gpus 2.  On this one-GPU box the ranks share the device over gloo (PARC_DIST_BACKEND); the nccl path needs 2 GPUs."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, PARC_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--envs", "64", "--steps", "1", "--warmup", "1"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
+    assert abs(line["value"] - 2 * 64 * 32 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    if torch.cuda.device_count() < 8:
+        env.pop("PARC_DIST_BACKEND")
+        bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--envs", "64", "--steps", "1"],
+                             capture_output=True, text=True, env=env, timeout=300)
+        assert bad.returncode != 0 and bad.stdout.strip() == ""

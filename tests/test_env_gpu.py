@@ -174,6 +174,35 @@ def test_graph_rollout_matches_eager_bookkeeping(env):
     assert np.isfinite(info["mean_return"]) and len(agent._graphs) == 1
 
 
+def test_annealed_exploration_probability_reaches_the_captured_step(env):
+    """ppo_agent.py:97-99: the exploration probability anneals with the sample count.  The captured rollout step must draw its
+    Bernoulli mask with the CURRENT probability, not the one of the step it was captured on."""
+    from parc_amd import workloads
+    T = 16
+    agent = workloads.build_agent(env, DEV, steps_per_iter=T, update_epochs=1, batch_size=2, exp_prob_beg=0.9, exp_prob_end=0.1,
+                                  exp_anneal_samples=1000.0)
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    agent._sample_count = 0                     # exp_prob 0.9: two eager steps, capture, replays
+    agent._rollout_train(T)
+    agent._exp_buffer.reset()
+    torch.cuda.synchronize()
+    assert len(agent._graphs) == 1
+    m_hi = agent._exp_buffer.get_data("rand_action_mask")[4:T].mean().item()
+    agent._sample_count = 1000                  # annealed to 0.1: same graph key (< 1), replays only
+    agent._rollout_train(T)
+    torch.cuda.synchronize()
+    assert len(agent._graphs) == 1
+    m_lo = agent._exp_buffer.get_data("rand_action_mask").mean().item()
+    n = 96 * (T - 4)
+    assert abs(m_hi - 0.9) < 5 * (0.09 / n) ** 0.5 + 1e-3, m_hi
+    assert abs(m_lo - 0.1) < 5 * (0.09 / (96 * T)) ** 0.5 + 1e-3, m_lo
+    # masked-out samples carry the mode: their action equals the un-normalised mean, so the log-probability is the maximum
+    lp = agent._exp_buffer.get_data("a_logp")
+    mk = agent._exp_buffer.get_data("rand_action_mask")
+    assert torch.all(lp[mk == 0] >= lp.max() - 1e-4)
+
+
 def _snapshot(env):
     c = env._core
     names = ["root_state", "dof_state", "rigid_body_state", "contact_forces", "motion_ids", "motion_terrain_ids", "motion_time_offsets",

@@ -313,3 +313,155 @@ def test_kernarg_offsets_of_post_step_kernel_match_code_object():
     import check_kernarg_offsets as cko
     meta = [(o, s) for o, s, k in cko.metadata_offsets() if k == "by_value"][:5]
     assert meta == cko.expected_offsets()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Files written for the reference's readers, and the module names the reference's scripts import
+# ---------------------------------------------------------------------------------------------------------------
+NUMPY_GLOBALS = {("numpy._core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+                 ("numpy", "dtype"), ("numpy._core.multiarray", "scalar"), ("numpy.core.multiarray", "scalar")}
+TORCH_GLOBALS = {("torch._utils", "_rebuild_tensor_v2"), ("torch.storage", "_load_from_bytes"), ("collections", "OrderedDict")}
+
+
+def pickle_globals(path):
+    """Every class / function a pickle file names (GLOBAL and STACK_GLOBAL), found by disassembly."""
+    import pickletools
+    out, strings = set(), []
+    with open(path, "rb") as f:
+        data = f.read()
+    for op, arg, _ in pickletools.genops(data):
+        if op.name == "GLOBAL":
+            out.add(tuple(arg.split(" ")))
+        elif op.name in ("SHORT_BINUNICODE", "BINUNICODE", "UNICODE"):
+            strings.append(arg)
+        elif op.name == "STACK_GLOBAL":
+            out.add((strings[-2], strings[-1]))
+        elif op.name in ("BINGET", "LONG_BINGET"):
+            strings.append(None)          # a memoised string: resolved below through the inert loader instead
+    if any(None in g for g in out):
+        from parc_amd.util import safe_pickle
+        out = set()
+
+        def walk(r):
+            if isinstance(r, safe_pickle.Global):
+                out.add((r.module, r.name))
+            elif isinstance(r, safe_pickle.Call):
+                walk(r.func), walk(r.args), walk(r.state)
+            elif isinstance(r, safe_pickle.Obj):
+                walk(r.cls), walk(r.args), walk(r.state)
+            elif isinstance(r, dict):
+                for k, v in r.items():
+                    walk(k), walk(v)
+            elif isinstance(r, (list, tuple)):
+                for v in r:
+                    walk(v)
+        walk(safe_pickle.load_inert(data))
+    return out
+
+
+_FAKE_REFERENCE_READER = r"""
+import pickle, sys, types
+# stands for the reference's own util/terrain_util.py in a process that has never heard of parc_amd
+util = types.ModuleType("util"); util.__path__ = []
+tu = types.ModuleType("util.terrain_util")
+class SubTerrain:
+    pass
+SubTerrain.__module__ = "util.terrain_util"
+tu.SubTerrain = SubTerrain
+sys.modules["util"] = util; sys.modules["util.terrain_util"] = tu
+with open(sys.argv[1], "rb") as f:
+    d = pickle.load(f)
+t = d["terrain"]
+assert type(t) is SubTerrain, type(t)
+assert not any(m.startswith("parc_amd") for m in sys.modules), "reading the file pulled parc_amd in"
+print(type(t.hf).__module__, tuple(t.hf.shape), sorted(t.__dict__))
+"""
+
+
+def test_written_files_name_only_reference_classes(tmp_path):
+    """A recorded clip / terrain cache must unpickle in the REFERENCE (anim/motion_lib.py:240, dm_env.py:493-507): the only
+    non-numpy / non-torch class a file may name is util.terrain_util.SubTerrain, and a plain pickle.load in a process
+    without parc_amd must rebuild it."""
+    import subprocess
+    import sys
+    from parc_amd.util import terrain_util
+    assert terrain_util.SubTerrain.__module__ == "util.terrain_util"
+    ter = terrain_util.SubTerrain("terrain", 6, 5, 0.4, 0.4, -1.0, 2.0, device="cpu")
+    clip = {"fps": 30, "loop_mode": "CLAMP", "frames": np.zeros((7, 34), np.float32), "contacts": np.ones((7, 15), np.float32),
+            "terrain": ter.numpy_copy()}
+    p = str(tmp_path / "clip.pkl")
+    terrain_util.dump_reference_pickle(clip, p)
+    g = pickle_globals(p)
+    assert ("util.terrain_util", "SubTerrain") in g and g - NUMPY_GLOBALS == {("util.terrain_util", "SubTerrain")}, g
+    out = subprocess.run([sys.executable, "-c", _FAKE_REFERENCE_READER, p], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[0] == "numpy" and "(6, 5)" in out.stdout
+    # the terrain cache of the `square` / `wide` build modes: torch tensors inside, like the reference's (dm_env.py:344-354)
+    e, _ = _dm_env_cpu("wide", tmp_path, R=2)
+    cache = str(tmp_path / "terrain.pkl")
+    e.build_terrain({"dm": {"heightmap": {"horizontal_scale": 0.4, "padding": 0.8}}}, cache)
+    g = pickle_globals(cache)
+    assert g - NUMPY_GLOBALS - TORCH_GLOBALS == {("util.terrain_util", "SubTerrain")}, g
+    out = subprocess.run([sys.executable, "-c", _FAKE_REFERENCE_READER, cache], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[0] == "torch"            # reference load_terrain calls .set_device / .to on these
+    # ... and it also works while a foreign util.terrain_util is registered in THIS process (the writer swaps it in)
+    import sys as _sys
+    import types
+    prev = _sys.modules.get("util.terrain_util")
+    _sys.modules["util.terrain_util"] = types.ModuleType("util.terrain_util")
+    try:
+        terrain_util.dump_reference_pickle(clip, p)
+        assert _sys.modules["util.terrain_util"] is not _sys.modules["parc_amd.util.terrain_util"]
+    finally:
+        _sys.modules["util.terrain_util"] = prev
+    assert ("util.terrain_util", "SubTerrain") in pickle_globals(p)
+
+
+def test_reference_module_names_resolve_strictly():
+    """What run.py:7-12, parc_3_tracker.py:1-6 and parc_4_phys_record.py:1-6 import must resolve after
+    install_reference_aliases(strict=True) in a fresh interpreter; a missing alias is an error, not a skip."""
+    import subprocess
+    import sys
+    code = r"""
+import parc_amd
+parc_amd.install_reference_aliases(strict=True)
+import envs.env_builder as env_builder
+import learning.agent_builder as agent_builder
+import util.arg_parser as arg_parser
+from util.logger import Logger
+import util.mp_util as mp_util
+import util.util as util
+from PARC.util.create_dataset import create_dataset_yaml_from_config
+import util.torch_util as torch_util, util.terrain_util as terrain_util, util.geom_util, anim.kin_char_model, anim.motion_lib
+import learning.base_agent as base_agent, learning.ppo_agent, learning.dm_ppo_agent, learning.experience_buffer
+assert callable(env_builder.build_env) and callable(agent_builder.build_agent) and callable(create_dataset_yaml_from_config)
+assert base_agent.AgentMode.TRAIN.value == 0 and hasattr(torch_util, "quat_rotate") and hasattr(terrain_util, "SubTerrain")
+for name in parc_amd._ALIASES:
+    __import__(name)
+parc_amd._ALIASES["util.no_such_module"] = "util.no_such_module"
+try:
+    parc_amd.install_reference_aliases()
+except ModuleNotFoundError:
+    print("strict ok")
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=REPO)
+    assert out.returncode == 0 and "strict ok" in out.stdout, out.stderr
+
+
+def test_torch_util_matches_reference_fixture():
+    """parc_amd/util/torch_util.py (served as util.torch_util) against fixture G1 (reference util/torch_util.py on CPU)."""
+    from parc_amd.util import torch_util as tu
+    z = golden("g1_quat")
+    t = lambda k: torch.tensor(z[k])
+    chk = lambda got, k, tol=2e-6: np.testing.assert_allclose(got.numpy(), z[k], atol=tol, rtol=0)
+    chk(tu.quat_mul(t("a"), t("b")), "quat_mul")
+    chk(tu.quat_rotate(t("a"), t("v")), "quat_rotate")
+    chk(tu.exp_map_to_quat(t("exp_map")), "exp_map_to_quat")
+    chk(tu.quat_to_exp_map(t("a")), "quat_to_exp_map", 1e-5)
+    chk(tu.axis_angle_to_quat(t("axis"), t("angle")), "axis_angle_to_quat")
+    chk(tu.quat_to_tan_norm(t("a")), "quat_to_tan_norm")
+    chk(tu.slerp(t("a"), t("b"), t("blend")), "slerp", 1e-5)
+    chk(tu.calc_heading(t("a")), "calc_heading", 1e-5)
+    chk(tu.calc_heading_quat_inv(t("a")), "calc_heading_quat_inv", 1e-5)
+    chk(tu.quat_diff_angle(t("a"), t("b")), "quat_diff_angle", 2e-5)
