@@ -7,6 +7,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     s = socket.socket()
