@@ -107,7 +107,9 @@ __global__ __launch_bounds__(128) void ppo_reduce_kernel(int B, int A, int nblk,
     }
     __syncthreads();
     const float msum = s[0];
-    const float cnt = fmaxf(msum, 1.0f);
+    // no random-action sample in the batch: the reference takes means over an empty selection, which are NaN, and its NaN trap
+    // then stops the run (ppo_agent.py:242-252).  Dividing by the raw count reproduces that (0/0) instead of hiding it.
+    const float cnt = msum;
     const float critic_loss = s[1] / (float)B;
     float sum_logstd = 0.f;
     for (int j = 0; j < A; ++j) sum_logstd += logstd[j];

@@ -24,7 +24,7 @@ from ...anim import kin_char_model
 from ...gym_spaces import Box
 from ...sim_model import SimModel, action_bounds_pd
 from ...tracker_core import TrackerConfig, TrackerCore
-from ...util import geom_util, terrain_util
+from ...util import geom_util, terrain_util, torch_util
 from .. import base_env
 from . import dm_env
 
@@ -412,9 +412,7 @@ class IGParkourEnv(base_env.BaseEnv):
         bp, br = km.forward_kinematics(self._char_root_pos.contiguous(), self._char_root_rot.contiguous(), jr)
         rbp, rbr = km.forward_kinematics(c.ref_root_pos, c.ref_root_rot, c.ref_joint_rot)
 
-        def qangle(q0, q1):
-            d = torch.abs(torch.sum(q0 * q1, dim=-1)).clamp(max=1.0)
-            return 2.0 * torch.acos(d)
+        qangle = torch_util.quat_diff_angle          # 2 atan2(|v|, w) of the w >= 0 difference, like the reference (accurate near 0)
         pose_err = qangle(br, rbr).mean(dim=-1)
         root_pos_err = torch.linalg.vector_norm(c.ref_root_pos - self._char_root_pos, dim=-1)
         body_err = torch.linalg.vector_norm((rbp - c.ref_root_pos.unsqueeze(1)) - (bp - self._char_root_pos.unsqueeze(1)), dim=-1).mean(dim=-1)

@@ -39,6 +39,19 @@ for _n in ["trimesh", "gym", "gym.spaces", "isaacgym", "isaacgym.gymapi", "isaac
            "isaacgym.gymutil", "wandb", "tensorboardX", "polyscope", "cv2", "embreex"]:
     _stub(_n)
 sys.modules["gym"].spaces = sys.modules["gym.spaces"]
+
+
+class _Box:                       # what the reference's agent checks with isinstance(space, gym.spaces.Box)
+    def __init__(self, low, high, shape=None, dtype=np.float32):
+        self.low, self.high, self.shape, self.dtype = low, high, shape if shape is not None else low.shape, dtype
+
+
+class _Discrete:
+    pass
+
+
+sys.modules["gym.spaces"].Box = _Box
+sys.modules["gym.spaces"].Discrete = _Discrete
 sys.path.insert(0, REF)
 os.chdir(REF)  # the reference opens data/assets/humanoid.xml relative to its root
 
@@ -509,6 +522,8 @@ def gen_dataset_yaml():
     import PARC.util.create_dataset as ref_cd
     # the function samples character surface points through trimesh (not installed) before it knows whether the
     # preprocessing step is requested; with compute_preprocessing_data=False the points are never used
+    # (patched for the duration of this call only: gen_terrain_geometry needs the real function afterwards)
+    real_samples = ref_cd.geom_util.get_char_point_samples
     ref_cd.geom_util.get_char_point_samples = lambda char_model: None
 
     def make_terrain(hf):
@@ -517,7 +532,11 @@ def gen_dataset_yaml():
     root = tempfile.mkdtemp(prefix="parc_ds_")
     folders = dataset_tree.build(root, make_terrain)
     out = os.path.join(root, "out.yaml")
-    ref_cd.create_dataset_yaml([Path(f) for f in folders], Path(out), os.path.join(REF, "data/assets/humanoid.xml"), False, True, ["running"], 45, 45)
+    try:
+        ref_cd.create_dataset_yaml([Path(f) for f in folders], Path(out), os.path.join(REF, "data/assets/humanoid.xml"), False, True,
+                                   ["running"], 45, 45)
+    finally:
+        ref_cd.geom_util.get_char_point_samples = real_samples
     with open(out) as f:
         y = yaml.safe_load(f)
     entries = [{"file": os.path.relpath(m["file"], root), "weight": float(m["weight"])} for m in y["motions"]]
@@ -616,19 +635,404 @@ def gen_terrain_geometry():
     save("g13_terrain_geometry", **out)
 
 
-def main():
-    if "--only-terrain-geometry" in sys.argv:
-        gen_terrain_geometry()
-        return
-    if "--only-procgen" in sys.argv:
-        gen_procgen()
-        return
-    if "--only-dataset-yaml" in sys.argv:
-        gen_dataset_yaml()
-        return
-    if "--only-voxel-mesh" in sys.argv:
-        gen_voxel_mesh(np.random.default_rng(10))
-        return
+# --------------------------------------------------------------------------------------------
+# Learner side (K12, K14, K19, K21, K22) and the widened termination fixture.  Each stage seeds its own generator, so
+# adding a stage never changes the fixtures of the others.
+# --------------------------------------------------------------------------------------------
+def mlib_from_fixture(km):
+    """The 4-clip MotionLib of G3 rebuilt from the frames stored in g3_motion.npz (independent of the main rng stream)."""
+    import yaml
+    z = np.load(os.path.join(OUT, "g3_motion.npz"))
+    civ = load_motion_file_safe(os.path.join(REF, "data/terrains/civilization.pkl"))
+    ter = ref_terrain_from_dict(civ["terrain"]).numpy_copy()
+    tmp = tempfile.mkdtemp(prefix="parc_golden_")
+    entries = []
+    for k in range(4):
+        pth = os.path.join(tmp, str(z["clip_names"][k]) + ".pkl")
+        write_motion_file(pth, z["frames_%d" % k].astype(np.float32), z["contacts_%d" % k].astype(np.float32), int(z["clip_fps"][k]),
+                          motion_lib.LoopMode(int(z["clip_loop"][k])).name, ter)
+        entries.append({"file": pth, "weight": float(z["clip_weights_in"][k])})
+    ypath = os.path.join(tmp, "motions.yaml")
+    with open(ypath, "w") as f:
+        yaml.safe_dump({"motions": entries}, f)
+    return motion_lib.MotionLib(ypath, km, "cpu", contact_info=True)
+
+
+def gen_done_branches():
+    """G8b: RefCharEnv.update_done / compute_done (mgdm_dm_util.py:205-230,392-460) + the motion-end override of
+    DeepMimicEnv.update_done (dm_env.py:746-783), every branch tripped on its own.  Base state of every env = the reference
+    pose exactly (no failure); each env then gets ONE perturbation.  `case` names the branch, `expect_fail` what the
+    perturbation is meant to do (the stored flags are what the reference returned, not this intent)."""
+    rng = np.random.default_rng(81)
+    km = load_char()
+    mlib = mlib_from_fixture(km)
+    pose_term = np.array([0.7, 1.0, 0.7, 0.7, 0.7, 0.7, 0.7, 0.7, 1.0, 1.2, 10.0, 1.0, 1.2, 10.0], np.float32)
+    feet = [km.get_body_id("right_foot"), km.get_body_id("left_foot")]
+    cases = []          # (name, expect_fail(None = n/a), fn(env state dict))
+    for b in range(1, 15):
+        thr = float(pose_term[b - 1])
+        for axis, scale in ((0, 1.05), (1, 1.05), (2, -1.05), (0, 0.95)):
+            cases.append(("body%d_%s" % (b, "over" if abs(scale) > 1 else "under"), abs(scale) > 1, ("body", b, axis, scale * thr)))
+    for d, over in (([0.61, 0, 0], True), ([0, -0.45, 0.45], True), ([0.59, 0, 0], False), ([0.3, 0.3, 0.3], False)):
+        cases.append(("root_pos_" + ("over" if over else "under"), over, ("root_pos", d)))
+    for e, over in (([0, 0, 1.33], True), ([1.0, 0.9, 0], True), ([0, 0, 1.29], False), ([0.7, -0.7, 0.7], False)):
+        cases.append(("root_rot_" + ("over" if over else "under"), over, ("root_rot", e)))
+    # fall branch (only evaluated with contact bodies = feet): body below the termination height AND a contact force on a non-foot body
+    cases += [("fall_height_and_force_same_body", True, ("fall", "low", "force_same")),
+              ("fall_height_and_force_other_body", True, ("fall", "low", "force_other")),
+              ("fall_height_only", False, ("fall", "low", None)),
+              ("fall_force_only", False, ("fall", None, "force_same")),
+              ("fall_force_below_threshold", False, ("fall", "low", "force_small")),
+              ("fall_foot_low_foot_force", False, ("fall", "foot_low", "force_foot")),
+              ("fall_height_and_foot_force", False, ("fall", "low", "force_foot")),
+              ("fall_negative_force_component", True, ("fall", "low", "force_neg"))]
+    cases += [("first_step_body", False, ("first", "body")), ("first_step_root_pos", False, ("first", "root_pos")),
+              ("first_step_root_rot", False, ("first", "root_rot")), ("first_step_time_2e-5", True, ("first", "late"))]
+    cases += [("timeout", None, ("time", 10.5, False)), ("timeout_exact", None, ("time", 10.0, False)),
+              ("just_before_timeout", None, ("time", 9.99, False)), ("timeout_and_fail", True, ("time", 11.0, True))]
+    cases += [("motion_end_clamp_past", None, ("mend", 0, 0.2)), ("motion_end_clamp_before", None, ("mend", 0, -0.2)),
+              ("motion_end_clamp_short_clip", None, ("mend", 3, 0.05)), ("motion_end_wrap_past", None, ("mend", 2, 0.7)),
+              ("motion_end_wrap_far_past", None, ("mend", 2, 3.1)), ("motion_end_clamp_teaser_past", None, ("mend", 1, 1.0))]
+    n = len(cases)
+    M = mlib.num_motions()
+    lens = npy(mlib._motion_lengths)
+    motion_ids = rng.integers(0, M, n).astype(np.int64)
+    time_buf = np.full(n, 1.0, np.float32)
+    mto = (rng.random(n).astype(np.float32) * np.maximum(lens[motion_ids] - 1.3, 0.0)).astype(np.float32)
+    mto[lens[motion_ids] < 1.3] = 0.0
+    for i, (name, _, spec) in enumerate(cases):
+        if spec[0] == "mend":
+            motion_ids[i] = spec[1]
+            mto[i] = np.float32(lens[spec[1]] + spec[2]) - time_buf[i]
+        elif lens[motion_ids[i]] < 1.3:           # the 4-frame clip ends before t = 1 s: keep it for the motion-end cases only
+            motion_ids[i] = 0
+            mto[i] = np.float32(rng.random() * (lens[0] - 1.3))
+        if spec[0] == "time":
+            time_buf[i] = spec[1]
+            mto[i] = 0.0
+            motion_ids[i] = 2                      # WRAP clip: no motion end however late
+        if spec[0] == "first":
+            time_buf[i] = 2e-5 if spec[1] == "late" else 0.0
+    nonfoot = [b for b in range(15) if b not in feet]
+    for sweep in range(2):
+        motion_ids_t, times = t(motion_ids, torch.int64), t(time_buf + mto)
+        rp, rr, rv, rav, jr, dv, cont = mlib.calc_motion_frame(motion_ids_t, times)
+        ref_body_pos, _ = km.forward_kinematics(rp, rr, jr)
+        if sweep == 0:
+            # the fall cases lower a body to just under the termination height; that must stay far below the pose thresholds,
+            # so they all use the pose whose lowest non-foot body is the lowest of the whole fixture
+            star = int(torch.argmin(ref_body_pos[:, nonfoot, 2].min(dim=-1)[0]))
+            for i, (name, _, spec) in enumerate(cases):
+                if spec[0] == "fall":
+                    motion_ids[i], mto[i], time_buf[i] = motion_ids[star], mto[star], time_buf[star]
+    ref_dof_pos = mlib.joint_rot_to_dof(jr)
+    # flat terrain 0.25 m under the lowest non-foot body of any env: nobody is below the termination height (0.15) unperturbed
+    h0 = float(ref_body_pos[:, nonfoot, 2].min()) - 0.25
+    hf = np.full((40, 40), h0, np.float32)
+    min_point = np.array([-8.0, -8.0], np.float32)
+    dxdy = np.array([0.4, 0.4], np.float32)
+    ter = terrain_util.SubTerrain("flat", 40, 40, 0.4, 0.4, -8.0, -8.0, device="cpu")
+    ter.hf[:] = t(hf)
+    char_root_pos, char_root_rot = rp.clone(), rr.clone()
+    body_pos = ref_body_pos.clone()
+    contact_forces = torch.zeros(n, 15, 3)
+    for i, (name, _, spec) in enumerate(cases):
+        kind = spec[0]
+        if kind == "body" or (kind == "first" and spec[1] in ("body", "late")) or (kind == "time" and spec[2]):
+            b, axis, d = (spec[1], spec[2], spec[3]) if kind == "body" else (4, 0, 1.5)
+            body_pos[i, b, axis] += d
+        elif kind == "root_pos" or (kind == "first" and spec[1] == "root_pos"):
+            d = t(spec[1]) if kind == "root_pos" else t([0.9, 0.0, 0.0])
+            char_root_pos[i] += d
+            body_pos[i] += d                          # the whole character moves: relative body positions stay equal
+        elif kind == "root_rot" or (kind == "first" and spec[1] == "root_rot"):
+            e = t([spec[1]]) if kind == "root_rot" else t([[0.0, 0.0, 2.0]])
+            char_root_rot[i] = torch_util.quat_mul(torch_util.exp_map_to_quat(e), rr[i:i + 1])[0]
+        elif kind == "fall":
+            low_b = nonfoot[int(torch.argmin(ref_body_pos[i, nonfoot, 2]))]
+            other_b = 2 if low_b != 2 else 1
+            if spec[1] == "low":
+                body_pos[i, low_b, 2] = h0 + 0.15 - 0.02
+            elif spec[1] == "foot_low":
+                body_pos[i, feet[0], 2] = h0 + 0.15 - 0.10
+            f = {"force_same": (low_b, [0.0, 0.0, 30.0]), "force_other": (other_b, [0.15, 0.0, 0.0]), "force_small": (low_b, [0.09, -0.09, 0.09]),
+                 "force_foot": (feet[0], [0.0, 0.0, 400.0]), "force_neg": (other_b, [0.0, -0.2, 0.0]), None: None}[spec[2]]
+            if f is not None:
+                contact_forces[i, f[0]] = t(f[1])
+    margin = float((body_pos[..., nonfoot, 2] - (h0 + 0.15)).abs().min())
+    assert margin > 2e-3, margin                   # no body sits on the termination height itself: the flags are not roundoff
+    env_offsets = torch.zeros(n, 3)
+    gbi = ter.get_grid_index(body_pos[..., 0:2] + env_offsets[:, 0:2].unsqueeze(1))
+    term_h = ter.hf[gbi[..., 0], gbi[..., 1]] + 0.15
+    outs = {}
+    for tag, cb in (("nocontact", torch.zeros(0, dtype=torch.int64)), ("feet", t(feet, torch.int64))):
+        outs[tag] = dmu.compute_done(done_buf=torch.zeros(n, dtype=torch.int), time=t(time_buf), ep_len=10.0, root_rot=char_root_rot,
+                                     body_pos=body_pos, char_root_pos=char_root_pos, tar_root_rot=rr, tar_body_pos=ref_body_pos,
+                                     contact_force=contact_forces, contact_body_ids=cb, termination_heights=term_h, pose_termination=True,
+                                     pose_termination_dist=t(pose_term), global_obs=False, enable_early_termination=True, track_root=True,
+                                     root_pos_termination_dist=0.6, root_rot_termination_angle=1.309).clone()
+    motion_len = mlib.get_motion_length(motion_ids_t)
+    motion_end = torch.logical_and(times >= motion_len, mlib.get_motion_loop_mode(motion_ids_t) != motion_lib.LoopMode.WRAP.value)
+    finals, frs = {}, {}
+    for tag in outs:                                   # fail-rate EMA in env order, then the motion-end override (dm_env.py:746-783)
+        fr = torch.ones(M)
+        done_any = torch.logical_or(outs[tag] != 0, motion_end)
+        for e in torch.nonzero(done_any).flatten().tolist():
+            fr[motion_ids[e]] = fr[motion_ids[e]] * (1.0 - 0.01) + (0.01 if outs[tag][e] == 1 else 0.0)
+        fin = outs[tag].clone()
+        fin[motion_end] = 1
+        finals[tag], frs[tag] = fin, fr
+    # the fixture must actually exercise what it claims: report every case whose reference flag differs from the intent
+    for i, (name, expect, spec) in enumerate(cases):
+        tag = "feet" if spec[0] == "fall" else "nocontact"
+        if expect is not None:
+            assert bool(outs[tag][i] == 1) == expect, (name, int(outs[tag][i]))
+    char_dof_pos = ref_dof_pos.clone()
+    save("g8b_done_branches", case=np.array([c[0] for c in cases]), expect_fail=np.array([-1 if c[1] is None else int(c[1]) for c in cases]),
+         motion_ids=motion_ids, time_buf=time_buf, motion_time_offsets=mto, motion_offsets=np.zeros((M, 1, 2), np.float32),
+         env_offsets=env_offsets, hf=hf, min_point=min_point, dxdy=dxdy, rays=gen_rays_points(),
+         char_root_pos=char_root_pos, char_root_rot=char_root_rot, char_root_vel=rv, char_root_ang_vel=rav, char_dof_pos=char_dof_pos,
+         char_dof_vel=dv, char_rigid_body_pos=body_pos, contact_forces=contact_forces, ref_root_pos=rp, ref_root_rot=rr,
+         ref_body_pos=ref_body_pos, pose_termination_dist=pose_term, termination_heights=term_h, motion_end=motion_end,
+         done_nocontact=outs["nocontact"], done_feet=outs["feet"], done_final_nocontact=finals["nocontact"], done_final_feet=finals["feet"],
+         fail_rates_nocontact=frs["nocontact"], fail_rates_feet=frs["feet"], feet=np.array(feet))
+
+
+def gen_rays_points():
+    return geom_util.get_xy_points_cone(center=torch.zeros(2), dx=0.05, num_neg=2, num_pos=60, num_rays_neg=3, num_rays_pos=3,
+                                        angle_between_rays=0.26179938779)
+
+
+class _Stub:
+    pass
+
+
+def _import_learning():
+    import learning.base_agent as base_agent
+    import learning.distribution_gaussian_diag as dgd
+    import learning.dm_ppo_return_tracker as rt
+    import learning.normalizer as normalizer
+    import learning.ppo_agent as ppo_agent
+    import learning.tracking_error_tracker as tet
+    return base_agent, dgd, rt, normalizer, ppo_agent, tet
+
+
+def gen_ppo_loss():
+    """G14: PPOAgent._compute_loss / _compute_actor_loss / _compute_critic_loss (learning/ppo_agent.py:212-330) and
+    BaseAgent._compute_action_bound_loss (learning/base_agent.py:456-475), called as unbound methods on a stub agent whose model
+    returns the reference's own DistributionGaussianDiag over given means.  Stored per case: loss, every info term, and the
+    autograd gradients with respect to mean, logstd and the critic's prediction."""
+    base_agent, dgd, _, normalizer, ppo_agent, _ = _import_learning()
+    g = torch.Generator().manual_seed(14)
+    B, A = 1500, 28
+    mean0 = torch.randn(B, A, generator=g) * 0.7            # some |mean| > 1: the action-bound term is active
+    logstd0 = torch.randn(A, generator=g) * 0.2 - 1.5
+    pred0 = torch.randn(B, generator=g)
+    norm_a = mean0 + torch.exp(logstd0) * torch.randn(B, A, generator=g)
+    adv = torch.randn(B, generator=g)
+    tar = torch.randn(B, generator=g)
+    old_noise = 0.3 * torch.randn(B, generator=g)
+    masks = {"most": (torch.rand(B, generator=g) < 0.8).float(), "all": torch.ones(B), "one": torch.zeros(B), "none": torch.zeros(B)}
+    masks["one"][1234 % B] = 1.0
+    a_low, a_high = -np.ones(A, np.float32) * 2.0, np.ones(A, np.float32) * 3.0
+    cases = {"default": dict(mask="most"), "all_terms_l1": dict(mask="most", ew=0.01, rw=0.003, l1=True),
+             "critic_gate": dict(mask="most", tar_shift=9.0), "mask_all": dict(mask="all"), "mask_one": dict(mask="one", ew=0.01, rw=0.003),
+             "mask_none": dict(mask="none"), "no_bound_term": dict(mask="most", bw=0.0)}
+    out = dict(mean=mean0, logstd=logstd0, pred=pred0, norm_action=norm_a, adv=adv, tar_val=tar, a_low=a_low, a_high=a_high,
+               case_names=np.array(list(cases.keys())), info_names=np.array(["loss", "critic_loss", "actor_loss", "clip_frac", "imp_ratio",
+                                                                             "action_bound_loss", "action_entropy", "action_reg_loss"]))
+    old_logp = dgd.DistributionGaussianDiag(mean0, logstd0.expand(B, A)).log_prob(norm_a) + old_noise
+    out["a_logp"] = old_logp
+    for name, c in cases.items():
+        mean, logstd, pred = mean0.clone().requires_grad_(True), logstd0.clone().requires_grad_(True), pred0.clone().requires_grad_(True)
+        ag = _Stub()
+        ag._ppo_clip_ratio, ag._critic_loss_weight = 0.2, 0.5
+        ag._action_bound_weight, ag._action_entropy_weight, ag._action_reg_weight = c.get("bw", 10.0), c.get("ew", 0.0), c.get("rw", 0.0)
+        ag._critic_loss_type = "L1" if c.get("l1") else "L2"
+        ident = _Stub()
+        ident.normalize = lambda x: x
+        ag._obs_norm = ag._a_norm = ident
+        ag._env = _Stub()
+        ag._env.get_action_space = lambda: _Box(a_low, a_high)
+        model = _Stub()
+        # "observations" are row numbers, so that the rows the reference selects by mask reach the right means
+        model.eval_actor = lambda o: dgd.DistributionGaussianDiag(mean[o[:, 0].long()], torch.broadcast_to(logstd, (o.shape[0], A)))
+        model.eval_critic = lambda o: pred[o[:, 0].long()].unsqueeze(-1)
+        ag._model = model
+        for fn in ("_compute_critic_loss", "_compute_actor_loss", "_compute_action_bound_loss"):
+            setattr(ag, fn, getattr(ppo_agent.PPOAgent, fn).__get__(ag))
+        tar_c = tar + c.get("tar_shift", 0.0)
+        batch = {"obs": torch.arange(B, dtype=torch.float32).unsqueeze(-1), "action": norm_a, "tar_val": tar_c, "a_logp": old_logp,
+                 "adv": adv, "rand_action_mask": masks[c["mask"]]}
+        if c["mask"] == "none":
+            # no random action in the batch: the reference's mean over an empty selection is NaN, its NaN trap then dumps the
+            # batch and exits the program (ppo_agent.py:242-252).  Only the terms are recorded, the trap is not run.
+            info = {**ppo_agent.PPOAgent._compute_critic_loss(ag, {"norm_obs": batch["obs"], "tar_val": tar_c}),
+                    **ppo_agent.PPOAgent._compute_actor_loss(ag, {"norm_obs": batch["obs"], "norm_action": norm_a, "a_logp": old_logp,
+                                                                   "adv": adv, "rand_action_mask": masks["none"]})}
+            assert torch.isnan(info["actor_loss"])
+            info["loss"] = info["actor_loss"] + 0.5 * info["critic_loss"]
+            grads = [torch.zeros_like(mean), torch.zeros_like(logstd), torch.zeros_like(pred)]
+        else:
+            info = ppo_agent.PPOAgent._compute_loss(ag, batch)
+            grads = torch.autograd.grad(info["loss"], [mean, logstd, pred], allow_unused=True)
+            grads = [torch.zeros_like(p_) if g_ is None else g_ for g_, p_ in zip(grads, (mean, logstd, pred))]
+        vals = [float(info[k]) if k in info else np.nan for k in out["info_names"]]
+        out[name + "_info"] = np.array(vals, np.float64)
+        out[name + "_mask"] = masks[c["mask"]]
+        out[name + "_tar_val"] = tar_c
+        out[name + "_params"] = np.array([0.2, ag._action_bound_weight, ag._action_entropy_weight, ag._action_reg_weight, 0.5, 20.0,
+                                          1.0 if c.get("l1") else 0.0], np.float64)
+        out[name + "_grad_mean"], out[name + "_grad_logstd"], out[name + "_grad_pred"] = grads
+    save("g14_ppo_loss", **out)
+
+
+def gen_normalizer():
+    """G15: Normalizer.record / update / normalize / unnormalize (learning/normalizer.py:18-86) over three update rounds, with
+    the tracker's non-normalised index set (contacts + heightmap columns) and clip 10."""
+    _, _, _, normalizer, _, _ = _import_learning()
+    rng = np.random.default_rng(15)
+    D = 1312
+    nn_idx = torch.arange(766, D)                      # tar_contacts, char_contacts, hf (dm_ppo_agent.py:78-117)
+    nz = normalizer.Normalizer((D,), "cpu", clip=10.0, non_norm_indices=nn_idx)
+    out = {"non_norm_indices": nn_idx, "clip": np.float64(10.0)}
+    scale = (rng.random(D) * 3 + 0.01).astype(np.float32)
+    shift = rng.standard_normal(D).astype(np.float32) * 2
+    scale[5] = 0.0                                     # a constant column: variance floor (min_std 1e-4)
+    for r in range(3):
+        for k in range(2):                             # two record calls per round, one [T, N, D] and one [N, D]
+            x = (rng.standard_normal((3, 8, D) if k == 0 else (12, D)).astype(np.float32) * scale + shift * (1 + 0.2 * r))
+            out["x_%d_%d" % (r, k)] = x
+            nz.record(t(x))
+            if r == 0 and k == 1:
+                out["new_count_r0"], out["new_sum_r0"], out["new_sum_sq_r0"] = np.int64(nz._new_count), nz._new_sum.clone(), nz._new_sum_sq.clone()
+        nz.update()
+        out["count_%d" % r], out["mean_%d" % r], out["std_%d" % r] = nz._count.clone(), nz._mean.clone(), nz._std.clone()
+    q = (rng.standard_normal((16, D)).astype(np.float32) * 4 * np.maximum(scale, 0.05) + shift)
+    q[0, :10] = 1e6                                    # clamps at +-clip
+    out["query"], out["normalized"] = q, nz.normalize(t(q))
+    out["unnormalized"] = nz.unnormalize(t(q))
+    # the action normaliser built from the action bounds (base_agent.py:195-203)
+    lo, hi = (-rng.random(28) * 2 - 0.1).astype(np.float32), (rng.random(28) * 2 + 0.1).astype(np.float32)
+    an = normalizer.Normalizer((28,), "cpu", init_mean=t(0.5 * (hi + lo)), init_std=t(0.5 * (hi - lo)))
+    na = rng.standard_normal((32, 28)).astype(np.float32)
+    out.update(a_low=lo, a_high=hi, a_mean=an._mean.clone(), a_std=an._std.clone(), norm_action=na, action=an.unnormalize(t(na)),
+               action_renormalized=an.normalize(an.unnormalize(t(na))))
+    save("g15_normalizer", **out)
+
+
+def gen_trackers():
+    """G16: DMPPOReturnTracker.update (learning/dm_ppo_return_tracker.py:66-99) and TrackingErrorTracker.update
+    (learning/tracking_error_tracker.py:73-122) over a seeded 40-step episode stream of 24 envs."""
+    _, _, rt, _, _, tet = _import_learning()
+    rng = np.random.default_rng(16)
+    S, N = 40, 24
+    keys = ["total_r", "pose_r", "vel_r", "root_pos_r", "root_vel_r", "key_pos_r", "contact_penalty"]
+    rewards = rng.random((S, len(keys), N)).astype(np.float32)
+    rewards[:, 6] *= -0.1
+    done = rng.choice([0, 0, 0, 0, 0, 0, 0, 0, 1, 3], size=(S, N)).astype(np.int32)
+    done[3] = 0
+    done[4] = 0                                        # steps without any finished env
+    done[7, :] = 1                                     # every env at once
+    terr = rng.random((S, N, 7)).astype(np.float32)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        tr = rt.DMPPOReturnTracker(N, "cpu")
+    te = tet.TrackingErrorTracker(N, "cpu")
+    means, ep_len, episodes, te_means = [], [], [], []
+    for s in range(S):
+        info = {"rewards": {k: t(rewards[s, i]) for i, k in enumerate(keys)}}
+        tr.update(info, t(done[s], torch.int))
+        te.update(t(terr[s]), t(done[s], torch.int))
+        means.append(np.array([float(tr.get_specific_mean_return(k)) for k in keys], np.float32))
+        ep_len.append(float(tr.get_mean_ep_len()))
+        episodes.append(tr.get_episodes())
+        te_means.append(np.array([float(x) for x in (te.get_mean_root_pos_err(), te.get_mean_root_rot_err(), te.get_mean_body_pos_err(),
+                                                     te.get_mean_body_rot_err(), te.get_mean_dof_vel_err(), te.get_mean_root_vel_err(),
+                                                     te.get_mean_root_ang_vel_err())], np.float32))
+    save("g16_trackers", keys=np.array(keys), rewards=rewards, done=done, tracking_error=terr, mean_returns=np.stack(means),
+         mean_ep_len=np.array(ep_len, np.float32), episodes=np.array(episodes, np.int64), eps_per_env=tr.get_eps_per_env().clone(),
+         return_bufs=torch.stack([tr._return_bufs[k] for k in keys]), ep_len_buf=tr._ep_len_buf.clone(), te_means=np.stack(te_means),
+         te_names=np.array(["root_pos", "root_rot", "body_pos", "body_rot", "dof_vel", "root_vel", "root_ang_vel"]))
+
+
+def gen_action_head():
+    """G17: PPOAgent._decide_action (learning/ppo_agent.py:87-119) in TRAIN and TEST mode with DistributionGaussianDiag
+    sample / mode / log_prob / entropy / param_reg (learning/distribution_gaussian_diag.py:39-102), called on a stub agent.  The two
+    random draws (torch.normal, torch.bernoulli) are replaced by stored arrays for the duration of the call, so the result is a
+    function of the fixture's inputs."""
+    base_agent, dgd, _, normalizer, ppo_agent, _ = _import_learning()
+    rng = np.random.default_rng(17)
+    n, A = 200, 28
+    mean = (rng.standard_normal((n, A)) * 0.8).astype(np.float32)
+    logstd = (rng.standard_normal(A) * 0.3 - 2.0).astype(np.float32)
+    noise = rng.standard_normal((n, A)).astype(np.float32)
+    bern = (rng.random((n, 1)) < 0.7).astype(np.float32)
+    lo, hi = (-rng.random(A) * 2 - 0.1).astype(np.float32), (rng.random(A) * 2 + 0.1).astype(np.float32)
+    ag = _Stub()
+    ag._device = "cpu"
+    ident = _Stub()
+    ident.normalize = lambda x: x
+    ag._obs_norm = ident
+    ag._a_norm = normalizer.Normalizer((A,), "cpu", init_mean=t(0.5 * (hi + lo)), init_std=t(0.5 * (hi - lo)))
+    dist = dgd.DistributionGaussianDiag(t(mean), torch.broadcast_to(t(logstd), (n, A)))
+    model = _Stub()
+    model.eval_actor = lambda o: dist
+    ag._model = model
+    ag._get_exp_prob = lambda: 0.7
+    out = dict(mean=mean, logstd=logstd, noise=noise, bernoulli=bern[:, 0], a_low=lo, a_high=hi, entropy=dist.entropy(), param_reg=dist.param_reg(),
+               logp_of_noise=dist.log_prob(t(mean + np.exp(logstd) * noise)))
+    real_normal, real_bern = torch.normal, torch.bernoulli
+    torch.normal = lambda m, s: t(noise)
+    torch.bernoulli = lambda p: t(bern)
+    try:
+        for mode in ("TRAIN", "TEST"):
+            ag._mode = base_agent.AgentMode[mode]
+            a, info = ppo_agent.PPOAgent._decide_action(ag, torch.zeros(n, 4), None)
+            out["action_" + mode], out["a_logp_" + mode], out["mask_" + mode] = a, info["a_logp"], info["rand_action_mask"]
+    finally:
+        torch.normal, torch.bernoulli = real_normal, real_bern
+    # action-bound penalty of the same distribution (base_agent.py:456-475)
+    ag._env = _Stub()
+    ag._env.get_action_space = lambda: _Box(lo, hi)
+    out["action_bound_loss"] = base_agent.BaseAgent._compute_action_bound_loss(ag, dist)
+    save("g17_action_head", **out)
+
+
+def gen_recorded_files():
+    """G19: the files THIS package wrote on the GPU (tests/golden/recorded/: a clip recorded by record mode and the terrain cache,
+    produced by tools/make_recorded_fixture.py) opened by the REFERENCE's readers: MotionLib._load_motions (anim/motion_lib.py:204-380,
+    plain pickle.load) and DeepMimicEnv.load_terrain (envs/ig_parkour/dm_env.py:493-507)."""
+    rec_dir = os.path.join(OUT, "recorded")
+    km = load_char()
+    clip = os.path.join(rec_dir, "recorded_clip_dm.pkl")
+    ml = motion_lib.MotionLib(clip, km, "cpu", contact_info=True)
+    with open(clip, "rb") as f:
+        raw = pickle.load(f)                       # (a file of our own making; SubTerrain resolves to the reference's class here)
+    assert type(raw["terrain"]).__module__ == "util.terrain_util" and raw["terrain"].__class__ is terrain_util.SubTerrain
+    ter = ml._terrains[0]
+    import envs.ig_parkour.dm_env as ref_dm_env
+    stub = _Stub()
+    stub._device = "cpu"
+    verts, tris = ref_dm_env.DeepMimicEnv.load_terrain(stub, os.path.join(rec_dir, "terrain.pkl"))
+    rp, rr, rv, rav, jr, dv, cont = ml.calc_motion_frame(torch.zeros(3, dtype=torch.int64), t([0.0, 0.21, 10.0]))
+    save("g19_recorded_files", num_frames=ml._motion_num_frames, length=ml._motion_lengths, fps=ml._motion_fps, loop_mode=ml._motion_loop_modes,
+         frame_root_pos=ml._frame_root_pos, frame_root_rot=ml._frame_root_rot, frame_joint_rot=ml._frame_joint_rot,
+         frame_root_vel=ml._frame_root_vel, frame_dof_vel=ml._frame_dof_vel, frame_contacts=ml._frame_contacts,
+         obs=raw["obs"], obs_shape_names=np.array(list(raw["obs_shapes"].keys())),
+         ter_hf=ter.hf, ter_min_point=ter.min_point, ter_dxdy=ter.dxdy, ter_dims=ter.dims, ter_hf_mask=ter.hf_mask, ter_hf_maxmin=ter.hf_maxmin,
+         q_root_pos=rp, q_root_rot=rr, q_joint_rot=jr, q_contacts=cont,
+         cache_hf=stub._terrain.hf, cache_min_point=stub._terrain.min_point, cache_dxdy=stub._terrain.dxdy, cache_dims=stub._terrain.dims,
+         cache_motion_offsets=stub._dm_motion_offsets, cache_terrains_per_motion=np.int64(stub._terrains_per_motion),
+         cache_num_vert_lists=np.int64(len(verts)), cache_verts_0=np.asarray(verts[0][0]), cache_tris_0=np.asarray(tris[0][0]))
+
+
+STAGES = ["core", "voxel-mesh", "dataset-yaml", "procgen", "terrain-geometry", "done-branches", "ppo-loss", "normalizer", "trackers",
+          "action-head", "recorded-files"]
+
+
+def gen_core():
     rng = np.random.default_rng(0)
     torch.manual_seed(0)
     civ = load_motion_file_safe(os.path.join(REF, "data/terrains/civilization.pkl"))
@@ -642,10 +1046,17 @@ def main():
     gen_heightmap(rng, civ, teaser, rays)
     gen_obs_reward_done(rng, km, mlib, civ, rays)
     gen_td_lambda(rng)
-    gen_voxel_mesh(np.random.default_rng(10))
-    gen_dataset_yaml()
-    gen_procgen()
-    gen_terrain_geometry()
+
+
+def main():
+    """No flag: every stage, in order (reproduces all committed fixtures).  --only-<stage>: that stage alone."""
+    run = {"core": gen_core, "voxel-mesh": lambda: gen_voxel_mesh(np.random.default_rng(10)), "dataset-yaml": gen_dataset_yaml,
+           "procgen": gen_procgen, "terrain-geometry": gen_terrain_geometry, "done-branches": gen_done_branches, "ppo-loss": gen_ppo_loss,
+           "normalizer": gen_normalizer, "trackers": gen_trackers, "action-head": gen_action_head, "recorded-files": gen_recorded_files}
+    picked = [s_ for s_ in STAGES if "--only-" + s_ in sys.argv]
+    for s_ in picked or STAGES:
+        print("== stage", s_)
+        run[s_]()
 
 
 if __name__ == "__main__":

@@ -143,13 +143,13 @@ def test_g5_heightmap_gather(name, oracle):
     assert torch.equal(obs2[:7, 871:], obs[:7, 871:]) and torch.all(obs2[7:] == -99.0)
 
 
-def _core_from_golden(km, mlib):
+def _core_from_golden(km, mlib, name="g6_step"):
     from parc_amd.tracker_core import TrackerConfig, TrackerCore
     from parc_amd.util.terrain_util import SubTerrain
     from parc_amd.envs.ig_parkour.default_config import default_env_config
-    z = golden("g6_step")
+    z = golden(name)
     cfg = TrackerConfig(default_env_config()["env"], km, 441)
-    n = 64
+    n = z["motion_ids"].shape[0]
     core = TrackerCore(n, DEV, km, mlib, cfg, T(z["rays"]))
     core.set_terrain(SubTerrain.from_arrays(z["hf"], z["min_point"], z["dxdy"], device=DEV))
     core.root_state[:, 0:3] = T(z["char_root_pos"])
@@ -244,6 +244,32 @@ def test_g6_post_step_subset_and_contact_bodies(km, mlib):
     me = z["motion_end"]
     np.testing.assert_array_equal(done[~me], z["done_feet"][~me])
     assert np.all(done[me] == 1)
+    core.cfg.struct.num_contact_bodies = 0
+
+
+def test_g8b_done_every_branch_on_the_device(km, mlib):
+    """The fused post-step kernel's termination logic on fixture G8b: every branch of compute_done / update_done tripped on its own
+    (per-body pose distance for each of the 14 bodies, root position, root rotation, fall = height AND force, first-step
+    exemption, timeout, motion end on CLAMP vs WRAP), flags as returned by the reference (mgdm_dm_util.py:392-460, dm_env.py:746-783)."""
+    from parc_amd import _hip
+    core, z = _core_from_golden(km, mlib, "g8b_done_branches")
+    case = [str(c) for c in z["case"]]
+    for tag, feet in (("nocontact", []), ("feet", [int(b) for b in z["feet"]])):
+        core.cfg.struct.num_contact_bodies = len(feet)
+        for b in range(15):
+            core.cfg.struct.contact_body_mask[b] = 1 if b in feet else 0
+        core.post_step(_hip.POST_REF | _hip.POST_REWARD_DONE)
+        torch.cuda.synchronize()
+        close(core.ref_body_pos, z["ref_body_pos"])
+        done = core.done.cpu().numpy()
+        bad = np.nonzero(done != z["done_final_" + tag])[0]
+        assert bad.size == 0, [(case[i], int(done[i]), int(z["done_final_" + tag][i])) for i in bad]
+        # before the motion-end override the flag is the reference's compute_done output
+        me = z["motion_end"]
+        np.testing.assert_array_equal(done[~me], z["done_" + tag][~me])
+        fr = torch.ones(4, device=DEV)
+        core.update_fail_rates(fr, 0.01)
+        close(fr, z["fail_rates_" + tag], atol=1e-6)
     core.cfg.struct.num_contact_bodies = 0
 
 

@@ -6,6 +6,7 @@ import pickle
 import re
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import REPO, golden
@@ -465,3 +466,108 @@ def test_torch_util_matches_reference_fixture():
     chk(tu.calc_heading(t("a")), "calc_heading", 1e-5)
     chk(tu.calc_heading_quat_inv(t("a")), "calc_heading_quat_inv", 1e-5)
     chk(tu.quat_diff_angle(t("a"), t("b")), "quat_diff_angle", 2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Learner-side host classes against fixtures produced by the reference's own classes (G15, G16) and the reference's readers
+# on files this package wrote (G19).  The device kernels are checked against the same fixtures in tests/test_learner_gpu.py.
+# ---------------------------------------------------------------------------------------------------------------
+def check_normalizer_against_g15(device):
+    from parc_amd.learning.normalizer import Normalizer
+    z = golden("g15_normalizer")
+    T = lambda a, dt=torch.float32: torch.tensor(np.asarray(a), dtype=dt, device=device)
+    nz = Normalizer((1312,), device, clip=float(z["clip"]), non_norm_indices=T(z["non_norm_indices"], torch.int64))
+    for r in range(3):
+        for k in range(2):
+            nz.record(T(z["x_%d_%d" % (r, k)]))
+            if r == 0 and k == 1:
+                assert nz._new_count == int(z["new_count_r0"])
+                np.testing.assert_allclose(nz._new_sum.cpu().numpy(), z["new_sum_r0"], rtol=2e-6, atol=2e-4)
+                np.testing.assert_allclose(nz._new_sum_sq.cpu().numpy(), z["new_sum_sq_r0"], rtol=2e-6, atol=2e-3)
+        nz.update()
+        assert int(nz._count.item()) == int(z["count_%d" % r][0])
+        np.testing.assert_allclose(nz._mean.cpu().numpy(), z["mean_%d" % r], rtol=1e-5, atol=2e-6)
+        std, ref_std = nz._std.cpu().numpy().copy(), z["std_%d" % r].copy()
+        if r == 0:                               # column 5 is constant in round 0: its variance is fp32 cancellation noise, which
+            assert std[5] < 2e-3 and ref_std[5] < 2e-3      # depends on the summation order; everything else must agree
+            std[5] = ref_std[5] = 0.0
+        np.testing.assert_allclose(std, ref_std, rtol=2e-4, atol=2e-6)
+    assert torch.all(nz._mean[766:] == 0) and torch.all(nz._std[766:] == 1)
+    # normalise with the REFERENCE's statistics, so that the comparison is about normalize() alone
+    nz._mean[:] = T(z["mean_2"])
+    nz._std[:] = T(z["std_2"])
+    q = T(z["query"])
+    np.testing.assert_allclose(nz.normalize(q).cpu().numpy(), z["normalized"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(nz.unnormalize(q).cpu().numpy(), z["unnormalized"], rtol=2e-6, atol=2e-6)
+    an = Normalizer((28,), device, init_mean=T(0.5 * (z["a_high"] + z["a_low"])), init_std=T(0.5 * (z["a_high"] - z["a_low"])))
+    np.testing.assert_array_equal(an._mean.cpu().numpy(), z["a_mean"])
+    np.testing.assert_array_equal(an._std.cpu().numpy(), z["a_std"])
+    np.testing.assert_allclose(an.unnormalize(T(z["norm_action"])).cpu().numpy(), z["action"], rtol=1e-6, atol=1e-6)
+
+
+def check_trackers_against_g16(device):
+    from parc_amd.learning.dm_ppo_return_tracker import DMPPOReturnTracker
+    from parc_amd.learning.tracking_error_tracker import TrackingErrorTracker
+    z = golden("g16_trackers")
+    keys = [str(k) for k in z["keys"]]
+    S, K, N = z["rewards"].shape
+    tr, te = DMPPOReturnTracker(N, device), TrackingErrorTracker(N, device)
+    T = lambda a, dt=torch.float32: torch.tensor(np.asarray(a), dtype=dt, device=device)
+    for s in range(S):
+        block = T(z["rewards"][s])
+        info = {"rewards": {k: block[i] for i, k in enumerate(keys)}, "rewards_all": (keys, block)}
+        done = T(z["done"][s], torch.int32)
+        tr.update(info, done)
+        te.update(T(z["tracking_error"][s]), done)
+        got = np.array([tr.get_specific_mean_return(k).item() for k in keys], np.float32)
+        np.testing.assert_allclose(got, z["mean_returns"][s], rtol=3e-6, atol=1e-6, err_msg="step %d" % s)
+        assert tr.get_mean_ep_len().item() == pytest.approx(float(z["mean_ep_len"][s]), rel=3e-6)
+        assert tr.get_episodes() == int(z["episodes"][s])
+        np.testing.assert_allclose(te._mean.cpu().numpy(), z["te_means"][s], rtol=3e-6, atol=1e-6, err_msg="step %d" % s)
+    np.testing.assert_array_equal(tr.get_eps_per_env().cpu().numpy(), z["eps_per_env"])
+    np.testing.assert_allclose(tr._return_buf.cpu().numpy(), z["return_bufs"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(tr._ep_len_buf.cpu().numpy(), z["ep_len_buf"])
+    assert tr.get_mean_return().item() == pytest.approx(float(z["mean_returns"][-1, 0]), rel=3e-6)
+
+
+def test_g15_normalizer_host_path():
+    check_normalizer_against_g15("cpu")
+
+
+def test_g16_trackers_host_path():
+    check_trackers_against_g16("cpu")
+
+
+def test_g19_reference_read_our_recorded_files():
+    """tests/golden/recorded/ holds a clip written by record mode and a terrain cache written by the env, both on the GPU
+    (tools/make_recorded_fixture.py).  gen_golden.py opened them with the reference's MotionLib / load_terrain and stored what it
+    read (G19); here the same files, read by this package, must hold the same data - and name only reference classes."""
+    from parc_amd.util import safe_pickle
+    z = golden("g19_recorded_files")
+    rec_dir = os.path.join(REPO, "tests", "golden", "recorded")
+    clip = os.path.join(rec_dir, "recorded_clip_dm.pkl")
+    sub = {("util.terrain_util", "SubTerrain")}
+    assert pickle_globals(clip) - NUMPY_GLOBALS - {("collections", "OrderedDict")} == sub
+    assert pickle_globals(os.path.join(rec_dir, "terrain.pkl")) - NUMPY_GLOBALS - TORCH_GLOBALS == sub
+    d = safe_pickle.load_motion_file_safe(clip)
+    F = int(z["num_frames"][0])
+    assert d["frames"].shape == (F, 34) and d["fps"] == int(z["fps"][0]) and d["loop_mode"] == "CLAMP" and int(z["loop_mode"][0]) == 0
+    np.testing.assert_array_equal(d["frames"][:, 0:3], z["frame_root_pos"])
+    np.testing.assert_array_equal(d["contacts"], z["frame_contacts"])
+    np.testing.assert_array_equal(d["obs"], z["obs"])
+    assert list(d["obs_shapes"].keys()) == [str(k) for k in z["obs_shape_names"]]
+    t = d["terrain"]
+    np.testing.assert_array_equal(t["hf"], z["ter_hf"])
+    np.testing.assert_array_equal(np.asarray(t["min_point"]), z["ter_min_point"])
+    np.testing.assert_array_equal(np.asarray(t["dxdy"]), z["ter_dxdy"])
+    np.testing.assert_array_equal(np.asarray(t["dims"]), z["ter_dims"])
+    np.testing.assert_array_equal(np.asarray(t["hf_mask"]), z["ter_hf_mask"])
+    # the terrain cache through this package's own load_terrain
+    e, _ = _dm_env_cpu("square", None)
+    verts, tris = e.load_terrain(os.path.join(rec_dir, "terrain.pkl"))
+    np.testing.assert_array_equal(e._terrain.hf.numpy(), z["cache_hf"])
+    np.testing.assert_array_equal(e._terrain.min_point.numpy(), z["cache_min_point"])
+    np.testing.assert_array_equal(e._dm_motion_offsets.numpy(), z["cache_motion_offsets"])
+    assert e._terrains_per_motion == int(z["cache_terrains_per_motion"]) and len(verts) == int(z["cache_num_vert_lists"])
+    np.testing.assert_array_equal(np.asarray(verts[0][0]), z["cache_verts_0"])
+    np.testing.assert_array_equal(np.asarray(tris[0][0]), z["cache_tris_0"])

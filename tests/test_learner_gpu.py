@@ -1,0 +1,155 @@
+"""GPU parity of the learner-side kernels (K12, K14, K19, K21, K22) and of the tracking-error metric against fixtures produced
+by the REFERENCE's own classes on CPU (tests/golden/gen_golden.py stages ppo-loss, normalizer, trackers, action-head):
+PPOAgent._compute_loss (learning/ppo_agent.py:212-330), Normalizer (learning/normalizer.py:18-86), DMPPOReturnTracker.update
+(learning/dm_ppo_return_tracker.py:66-99), TrackingErrorTracker.update, PPOAgent._decide_action with DistributionGaussianDiag
+(learning/ppo_agent.py:87-119, learning/distribution_gaussian_diag.py:39-102), compute_tracking_error (mgdm_dm_util.py:578-611)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, golden
+from test_hip_parity import DEV, T, _core_from_golden, close, km, mlib  # noqa: F401  (km, mlib are fixtures)
+
+pytestmark = pytest.mark.gpu
+
+G14_CASES = ["default", "all_terms_l1", "critic_gate", "mask_all", "mask_one", "mask_none", "no_bound_term"]
+
+
+@pytest.mark.parametrize("case", G14_CASES)
+def test_g14_fused_ppo_loss_against_reference(case):
+    """parc_ppo_loss: loss, every logged term and the gradients w.r.t. the network outputs equal what the reference's
+    _compute_loss + autograd produced on the same batch (fixture G14)."""
+    from parc_amd.learning import rl_util
+    z = golden("g14_ppo_loss")
+    assert case in [str(c) for c in z["case_names"]]
+    clip, bw, ew, rw, cw, gate, l1 = [float(v) for v in z[case + "_params"]]
+    mean = T(z["mean"]).requires_grad_(True)
+    logstd = T(z["logstd"]).requires_grad_(True)
+    pred = T(z["pred"]).requires_grad_(True)
+    loss, out = rl_util.ppo_loss(mean, logstd, pred, T(z["norm_action"]), T(z["a_logp"]), T(z["adv"]), T(z[case + "_mask"]),
+                                 T(z[case + "_tar_val"]), clip, bw, ew, rw, cw, gate, bool(l1))
+    g_mean, g_logstd, g_pred = torch.autograd.grad(loss, [mean, logstd, pred])
+    torch.cuda.synchronize()
+    ref = dict(zip([str(k) for k in z["info_names"]], z[case + "_info"]))
+    if case == "mask_none":
+        # no random action in the batch: the reference's actor loss is the mean of an empty selection = NaN and its NaN trap stops
+        # the run (ppo_agent.py:242-252); the kernel must surface the same NaN (the agent's trap reads it), not a silent zero
+        assert np.isnan(ref["actor_loss"]) and np.isnan(ref["loss"])
+        assert torch.isnan(loss) and torch.isnan(out[2])
+        assert abs(out[1].item() - ref["critic_loss"]) <= 2e-6 * max(1.0, abs(ref["critic_loss"]))
+        return
+    got = {"loss": out[0], "critic_loss": out[1], "actor_loss": out[2], "clip_frac": out[3], "imp_ratio": out[4], "action_bound_loss": out[5],
+           "action_entropy": out[6], "action_reg_loss": out[7]}
+    for k, r in ref.items():
+        if np.isnan(r):          # a term the reference does not compute under this configuration (weight 0)
+            continue
+        assert abs(got[k].item() - r) <= 2e-5 * max(1.0, abs(r)), (k, got[k].item(), r)
+    assert out[8].item() == float(z[case + "_mask"].sum())
+    for a, name in ((g_mean, "grad_mean"), (g_logstd, "grad_logstd"), (g_pred, "grad_pred")):
+        b = z[case + "_" + name]
+        scale = max(float(np.abs(b).max()), 1e-6)
+        err = float(np.abs(a.cpu().numpy() - b).max())
+        assert err <= 3e-5 * scale + 1e-9, (name, err, scale)
+    if case == "critic_gate":        # critic loss > 20: the actor term must not move the policy (ppo_agent.py:225-238)
+        assert ref["critic_loss"] > 20.0 and float(g_mean.abs().max()) == 0.0 and float(g_logstd.abs().max()) == 0.0 and float(g_pred.abs().max()) > 0
+
+
+def test_g15_normalizer_kernels_against_reference():
+    """moments (K22: parc_moments_accumulate) + normalise-and-clamp (K12: parc_normalize_clamp) through the Normalizer class."""
+    from test_host_logic import check_normalizer_against_g15
+    check_normalizer_against_g15(DEV)
+    # and the kernel path was the one taken: same call on a tensor the kernel cannot take (unaligned view) agrees bit for bit
+    from parc_amd.learning.normalizer import Normalizer
+    z = golden("g15_normalizer")
+    nz = Normalizer((1312,), DEV, clip=10.0)
+    nz._mean[:] = T(z["mean_2"])
+    nz._std[:] = T(z["std_2"])
+    q = T(z["query"])
+    pad = torch.zeros(q.numel() + 1, device=DEV)
+    pad[1:] = q.flatten()
+    assert torch.equal(nz.normalize(q), nz.normalize(pad[1:].view_as(q)))
+
+
+def test_g16_return_tracker_kernel_against_reference():
+    """K21 (parc_return_tracker_update) and the tracking-error tracker over the reference's 40-step episode stream."""
+    from test_host_logic import check_trackers_against_g16
+    check_trackers_against_g16(DEV)
+
+
+def test_g17_action_head_against_reference(km):
+    """K14 (parc_action_head): sample / mode by the exploration mask, log-probability and un-normalised action, given the
+    reference's noise and Bernoulli draws (fixture G17, PPOAgent._decide_action in TRAIN and TEST mode)."""
+    from parc_amd import _hip
+    z = golden("g17_action_head")
+    n, A = z["mean"].shape
+    mean, logstd, noise = T(z["mean"]), T(z["logstd"]), T(z["noise"])
+    a_mean, a_std = T(0.5 * (z["a_high"] + z["a_low"])), T(0.5 * (z["a_high"] - z["a_low"]))
+    p = _hip.ptr
+    for mode, mask in (("TRAIN", T(z["bernoulli"])), ("TEST", torch.zeros(n, device=DEV))):
+        a, logp = torch.empty_like(mean), torch.empty(n, device=DEV)
+        _hip.check(_hip.lib().parc_action_head(_hip.stream(), n, A, p(mean), p(logstd), p(noise), p(mask), p(a_mean), p(a_std), p(a), p(logp)),
+                   "parc_action_head")
+        torch.cuda.synchronize()
+        close(a, z["action_" + mode], atol=2e-6, rtol=2e-6)
+        close(logp, z["a_logp_" + mode], atol=2e-4, rtol=2e-6)
+        np.testing.assert_array_equal(mask.cpu().numpy(), z["mask_" + mode])
+    assert 0.5 < z["mask_TRAIN"].mean() < 0.9 and z["mask_TEST"].sum() == 0
+    # the distribution object the model hands out: entropy / regulariser / log-probability as the reference's class computes them
+    from parc_amd.learning import dm_ppo_model
+    dist = dm_ppo_model.DistributionGaussianDiag(mean, logstd.expand(n, A))
+    close(dist.entropy(), z["entropy"], atol=1e-5)
+    close(dist.param_reg(), z["param_reg"], atol=1e-5)
+    close(dist.log_prob(mean + torch.exp(logstd) * noise), z["logp_of_noise"], atol=2e-4, rtol=2e-6)
+    # action-bound penalty (base_agent.py:456-475) = the bound term of the fused loss with every other term off
+    from parc_amd.learning import rl_util
+    ones = torch.ones(n, device=DEV)
+    zeros = torch.zeros(n, device=DEV)
+    _, out = rl_util.ppo_loss(mean, logstd, zeros, mean.clone(), dist.log_prob(mean), zeros, ones, zeros, 0.2, 1.0, 0.0, 0.0, 0.0)
+    assert abs(out[5].item() - float(z["action_bound_loss"].mean())) <= 1e-5 * max(1.0, float(z["action_bound_loss"].mean()))
+
+
+def test_g18_tracking_error_on_the_device(km, mlib):
+    """IGParkourEnv._compute_tracking_error (compute_tracking_error, mgdm_dm_util.py:578-611) on the G6 state."""
+    from parc_amd import _hip
+    from parc_amd.envs.ig_parkour.ig_parkour_env import IGParkourEnv
+    core, z = _core_from_golden(km, mlib)
+    core.post_step(_hip.POST_REF)
+    env = IGParkourEnv.__new__(IGParkourEnv)            # the method needs the kinematic model, the core and the state views only
+    env._kin_char_model, env._core = km, core
+    n = 64
+    env._char_root_pos, env._char_root_rot = core.root_state[:, 0:3], core.root_state[:, 3:7]
+    env._char_root_vel, env._char_root_ang_vel = core.root_state[:, 7:10], core.root_state[:, 10:13]
+    ds = core.dof_state.view(n, 28, 2)
+    env._char_dof_pos, env._char_dof_vel = ds[..., 0], ds[..., 1]
+    te = env._compute_tracking_error()
+    torch.cuda.synchronize()
+    assert te.shape == (n, 7)
+    close(te[:, [0, 2]], z["tracking_error"][:, [0, 2]], atol=2e-5)            # positions
+    close(te[:, [1, 3]], z["tracking_error"][:, [1, 3]], atol=1e-4)            # angles
+    close(te[:, 4:7], z["tracking_error"][:, 4:7], atol=3e-4)                  # finite-difference velocities of the clip database
+
+
+def test_g19_recorded_clip_loads_like_in_the_reference(km):
+    """A clip this package recorded (tests/golden/recorded/, written on the GPU by record mode) loaded by this package's MotionLib
+    gives the frame arrays the REFERENCE's MotionLib derived from the same file (fixture G19)."""
+    from parc_amd.anim.motion_lib import MotionLib
+    z = golden("g19_recorded_files")
+    ml = MotionLib(os.path.join(REPO, "tests", "golden", "recorded", "recorded_clip_dm.pkl"), km, DEV, contact_info=True)
+    assert ml.num_motions() == 1 and int(ml._motion_num_frames[0]) == int(z["num_frames"][0])
+    assert abs(ml._motion_lengths[0].item() - float(z["length"][0])) < 1e-6
+    rp, rr, rv, rav, jr, dv, cont = ml.calc_motion_frame(torch.zeros(3, dtype=torch.int64, device=DEV), T([0.0, 0.21, 10.0]))
+    close(rp, z["q_root_pos"])
+    close(rr, z["q_root_rot"])
+    close(jr, z["q_joint_rot"])
+    close(cont, z["q_contacts"])
+    F = int(z["num_frames"][0])
+    ids = torch.zeros(F, dtype=torch.int64, device=DEV)
+    times = torch.arange(F, device=DEV, dtype=torch.float32) / 30.0
+    rp, rr, rv, rav, jr, dv, cont = ml.calc_motion_frame(ids, times)
+    close(rp, z["frame_root_pos"], atol=2e-5)
+    sign = np.sign(np.sum(rr.cpu().numpy() * z["frame_root_rot"], axis=-1, keepdims=True))
+    close(rr.cpu().numpy() * sign, z["frame_root_rot"], atol=2e-5)
+    t = ml._terrains[0]
+    np.testing.assert_array_equal(np.asarray(t.hf.cpu()), z["ter_hf"])

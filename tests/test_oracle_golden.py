@@ -224,3 +224,36 @@ def test_g13_points_hf_sdf(oracle):
     pts = np.array([[[0.8, 0.8, 0.75], [0.8, 0.8, 1.5], [0.0, 0.0, 0.3], [0.0, 0.0, 0.05]]], np.float32)
     d = oracle.points_hf_sdf(pts, hf, np.zeros((1, 2), np.float32), np.array([0.4, 0.4], np.float32))
     close(d[0], [-0.2, 0.2, 0.2, 0.05], atol=1e-6)
+
+
+def test_g8b_done_every_branch(oracle, ref_mlib):
+    """Fixture G8b trips every branch of compute_done / update_done on its own (mgdm_dm_util.py:392-460, dm_env.py:746-783): each of
+    the 14 per-body pose distances, root position, root rotation, the fall test (height AND force on non-contact bodies), the
+    first-step exemption, timeout, motion end on CLAMP vs WRAP clips."""
+    z = golden("g8b_done_branches")
+    times = z["time_buf"] + z["motion_time_offsets"]
+    common = dict(time_buf=z["time_buf"], ep_len=10.0, char_root_rot=z["char_root_rot"], body_pos=z["char_rigid_body_pos"],
+                  ref_root_rot=z["ref_root_rot"], ref_body_pos=z["ref_body_pos"], contact_forces=z["contact_forces"],
+                  env_offsets=z["env_offsets"], hf=z["hf"], min_point=z["min_point"], dxdy=z["dxdy"], termination_height=0.15,
+                  pose_termination=True, pose_termination_dist=z["pose_termination_dist"], enable_early_termination=True,
+                  track_root=True, root_pos_term_dist=0.6, root_rot_term_angle=1.309, motion_ids=z["motion_ids"],
+                  motion_times=times, motion_len=ref_mlib.length, motion_loop_mode=ref_mlib.loop_mode,
+                  fail_rates=np.ones(4, np.float32))
+    for tag, cb in (("nocontact", []), ("feet", [int(b) for b in z["feet"]])):
+        pre, fin, fr = oracle.update_done(contact_body_ids=cb, **common)
+        bad = np.nonzero(pre != z["done_" + tag])[0]
+        assert bad.size == 0, [(str(z["case"][i]), int(pre[i]), int(z["done_" + tag][i])) for i in bad]
+        np.testing.assert_array_equal(fin, z["done_final_" + tag])
+        close(fr, z["fail_rates_" + tag], atol=1e-6)
+    # the fixture does exercise what it names (flags produced by the reference itself)
+    case = [str(c) for c in z["case"]]
+    exp = z["expect_fail"]
+    for i, c in enumerate(case):
+        tag = "done_feet" if c.startswith("fall") else "done_nocontact"
+        if exp[i] >= 0:
+            assert (z[tag][i] == 1) == bool(exp[i]), c
+    assert sum(c.endswith("_over") and c.startswith("body") for c in case) == 14 * 3
+    assert z["done_nocontact"][case.index("timeout")] == 3 and z["done_nocontact"][case.index("timeout_exact")] == 3
+    assert z["done_nocontact"][case.index("just_before_timeout")] == 0 and z["done_nocontact"][case.index("timeout_and_fail")] == 1
+    assert z["motion_end"][case.index("motion_end_clamp_past")] and not z["motion_end"][case.index("motion_end_wrap_past")]
+    assert z["done_final_nocontact"][case.index("motion_end_clamp_past")] == 1 and z["done_final_nocontact"][case.index("motion_end_wrap_far_past")] == 0
