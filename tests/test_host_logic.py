@@ -491,7 +491,12 @@ def check_normalizer_against_g15(device):
         if r == 0:                               # column 5 is constant in round 0: its variance is fp32 cancellation noise, which
             assert std[5] < 2e-3 and ref_std[5] < 2e-3      # depends on the summation order; everything else must agree
             std[5] = ref_std[5] = 0.0
-        np.testing.assert_allclose(std, ref_std, rtol=2e-4, atol=2e-6)
+        # std = sqrt(E[x^2] - E[x]^2) in fp32 (normalizer.py:88-93): a column whose spread is small against its mean loses digits
+        # to cancellation, by an amount that depends on the summation order -> tolerance from the conditioning of that formula
+        ref_mean = z["mean_%d" % r]
+        tol = 2e-4 * ref_std + 2e-6 + 8 * 1.2e-7 * (ref_mean ** 2 + ref_std ** 2) / np.maximum(ref_std, 1e-4)
+        assert np.all(np.abs(std - ref_std) <= tol), np.nonzero(np.abs(std - ref_std) > tol)
+        assert np.mean(np.abs(std - ref_std) <= 2e-4 * ref_std + 2e-6) > 0.99
     assert torch.all(nz._mean[766:] == 0) and torch.all(nz._std[766:] == 1)
     # normalise with the REFERENCE's statistics, so that the comparison is about normalize() alone
     nz._mean[:] = T(z["mean_2"])
