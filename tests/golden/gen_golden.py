@@ -12,7 +12,9 @@ The two motion clips that ship with the reference (data/terrains/*.pkl) are read
 non-executing reader parc_amd.util.safe_pickle (they are never unpickled); temporary motion files that
 the reference's MotionLib then loads are written by this script itself.
 
-usage:  python tests/golden/gen_golden.py
+usage:  python tests/golden/gen_golden.py            # every stage, rewrites tests/golden/*.npz
+        python tests/golden/gen_golden.py --check    # regenerate into a scratch dir and compare with the committed fixtures
+        python tests/golden/gen_golden.py --only-<stage>
 """
 import os
 import pickle
@@ -1004,7 +1006,7 @@ def gen_recorded_files():
     """G19: the files THIS package wrote on the GPU (tests/golden/recorded/: a clip recorded by record mode and the terrain cache,
     produced by tools/make_recorded_fixture.py) opened by the REFERENCE's readers: MotionLib._load_motions (anim/motion_lib.py:204-380,
     plain pickle.load) and DeepMimicEnv.load_terrain (envs/ig_parkour/dm_env.py:493-507)."""
-    rec_dir = os.path.join(OUT, "recorded")
+    rec_dir = os.path.join(HERE, "recorded")
     km = load_char()
     clip = os.path.join(rec_dir, "recorded_clip_dm.pkl")
     ml = motion_lib.MotionLib(clip, km, "cpu", contact_info=True)
@@ -1054,9 +1056,28 @@ def main():
            "procgen": gen_procgen, "terrain-geometry": gen_terrain_geometry, "done-branches": gen_done_branches, "ppo-loss": gen_ppo_loss,
            "normalizer": gen_normalizer, "trackers": gen_trackers, "action-head": gen_action_head, "recorded-files": gen_recorded_files}
     picked = [s_ for s_ in STAGES if "--only-" + s_ in sys.argv]
+    if "--check" in sys.argv:
+        # regenerate everything into a scratch directory and compare with the committed fixtures array by array
+        global OUT
+        OUT = tempfile.mkdtemp(prefix="parc_golden_check_")
     for s_ in picked or STAGES:
         print("== stage", s_)
         run[s_]()
+    if "--check" in sys.argv:
+        bad = 0
+        for f in sorted(os.listdir(OUT)):
+            if f.endswith(".json"):
+                same = open(os.path.join(OUT, f)).read() == open(os.path.join(HERE, f)).read()
+                bad += not same
+                continue
+            a, b = np.load(os.path.join(OUT, f)), np.load(os.path.join(HERE, f))
+            for k in sorted(set(a.files) | set(b.files)):
+                same = k in a.files and k in b.files and a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f")
+                if not same:
+                    bad += 1
+                    print("DIFFERS", f, k)
+        print("check: {} arrays differ from the committed fixtures".format(bad))
+        sys.exit(1 if bad else 0)
 
 
 if __name__ == "__main__":
