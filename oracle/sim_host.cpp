@@ -3,7 +3,14 @@
 // reference: it is the same source compiled for the CPU, used by tests to check physical invariants without a
 // GPU, to run sanitizers, and to cross-check the device build.  Same signatures as include/parc_sim.h but all
 // pointers are HOST pointers.
+#include <string.h>
+
 #include "../parc_amd/csrc/parc_sim_core.h"
+
+// >= 0: the per-env work arrays start from this byte pattern (0xFF = NaN everywhere) instead of whatever the stack holds.  A
+// read of an element that the algorithm never wrote then shows up as a changed (NaN) result: tests compare fill 0x00 with 0xFF.
+static int g_fill = -1;
+extern "C" void sim_host_set_fill(int byte) { g_fill = byte; }
 
 extern "C" int sim_host_step(const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state, float *dof_state,
                              float *rigid_body_state, float *contact_forces, const float *env_offsets, const float *action,
@@ -12,6 +19,7 @@ extern "C" int sim_host_step(const parc_sim_model_t *model, parc_terrain_t terra
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < n_envs; ++e) {
         parc_sim::Scratch s;
+        if (g_fill >= 0) memset((void *)&s, g_fill, sizeof s);
         parc_sim::env_step(*model, terrain, env_offsets + 3 * (size_t)e, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e,
                            rigid_body_state + 13 * (size_t)B * e, contact_forces + 3 * (size_t)B * e, action + (size_t)D * e, action_low,
                            action_high, n_substeps, h, s);

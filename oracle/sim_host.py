@@ -6,7 +6,11 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "_build", "libparc_sim_host.so")
+# PARC_SIM_HOST_LIB: another build of the same sources (oracle/Makefile `sanitize`: libparc_sim_host_asan.so / _poison.so)
+_LIB = os.environ.get("PARC_SIM_HOST_LIB") or os.path.join(_HERE, "_build", "libparc_sim_host.so")
+# which formulation HostSim.step runs by default: "core" = one env per lane (parc_sim_core.h), "bpl" = the body-per-lane kernel
+# the product launches (parc_sim_bpl.h) under the 16-fiber lane emulation of sim_host_bpl.cpp
+DEFAULT_VARIANT = os.environ.get("PARC_SIM_HOST_VARIANT", "core")
 _lib = None
 
 
@@ -18,9 +22,15 @@ class TerrainS(ctypes.Structure):
 def lib():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE] + (["sanitize"] if "PARC_SIM_HOST_LIB" in os.environ else []), stdout=subprocess.DEVNULL)
         _lib = ctypes.CDLL(_LIB)
     return _lib
+
+
+def set_fill(byte):
+    """Work arrays of both formulations start from this byte pattern (0xFF = NaN); -1 = leave them as they come."""
+    lib().sim_host_set_fill(ctypes.c_int(byte))
+    lib().sim_host_bpl_set_fill(ctypes.c_int(byte))
 
 
 def _p(a):
@@ -30,8 +40,9 @@ def _p(a):
 class HostSim:
     """State arrays in the Isaac Gym layouts, stepped on the CPU."""
 
-    def __init__(self, model_struct, n, hf, min_point, dxdy, num_bodies=15, dof_size=28):
+    def __init__(self, model_struct, n, hf, min_point, dxdy, num_bodies=15, dof_size=28, variant=None):
         self.m = model_struct
+        self.variant = variant or DEFAULT_VARIANT
         self.n, self.B, self.D = n, num_bodies, dof_size
         self.hf = np.ascontiguousarray(hf, dtype=np.float32)
         self.ter = TerrainS(_p(self.hf), self.hf.shape[0], self.hf.shape[1], float(min_point[0]), float(min_point[1]),
@@ -47,7 +58,8 @@ class HostSim:
 
     def step(self, action, n_sub=4, h=1.0 / 120.0):
         action = np.ascontiguousarray(action, dtype=np.float32)
-        lib().sim_host_step(ctypes.byref(self.m), self.ter, self.n, _p(self.root_state), _p(self.dof_state), _p(self.rigid_body_state),
+        fn = lib().sim_host_step if self.variant == "core" else lib().sim_host_step_bpl
+        fn(ctypes.byref(self.m), self.ter, self.n, _p(self.root_state), _p(self.dof_state), _p(self.rigid_body_state),
                             _p(self.contact_forces), _p(self.env_offsets), _p(action), _p(self.act_lo), _p(self.act_hi),
                             ctypes.c_int(n_sub), ctypes.c_float(h))
 

@@ -35,17 +35,9 @@ __global__ __launch_bounds__(64) void sim_step_bpl_kernel(const parc_sim_model_t
     const int e = min((int)blockIdx.x * BPL_EPB + g, n_envs - 1);      // tail groups recompute the last env (same values)
     const parc_sim_model_t &m = *model;
     const int B = m.num_bodies, D = m.dof_size;
-    const Lane L = load_lane(m, b);
-    int maxd = L.depth;
-#pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) maxd = max(maxd, __shfl_xor(maxd, o, BPL_G));
-    LState x;
-    load_lane_state(m, L, b, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e, action + (size_t)D * e, act_lo, act_hi, x);
-    const parc_sim::V3 off = parc_sim::ld(env_offsets + 3 * (size_t)e);
-    const float w = 1.0f / (float)n_sub;
-    for (int s = 0; s < n_sub; ++s) substep(m, ter, off, L, b, maxd, x, h, w, lds[g], ccache[threadIdx.x]);
-    store_lane_state(L, b, maxd, x, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e, rigid_body_state + 13 * (size_t)B * e,
-                     contact_forces + 3 * (size_t)B * e);
+    step_lane(m, ter, b, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e, rigid_body_state + 13 * (size_t)B * e,
+              contact_forces + 3 * (size_t)B * e, env_offsets + 3 * (size_t)e, action + (size_t)D * e, act_lo, act_hi, n_sub, h, lds[g],
+              ccache[threadIdx.x]);
     // IGEnv._update_time (ig_env.py:862-865) for callers that ask for it: the env's step counter and clock advance with the simulator
     if (timestep && b == 0 && (int)blockIdx.x * BPL_EPB + g < n_envs) {
         const int ts = timestep[e] + 1;

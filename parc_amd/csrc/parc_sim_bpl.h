@@ -8,7 +8,12 @@
 // instead of per-thread scratch arrays.  Parent <- child accumulation of the inward sweep goes through LDS (27 floats per
 // child), parent -> child broadcasts of the outward sweeps are 16-lane shuffles.
 #pragma once
+#if !defined(PARC_LANE_EMU)
 #include <hip/hip_runtime.h>
+#endif
+// (PARC_LANE_EMU: oracle/sim_host_bpl.cpp compiles this very header for the host, with the lane primitives __shfl / __shfl_xor /
+// __ballot / __syncthreads / threadIdx provided by a 16-fiber lock-step emulation, so that sanitizers and the CPU invariant tests
+// reach the kernel the product runs -- test infrastructure, never linked into libparc_hip.so)
 
 #include "parc_sim_core.h"
 
@@ -450,6 +455,26 @@ __device__ __forceinline__ void store_lane_state(const Lane &L, int b, int maxd,
         st(o + 10, mul(k.R, k.v.a));
         st(contact_forces + 3 * b, x.cforce);
     }
+}
+
+// The whole env step as seen by lane b of an env's 16-lane group: what sim_step_bpl_kernel runs (and what the host lane
+// emulation runs, lane by lane in lock step).  `lds`: BPL_G * BPL_CONTRIB floats shared by the group, `cc`: this lane's contact cache.
+__device__ __forceinline__ void step_lane(const parc_sim_model_t &m, const parc_terrain_t &ter, int b, float *root_state, float *dof_state,
+                                          float *rigid_body_state, float *contact_forces, const float *env_offset, const float *action,
+                                          const float *act_lo, const float *act_hi, int n_sub, float h, float *lds, float *cc) {
+    const Lane L = load_lane(m, b);
+    int maxd = L.depth;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) {
+        const int other = __shfl_xor(maxd, o, BPL_G);
+        maxd = other > maxd ? other : maxd;
+    }
+    LState x;
+    load_lane_state(m, L, b, root_state, dof_state, action, act_lo, act_hi, x);
+    const V3 off = ld(env_offset);
+    const float w = 1.0f / (float)n_sub;
+    for (int s = 0; s < n_sub; ++s) substep(m, ter, off, L, b, maxd, x, h, w, lds, cc);
+    store_lane_state(L, b, maxd, x, root_state, dof_state, rigid_body_state, contact_forces);
 }
 
 }  // namespace parc_sim_bpl

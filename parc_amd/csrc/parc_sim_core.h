@@ -678,6 +678,9 @@ PARC_HD void env_step(const parc_sim_model_t &m, const parc_terrain_t &ter, cons
                       float *rigid_body_state, float *contact_forces, const float *action, const float *act_lo, const float *act_hi,
                       int n_sub, float h, Scratch &s) {
     State x;
+#if defined(PARC_SIM_FILL_STATE)     // host test builds: start from a known byte pattern (oracle/Makefile `poison`)
+    memset((void *)&x, PARC_SIM_FILL_STATE, sizeof x);
+#endif
     load_state(m, root_state, dof_state, action, act_lo, act_hi, x);
     V3 off = ld(env_offset);
     const float w = 1.0f / (float)n_sub;

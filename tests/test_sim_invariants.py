@@ -11,6 +11,17 @@ import torch
 from conftest import REPO  # noqa: F401
 
 
+@pytest.fixture(scope="module", params=["core", "bpl"], autouse=True)
+def formulation(request):
+    """Every invariant is checked on both formulations of the same equations: the one-env-per-lane core (parc_sim_core.h) and
+    the body-per-lane kernel the product launches (parc_sim_bpl.h, run on the host by the lane emulation of sim_host_bpl.cpp)."""
+    from oracle import sim_host
+    prev = sim_host.DEFAULT_VARIANT
+    sim_host.DEFAULT_VARIANT = request.param
+    yield request.param
+    sim_host.DEFAULT_VARIANT = prev
+
+
 @pytest.fixture(scope="module")
 def model():
     from parc_amd.anim.kin_char_model import KinCharModel
@@ -204,3 +215,74 @@ def test_random_actions_stay_finite(model):
     assert np.all(np.isfinite(sim.root_state)) and np.all(np.isfinite(sim.dof_state))
     assert np.all(np.abs(sim.root_state[:, 7:13]) < 120.0)
     assert np.all(sim.root_state[:, 2] > -0.2)          # nobody fell through the ground
+
+
+def test_both_formulations_agree(model):
+    """The body-per-lane kernel (level-synchronous sweeps, contacts cached per lane) and the one-env-per-lane core (serial loops)
+    are two independent codings of the same equations: on a contact-rich scene they must agree to fp32 reassociation error."""
+    from oracle.sim_host import HostSim
+    km, sm = model
+    rng = np.random.default_rng(11)
+    hf = (rng.random((40, 40)) * 0.5).astype(np.float32)
+    n = 12
+    sims = [HostSim(copy.deepcopy(sm.struct), n, hf, [-4.0, -4.0], [0.4, 0.4], variant=v) for v in ("core", "bpl")]
+    rs = np.zeros((n, 13), np.float32)
+    rs[:, 0:2] = rng.random((n, 2)) * 4.0
+    rs[:, 2] = 1.0 + 0.3 * rng.random(n)
+    rs[:, 6] = 1.0
+    ds = (rng.standard_normal((n, 28, 2)) * 0.2).astype(np.float32)
+    for s_ in sims:
+        s_.root_state[:], s_.dof_state[:] = rs, ds
+    hit = 0.0
+    for _ in range(12):
+        act = (rng.standard_normal((n, 28)) * 0.5).astype(np.float32)
+        for s_ in sims:
+            s_.step(act, n_sub=4, h=1.0 / 120.0)
+        hit = max(hit, float(np.abs(sims[0].contact_forces).max()))
+        a, b = sims
+        np.testing.assert_allclose(b.root_state[:, 0:7], a.root_state[:, 0:7], atol=2e-4)
+        np.testing.assert_allclose(b.dof_state[..., 0], a.dof_state[..., 0], atol=5e-4)
+        np.testing.assert_allclose(b.rigid_body_state[..., 0:3], a.rigid_body_state[..., 0:3], atol=5e-4)
+        np.testing.assert_allclose(b.contact_forces, a.contact_forces, atol=1.0, rtol=1e-2)     # N; stiff in the penetration depth
+        for s_ in sims:                      # restart both from the same state: the comparison is per step, not of chaotic drift
+            s_.root_state[:], s_.dof_state[:] = a.root_state, a.dof_state
+    assert hit > 50.0                        # the scene does have contacts
+
+
+def test_no_read_of_unwritten_work_memory(model):
+    """Per-env work arrays (the core's Scratch / State, the kernel's LDS exchange buffer and contact cache) filled with NaN
+    instead of zero must not change a single bit of the result: nothing reads an element the algorithm has not written."""
+    import os
+    import subprocess
+    from oracle import sim_host
+    from oracle.sim_host import HostSim
+    here = os.path.dirname(os.path.abspath(sim_host.__file__))
+    subprocess.check_call(["make", "-C", here, "sanitize"], stdout=subprocess.DEVNULL)
+    code = r"""
+import copy, sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import sim_host
+from parc_amd.anim.kin_char_model import KinCharModel
+from parc_amd.assets import humanoid_spec
+from parc_amd.sim_model import SimModel
+km = KinCharModel("cpu"); km.load_char_file(humanoid_spec.write_mjcf()); sm = SimModel(km)
+out = {}
+for variant in ("core", "bpl"):
+    for fill in (0x00, 0xFF):
+        sim_host.set_fill(fill)
+        rng = np.random.default_rng(4)
+        hf = (rng.random((40, 40)) * 0.5).astype(np.float32)
+        sim = sim_host.HostSim(copy.deepcopy(sm.struct), 6, hf, [-4.0, -4.0], [0.4, 0.4], variant=variant)
+        sim.root_state[:, 0:2] = rng.random((6, 2)) * 4.0
+        sim.root_state[:, 2] = 1.0
+        for _ in range(20):
+            sim.step(rng.standard_normal((6, 28)).astype(np.float32), n_sub=4, h=1.0 / 120.0)
+        out[(variant, fill)] = np.concatenate([sim.root_state.ravel(), sim.dof_state.ravel(), sim.rigid_body_state.ravel(), sim.contact_forces.ravel()])
+        assert np.all(np.isfinite(out[(variant, fill)])), (variant, fill)
+    assert np.array_equal(out[(variant, 0x00)], out[(variant, 0xFF)]), variant
+    assert np.abs(sim.contact_forces).max() > 50.0
+print("identical")
+""" % os.path.dirname(here)
+    env = dict(os.environ, PARC_SIM_HOST_LIB=os.path.join(here, "_build", "libparc_sim_host_poison.so"))
+    res = subprocess.run([__import__("sys").executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0 and "identical" in res.stdout, res.stderr[-3000:]
