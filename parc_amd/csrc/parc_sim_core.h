@@ -32,6 +32,14 @@
 #define PARC_HD static inline
 #endif
 
+// PARC_LOOP(k): no-op in the product.  tools/bisect_sim_o3.py rebuilds parc_sim.hip with -DPARC_BISECT -DPARC_ROLL_<k> to keep the
+// loops tagged k rolled at -O3, which is how the -O3 divergence of sim_step_kernel was localised.
+#if defined(PARC_BISECT)
+#include "parc_sim_bisect.h"
+#else
+#define PARC_LOOP(k)
+#endif
+
 namespace parc_sim {
 
 // Scalar primitives.  Device: the hardware's 1-ulp sqrt / reciprocal and short polynomials (the kernel is one long
@@ -104,29 +112,34 @@ PARC_HD V3 mulT(const M3 &a, V3 v) {
 }
 PARC_HD M3 mul(const M3 &a, const M3 &b) {
     M3 c;
+    PARC_LOOP(12)
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) c.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
     return c;
 }
 PARC_HD M3 mulABt(const M3 &a, const M3 &b) {
     M3 c;
+    PARC_LOOP(12)
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) c.m[3 * i + j] = a.m[3 * i] * b.m[3 * j] + a.m[3 * i + 1] * b.m[3 * j + 1] + a.m[3 * i + 2] * b.m[3 * j + 2];
     return c;
 }
 PARC_HD M3 transpose(const M3 &a) {
     M3 c;
+    PARC_LOOP(12)
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) c.m[3 * i + j] = a.m[3 * j + i];
     return c;
 }
 PARC_HD M3 add(const M3 &a, const M3 &b) {
     M3 c;
+    PARC_LOOP(12)
     for (int i = 0; i < 9; ++i) c.m[i] = a.m[i] + b.m[i];
     return c;
 }
 PARC_HD M3 sub(const M3 &a, const M3 &b) {
     M3 c;
+    PARC_LOOP(12)
     for (int i = 0; i < 9; ++i) c.m[i] = a.m[i] - b.m[i];
     return c;
 }
@@ -146,6 +159,7 @@ PARC_HD M3 outer(V3 a, V3 b) {
 }
 PARC_HD M3 ident(float s) {
     M3 c;
+    PARC_LOOP(12)
     for (int i = 0; i < 9; ++i) c.m[i] = 0.f;
     c.m[0] = c.m[4] = c.m[8] = s;
     return c;
@@ -279,6 +293,7 @@ PARC_HD bool sphere_vs_columns(const parc_terrain_t &t, V3 p, float rho, float &
     if (rho > 0.f) {
         // higher neighbours within reach: closest point on the neighbour's box (side face or top edge)
         int si = fx >= 0.f ? 1 : -1, sj = fy >= 0.f ? 1 : -1;
+        PARC_LOOP(13)
         for (int k = 0; k < 3; ++k) {
             int di = (k == 1) ? 0 : si, dj = (k == 0) ? 0 : sj;
             float hn = terrain_h(t, ci + di, cj + dj);
@@ -315,6 +330,7 @@ PARC_HD void pass1(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_
     s.P[0] = x.root_pos;
     s.v[0] = x.root_vel;
     s.c[0] = SV{v3(0, 0, 0), v3(0, 0, 0)};
+    PARC_LOOP(0)
     for (int i = 1; i < B; ++i) {
         const int p = m.parent[i];
         M3 E = mul(qmat(Q4{m.local_rotation[i][0], m.local_rotation[i][1], m.local_rotation[i][2], m.local_rotation[i][3]}), qmat(x.jq[i]));
@@ -332,6 +348,7 @@ PARC_HD void pass1(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_
         s.v[i] = vi;
         s.c[i] = SV{cross(vi.a, wj), cross(vi.l, wj)};
     }
+    PARC_LOOP(1)
     for (int i = 0; i < B; ++i) {
         const float mass = m.mass[i];
         V3 hc = mass * ld(m.com[i]);
@@ -355,6 +372,7 @@ PARC_HD void pass1(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_
         s.pA[i] = p;
     }
     // contacts: implicit spring-damper + regularised friction per penetrating sample sphere
+    PARC_LOOP(2)
     for (int k = 0; k < m.num_spheres; ++k) {
         const int b = m.sph_body[k];
         V3 rb = ld(m.sph_pos[k]);
@@ -382,6 +400,7 @@ PARC_HD void pass1(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_
         M3 SZ = mul(Sr, Z);
         // A += h * (-Sr Z Sr), B += h * (Sr Z), C += h * Z
         M3 SZS = mul(SZ, Sr);
+        PARC_LOOP(12)
         for (int q = 0; q < 9; ++q) {
             s.IA[b].A.m[q] -= h * SZS.m[q];
             s.IA[b].B.m[q] += h * SZ.m[q];
@@ -394,6 +413,7 @@ PARC_HD void pass1(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_
 
 // After the accelerations are known: realised contact force of every body, world frame (F+ = F0 - Z h J a)
 PARC_HD void report_contacts(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_off, const Scratch &s, float h, float weight, State &x) {
+    PARC_LOOP(3)
     for (int k = 0; k < m.num_spheres; ++k) {
         const int b = m.sph_body[k];
         V3 rb = ld(m.sph_pos[k]);
@@ -432,6 +452,7 @@ PARC_HD void substep(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 en
     pass1(m, ter, env_off, x, s, h);
     // ---- joint drives (implicit PD) and limits: tau and the diagonal augmentation of D
     // ---- pass 2: leaves -> root
+    PARC_LOOP(4)
     for (int i = B - 1; i >= 1; --i) {
         const int p = m.parent[i];
         const int jt = m.joint_type[i];
@@ -444,6 +465,7 @@ PARC_HD void substep(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 en
             V3 e = q_to_exp(x.jq[i]);
             float tau[3], aug[3];
             const float ev[3] = {err.x, err.y, err.z}, wv[3] = {x.jw[i].x, x.jw[i].y, x.jw[i].z}, ee[3] = {e.x, e.y, e.z};
+            PARC_LOOP(5)
             for (int k = 0; k < 3; ++k) {
                 float kp = m.kp[d0 + k], kd = m.kd[d0 + k];
                 float t = kp * ev[k] - kd * wv[k];
@@ -537,6 +559,7 @@ PARC_HD void substep(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 en
         s.a[0] = SV{alpha, lin};
     }
     // ---- pass 3: root -> leaves, joint accelerations and velocity update
+    PARC_LOOP(6)
     for (int i = 1; i < B; ++i) {
         const int p = m.parent[i];
         const int jt = m.joint_type[i];
@@ -570,6 +593,7 @@ PARC_HD void substep(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 en
     }
     x.root_pos = x.root_pos + h * mul(s.R[0], x.root_vel.l);
     x.root_rot = qnormalize(qmul(x.root_rot, exp_to_q(h * x.root_vel.a)));
+    PARC_LOOP(7)
     for (int i = 1; i < B; ++i) {
         const int jt = m.joint_type[i];
         if (jt == PARC_JOINT_SPHERICAL) {
@@ -593,6 +617,7 @@ PARC_HD void load_state(const parc_sim_model_t &m, const float *root_state, cons
     M3 R = qmat(x.root_rot);
     x.root_vel.l = mulT(R, ld(root_state + 7));    // world -> body coordinates
     x.root_vel.a = mulT(R, ld(root_state + 10));
+    PARC_LOOP(8)
     for (int i = 0; i < m.num_bodies; ++i) {
         x.jq[i] = Q4{0.f, 0.f, 0.f, 1.f};
         x.tq[i] = Q4{0.f, 0.f, 0.f, 1.f};
@@ -605,6 +630,7 @@ PARC_HD void load_state(const parc_sim_model_t &m, const float *root_state, cons
             x.jq[i] = exp_to_q(v3(dof_state[2 * d0], dof_state[2 * (d0 + 1)], dof_state[2 * (d0 + 2)]));
             x.jw[i] = v3(dof_state[2 * d0 + 1], dof_state[2 * (d0 + 1) + 1], dof_state[2 * (d0 + 2) + 1]);
             float t[3];
+            PARC_LOOP(8)
             for (int k = 0; k < 3; ++k) t[k] = clampf(action[d0 + k], act_lo[d0 + k], act_hi[d0 + k]);   // ig_char_env.py:490
             x.tq[i] = exp_to_q(v3(t[0], t[1], t[2]));
         } else if (m.joint_type[i] == PARC_JOINT_HINGE) {
@@ -623,6 +649,7 @@ PARC_HD void store_state(const parc_sim_model_t &m, const State &x, const Scratc
     root_state[3] = x.root_rot.x; root_state[4] = x.root_rot.y; root_state[5] = x.root_rot.z; root_state[6] = x.root_rot.w;
     st(root_state + 7, mul(R, x.root_vel.l));
     st(root_state + 10, mul(R, x.root_vel.a));
+    PARC_LOOP(9)
     for (int i = 1; i < m.num_bodies; ++i) {
         const int d0 = m.dof_idx[i];
         if (m.joint_type[i] == PARC_JOINT_SPHERICAL) {
@@ -649,6 +676,7 @@ PARC_HD void publish_bodies(const parc_sim_model_t &m, const State &x, float *ri
     Q[0] = x.root_rot;
     P[0] = x.root_pos;
     v[0] = x.root_vel;
+    PARC_LOOP(10)
     for (int i = 1; i < m.num_bodies; ++i) {
         const int p = m.parent[i];
         Q4 lq = qmul(Q4{m.local_rotation[i][0], m.local_rotation[i][1], m.local_rotation[i][2], m.local_rotation[i][3]}, x.jq[i]);
@@ -663,6 +691,7 @@ PARC_HD void publish_bodies(const parc_sim_model_t &m, const State &x, float *ri
         v[i].a = mulT(E, v[p].a) + wj;
         v[i].l = mulT(E, v[p].l + cross(v[p].a, r));
     }
+    PARC_LOOP(10)
     for (int i = 0; i < m.num_bodies; ++i) {
         float *o = rigid_body_state + 13 * i;
         st(o, P[i]);
@@ -684,6 +713,7 @@ PARC_HD void env_step(const parc_sim_model_t &m, const parc_terrain_t &ter, cons
     load_state(m, root_state, dof_state, action, act_lo, act_hi, x);
     V3 off = ld(env_offset);
     const float w = 1.0f / (float)n_sub;
+    PARC_LOOP(11)
     for (int k = 0; k < n_sub; ++k) substep(m, ter, off, x, s, h, w);
     store_state(m, x, s, root_state, dof_state, rigid_body_state, contact_forces);
     publish_bodies(m, x, rigid_body_state, contact_forces);
