@@ -80,22 +80,30 @@ def parkour_heightfield(kind, seed, dim, dx):
         np.random.set_state(state[2])
 
 
-def make_dataset(num_clips=64, seed=0, tile_cells=16, dx=0.4, frames_range=(120, 254), flat=False, boxes=10, terrain_kind="boxes"):
+def make_dataset(num_clips=64, seed=0, tile_cells=16, dx=0.4, frames_range=(120, 254), flat=False, boxes=10, terrain_kind="boxes",
+                 tile_cells_range=None):
     """-> list of dict(frames, contacts, fps, loop, weight, hf, min_point, dxdy) with per-clip local terrains.
-    terrain_kind: "boxes" (kin-gen recipe) or "stairs" / "paths" / "mix" (parkour terrains), cycled per clip for "parkour"."""
+    terrain_kind: "boxes" (kin-gen recipe) or "stairs" / "paths" / "mix" (parkour terrains), cycled per clip for "parkour".
+    tile_cells_range=(lo, hi): every clip gets its own rectangular terrain with both sides drawn from [lo, hi] cells (the iter-0
+    dataset keeps terrains up to 45 x 45 cells, PARC/create_dataset_config.yaml:16-17); box terrains only."""
     rng = np.random.default_rng(seed)
     clips = []
-    size = tile_cells * dx
     for k in range(num_clips):
         nf = int(rng.integers(frames_range[0], frames_range[1] + 1))
         kind = ("stairs", "paths", "mix", "boxes")[k % 4] if terrain_kind == "parkour" else terrain_kind
-        if flat:
-            hf = np.zeros((tile_cells, tile_cells), np.float32)
-        elif kind == "boxes":
-            hf = box_heightfield(rng, tile_cells, tile_cells, boxes)
+        if tile_cells_range is not None:
+            dim_x, dim_y = (int(v) for v in rng.integers(tile_cells_range[0], tile_cells_range[1] + 1, size=2))
         else:
-            hf = parkour_heightfield(kind, 1000 * seed + k, tile_cells, dx)
-        min_point = np.array([-size / 2 + dx / 2, -size / 2 + dx / 2], dtype=np.float32)   # cell centres symmetric about 0
+            dim_x = dim_y = tile_cells
+        size = min(dim_x, dim_y) * dx
+        if flat:
+            hf = np.zeros((dim_x, dim_y), np.float32)
+        elif kind == "boxes":
+            hf = box_heightfield(rng, dim_x, dim_y, boxes)
+        else:
+            assert dim_x == dim_y
+            hf = parkour_heightfield(kind, 1000 * seed + k, dim_x, dx)
+        min_point = np.array([-dim_x * dx / 2 + dx / 2, -dim_y * dx / 2 + dx / 2], dtype=np.float32)   # cell centres symmetric about 0
         heading = rng.random() * 2 * np.pi
         dur = (nf - 1) / 30.0
         speed = min(1.2, 0.35 * size / max(dur, 1e-3))
@@ -103,7 +111,7 @@ def make_dataset(num_clips=64, seed=0, tile_cells=16, dx=0.4, frames_range=(120,
         d = np.array([np.cos(heading), np.sin(heading)])
         start = -d * half
         # level a corridor under the path
-        ij = ((np.stack(np.meshgrid(np.arange(tile_cells), np.arange(tile_cells), indexing="ij"), -1)) * dx + min_point)
+        ij = ((np.stack(np.meshgrid(np.arange(dim_x), np.arange(dim_y), indexing="ij"), -1)) * dx + min_point)
         rel = ij - start
         along = rel @ d
         perp = np.abs(rel @ np.array([-d[1], d[0]]))

@@ -10,13 +10,18 @@ WORKLOADS = {
     "boxes_64clips": dict(num_clips=64, flat=False, tile_cells=16, frames_range=(120, 254)),
     # BASELINE.json configs[4] terrains: stairs / curvy paths / both / boxes from the reference's generators, 32x32 @ 0.4 m tiles
     "parkour_32clips": dict(num_clips=32, flat=False, tile_cells=32, frames_range=(120, 200), terrain_kind="parkour"),
+    # BASELINE.json configs[3] stand-in for the full iter-0 dataset (not downloadable): 1024 clips of 2-10 s at
+    # 30 fps, terrains of 16..45 cells per side @ 0.4 m -> 32 x 32 tiles of <= 47^2 cells = a <= 1504^2 heightfield (~9 MB) and ~80 MB
+    # of clip rows: the one workload whose clip database and heightfield do NOT fit in L2
+    "iter0_1024clips": dict(num_clips=1024, flat=False, tile_cells=45, tile_cells_range=(16, 45), frames_range=(61, 301)),
 }
 
 
 def build_env(name, num_envs, device, seed=0):
     spec = WORKLOADS[name]
     clips = synthetic.make_dataset(num_clips=spec["num_clips"], seed=seed, tile_cells=spec["tile_cells"], frames_range=spec["frames_range"],
-                                   flat=spec["flat"], terrain_kind=spec.get("terrain_kind", "boxes"))
+                                   flat=spec["flat"], terrain_kind=spec.get("terrain_kind", "boxes"),
+                                   tile_cells_range=spec.get("tile_cells_range"))
     tiled = synthetic.tile_square(clips)
     cfg = default_env_config()
     return IGParkourEnv(cfg, num_envs, device, False, motion_input=clips, tiled_terrain=tiled), clips, tiled
@@ -27,3 +32,42 @@ def build_agent(env, device, **overrides):
     cfg = default_agent_config()
     cfg.update(overrides)
     return DMPPOAgent(cfg, env, device)
+
+
+def build_core(name, num_envs, device, seed=0):
+    """The tracker core alone (no simulator, no agent) on a named workload, every env placed ON its reference pose at a random clip
+    time: the state the per-kernel benchmarks and profiles launch the fused post-step kernel on.  -> (core, clips, tiled)"""
+    import torch
+    from . import _hip
+    from .anim.kin_char_model import KinCharModel
+    from .anim.motion_lib import MotionLib
+    from .assets import humanoid_spec
+    from .tracker_core import TrackerConfig, TrackerCore
+    from .util import geom_util
+    from .util.terrain_util import SubTerrain
+    spec = WORKLOADS[name]
+    km = KinCharModel(device)
+    km.load_char_file(humanoid_spec.write_mjcf())
+    clips = synthetic.make_dataset(num_clips=spec["num_clips"], seed=seed, tile_cells=spec["tile_cells"], frames_range=spec["frames_range"],
+                                   flat=spec["flat"], terrain_kind=spec.get("terrain_kind", "boxes"), tile_cells_range=spec.get("tile_cells_range"))
+    M = len(clips)
+    mlib = MotionLib(clips, km, device, init_type="clips", contact_info=True)
+    tiled = synthetic.tile_square(clips)
+    hf, mn, dxdy, offs = tiled
+    rays = geom_util.get_xy_points_cone(torch.zeros(2), 0.05, 2, 60, 3, 3, 0.26179938779)
+    cfg = TrackerConfig(default_env_config()["env"], km, rays.shape[0])
+    core = TrackerCore(num_envs, device, km, mlib, cfg, rays)
+    core.set_terrain(SubTerrain.from_arrays(hf, mn, dxdy, device=device))
+    g = torch.Generator().manual_seed(seed)
+    n = num_envs
+    core.motion_ids[:] = torch.randint(0, M, (n,), generator=g).to(device)
+    core.motion_xy_offset[:] = torch.tensor(offs[:, 0]).to(device)[core.motion_ids]
+    lens = mlib._motion_lengths[core.motion_ids]
+    core.motion_time_offsets[:] = torch.rand(n, generator=g).to(device) * (lens - 1.9).clamp_min(0.0)
+    core.time_buf[:] = (torch.randint(1, 55, (n,), generator=g).float() / 30.0).to(device)
+    core.post_step(_hip.POST_REF)
+    core.root_state[:, 0:3] = core.ref_root_pos
+    core.root_state[:, 3:7] = core.ref_root_rot
+    core.dof_state.view(n, 28, 2)[..., 0] = core.ref_dof_pos
+    core.rigid_body_state.view(n, 15, 13)[..., 0:3] = core.ref_body_pos
+    return core, clips, tiled

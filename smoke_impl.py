@@ -4,10 +4,54 @@ import numpy as np
 import torch
 
 
+def oracle_compare(env, clips, tiled, obs, r, ids=None):
+    """Reference pose, observation rows and reward of the envs `ids` (all if None) recomputed by the CPU oracle from the state
+    the GPU holds, and compared.  Used by smoke() and by the workload tests (a slice of a 4096-env launch)."""
+    from oracle import oracle as orc
+    c = env._core
+    km = env._kin_char_model
+    ids = np.arange(env.get_num_envs()) if ids is None else np.asarray(ids)
+    z = lambda t: t.detach().cpu().numpy()[ids]
+    full = lambda t: t.detach().cpu().numpy()
+    par = full(km._parent_indices)
+    char = orc.Char(par, full(km._local_translation), full(km._local_rotation), [j.joint_type.value for j in km._joints],
+                    [full(j.axis) if j.axis is not None else np.zeros(3, np.float32) for j in km._joints], [j.dof_idx for j in km._joints])
+    mlib = orc.MotionLib(char, [cl["frames"] for cl in clips], [cl["fps"] for cl in clips], [cl["loop"] for cl in clips],
+                         [cl["weight"] for cl in clips], [cl["contacts"] for cl in clips])
+    n = len(ids)
+    mids = z(c.motion_ids)
+    times = z(c.time_buf + c.motion_time_offsets)
+    off = z(c.motion_xy_offset - c.env_offsets[:, 0:2])
+    ref = orc.update_ref_motion(char, mlib, mids, times, off)
+    np.testing.assert_allclose(z(c.ref_root_pos), ref["ref_root_pos"], atol=2e-5)
+    np.testing.assert_allclose(z(c.ref_body_pos), ref["ref_body_pos"], atol=5e-5)
+    rs = z(c.root_state)
+    ds = z(c.dof_state.view(env.get_num_envs(), 28, 2))
+    glob = rs[:, 0:3] + z(c.env_offsets)
+    hfs = orc.refresh_ray_obs_hfs(full(c.ray_xy_points), glob, orc.calc_heading(rs[:, 3:7]), tiled[0], tiled[1], tiled[2])
+    tar_dt = np.array(list(env._cfg.struct.tar_dt), np.float32)
+    cf = z(c.contact_forces.view(env.get_num_envs(), 15, 3))
+    o_obs = orc.compute_obs(char, mlib, tar_dt, env._cfg.key_body_ids, mids, times, off, rs[:, 0:3], rs[:, 3:7], rs[:, 7:10], rs[:, 10:13],
+                            np.ascontiguousarray(ds[..., 0]), np.ascontiguousarray(ds[..., 1]), cf, hfs)
+    g_obs = z(obs)
+    # 1e-3: the reference's slerp switches to a plain average when sin(half angle) < 1e-3 (util/torch_util.py:465); for
+    # nearly identical consecutive frames fp32 rounding decides the branch, the two branches differ by up to ~5e-4
+    np.testing.assert_allclose(g_obs[:, :871], o_obs[:, :871], atol=1e-3, rtol=1e-4)
+    assert np.mean(np.abs(g_obs[:, :871] - o_obs[:, :871]) > 1e-4) < 2e-3
+    assert np.mean(g_obs[:, 871:] != o_obs[:, 871:]) < 5e-3          # nearest-cell flips only at cell boundaries
+    st = dict(char_root_pos=rs[:, 0:3], char_root_rot=rs[:, 3:7], char_root_vel=rs[:, 7:10], char_root_ang_vel=rs[:, 10:13],
+              char_dof_pos=np.ascontiguousarray(ds[..., 0]), char_dof_vel=np.ascontiguousarray(ds[..., 1]),
+              char_rigid_body_pos=z(c.rigid_body_state.view(env.get_num_envs(), 15, 13))[..., 0:3], contact_forces=cf)
+    s = env._cfg.struct
+    o_r, _ = orc.compute_reward(char, env._cfg.key_body_ids, st, ref, list(s.joint_err_w)[:14], list(s.dof_err_w)[:28], list(s.contact_w)[:15],
+                                list(s.reward_w))
+    np.testing.assert_allclose(z(r), o_r, atol=1e-3)
+    return n
+
+
 def run():
     assert torch.cuda.is_available(), "smoke() needs the GPU"
-    from oracle import oracle as orc
-    from parc_amd import _hip, workloads
+    from parc_amd import workloads
     dev = "cuda:0"
     torch.manual_seed(0)
     env, clips, tiled = workloads.build_env("boxes_64clips", 64, dev, seed=0)
@@ -19,42 +63,8 @@ def run():
         obs, r, done, info = env.step(a)
     torch.cuda.synchronize()
     assert torch.isfinite(obs).all() and torch.isfinite(r).all()
-    # ---- oracle check of obs / reward / done on the state the simulator produced
-    c = env._core
-    km = env._kin_char_model
-    z = lambda t: t.detach().cpu().numpy()
-    par = z(km._parent_indices)
-    char = orc.Char(par, z(km._local_translation), z(km._local_rotation), [j.joint_type.value for j in km._joints],
-                    [z(j.axis) if j.axis is not None else np.zeros(3, np.float32) for j in km._joints], [j.dof_idx for j in km._joints])
-    mlib = orc.MotionLib(char, [cl["frames"] for cl in clips], [cl["fps"] for cl in clips], [cl["loop"] for cl in clips],
-                         [cl["weight"] for cl in clips], [cl["contacts"] for cl in clips])
-    n = 64
-    mids = z(c.motion_ids)
-    times = z(c.time_buf + c.motion_time_offsets)
-    off = z(c.motion_xy_offset - c.env_offsets[:, 0:2])
-    ref = orc.update_ref_motion(char, mlib, mids, times, off)
-    np.testing.assert_allclose(z(c.ref_root_pos), ref["ref_root_pos"], atol=2e-5)
-    np.testing.assert_allclose(z(c.ref_body_pos), ref["ref_body_pos"], atol=5e-5)
-    rs = z(c.root_state)
-    ds = z(c.dof_state).reshape(n, 28, 2)
-    glob = rs[:, 0:3] + z(c.env_offsets)
-    hfs = orc.refresh_ray_obs_hfs(z(c.ray_xy_points), glob, orc.calc_heading(rs[:, 3:7]), tiled[0], tiled[1], tiled[2])
-    tar_dt = np.array(list(env._cfg.struct.tar_dt), np.float32)
-    o_obs = orc.compute_obs(char, mlib, tar_dt, env._cfg.key_body_ids, mids, times, off, rs[:, 0:3], rs[:, 3:7], rs[:, 7:10], rs[:, 10:13],
-                            ds[..., 0], ds[..., 1], z(c.contact_forces).reshape(n, 15, 3), hfs)
-    g_obs = z(obs)
-    # 1e-3: the reference's slerp switches to a plain average when sin(half angle) < 1e-3 (util/torch_util.py:465); for
-    # nearly identical consecutive frames fp32 rounding decides the branch, the two branches differ by up to ~5e-4
-    np.testing.assert_allclose(g_obs[:, :871], o_obs[:, :871], atol=1e-3, rtol=1e-4)
-    assert np.mean(np.abs(g_obs[:, :871] - o_obs[:, :871]) > 1e-4) < 2e-3
-    assert np.mean(g_obs[:, 871:] != o_obs[:, 871:]) < 5e-3          # nearest-cell flips only at cell boundaries
-    st = dict(char_root_pos=rs[:, 0:3], char_root_rot=rs[:, 3:7], char_root_vel=rs[:, 7:10], char_root_ang_vel=rs[:, 10:13],
-              char_dof_pos=ds[..., 0], char_dof_vel=ds[..., 1], char_rigid_body_pos=z(c.rigid_body_state).reshape(n, 15, 13)[..., 0:3],
-              contact_forces=z(c.contact_forces).reshape(n, 15, 3))
-    s = env._cfg.struct
-    o_r, _ = orc.compute_reward(char, env._cfg.key_body_ids, st, ref, list(s.joint_err_w)[:14], list(s.dof_err_w)[:28], list(s.contact_w)[:15],
-                                list(s.reward_w))
-    np.testing.assert_allclose(z(r), o_r, atol=1e-3)
+    # ---- oracle check of obs / reward on the state the simulator produced
+    oracle_compare(env, clips, tiled, obs, r)
     # ---- one PPO iteration end to end
     agent._curr_obs, agent._curr_info = env.reset()
     agent._init_train()

@@ -505,3 +505,44 @@ def test_device_recorder_equals_per_step_host_lists(env, tmp_path):
     finally:
         env._bypass_record_fail = old_bypass
         env.set_write_agent_states_flag(False)
+
+
+@pytest.mark.parametrize("workload,num_envs", [("flat_1clip", 1024), ("iter0_1024clips", 4096)])
+def test_baseline_config_workloads_at_full_size(workload, num_envs):
+    """BASELINE.json configs[1] (1024 envs, flat terrain, one clip) and configs[3]'s single-GPU share (4096 envs on the iter-0 stand-in:
+    1024 clips, 32 x 32 tiles, a 1504^2 heightfield and ~83 MB of clip rows, i.e. nothing fits in L2) at their full env counts:
+    oracle parity on a 64-env slice of the full launch, finiteness, per-env independence of the fused post-step kernel (a subset
+    launch reproduces the rows of the full launch), and one PPO iteration end to end."""
+    import smoke_impl
+    from parc_amd import _hip, workloads
+    torch.manual_seed(0)
+    env, clips, tiled = workloads.build_env(workload, num_envs, DEV, seed=0)
+    assert env.get_num_envs() == num_envs and len(clips) == {"flat_1clip": 1, "iter0_1024clips": 1024}[workload]
+    if workload == "iter0_1024clips":
+        assert tiled[0].shape == (1504, 1504) and sum(c["frames"].shape[0] for c in clips) * 448 > 80e6
+    obs, info = env.reset()
+    lo, hi = env._action_bound_low, env._action_bound_high
+    mid, half = 0.5 * (hi + lo), 0.5 * (hi - lo)
+    for _ in range(3):
+        a = mid + 0.2 * half * torch.randn((num_envs, 28), device=DEV)
+        obs, r, done, info = env.step(a)
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(r).all() and torch.all((done >= 0) & (done <= 3))
+    assert r.mean().item() > 0.1                                         # three steps after a reset on the reference pose
+    c = env._core
+    if workload == "iter0_1024clips":
+        assert torch.unique(c.motion_ids).numel() > 900                  # the launch does touch (almost) the whole clip database
+    ids = np.linspace(0, num_envs - 1, 64).astype(np.int64)
+    assert smoke_impl.oracle_compare(env, clips, tiled, obs, r, ids) == 64
+    # per-env function: relaunching a subset rewrites exactly those rows with the same values
+    ref_obs = obs.clone()
+    sub = torch.tensor(ids[::4], dtype=torch.int64, device=DEV)
+    c.obs[sub] = -5.0
+    c.post_step(_hip.POST_OBS | _hip.POST_HF, sub)
+    assert torch.equal(c.obs, ref_obs)
+    # one PPO iteration on it
+    agent = workloads.build_agent(env, DEV, steps_per_iter=4, update_epochs=1, batch_size=2)
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    tinfo = agent._train_iter()
+    assert np.isfinite(tinfo["critic_loss"].item()) and np.isfinite(tinfo["actor_loss"].item())

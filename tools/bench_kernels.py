@@ -92,36 +92,12 @@ def main():
                       "us_single_min": us_min, "algorithmic_bytes": alg_bytes, "GBps_back_to_back": alg_bytes / us_loop / 1e3}))
 
 
-def bench_post_step(n, iters):
-    """Fused post-physics pass on the synthetic 64-clip box-terrain workload (BASELINE config 3 shape)."""
-    from parc_amd import synthetic
-    from parc_amd.anim.kin_char_model import KinCharModel
-    from parc_amd.anim.motion_lib import MotionLib
-    from parc_amd.assets import humanoid_spec
-    from parc_amd.envs.ig_parkour.default_config import default_env_config
-    from parc_amd.tracker_core import TrackerConfig, TrackerCore
-    from parc_amd.util.terrain_util import SubTerrain
-    dev = "cuda:0"
-    km = KinCharModel(dev)
-    km.load_char_file(humanoid_spec.write_mjcf())
-    clips = synthetic.make_dataset(64, seed=0)
-    mlib = MotionLib(clips, km, dev, init_type="clips", contact_info=True)
-    hf, mn, dxdy, offs = synthetic.tile_square(clips)
-    rays = geom_util.get_xy_points_cone(torch.zeros(2), 0.05, 2, 60, 3, 3, 0.26179938779)
-    cfg = TrackerConfig(default_env_config()["env"], km, rays.shape[0])
-    core = TrackerCore(n, dev, km, mlib, cfg, rays)
-    core.set_terrain(SubTerrain.from_arrays(hf, mn, dxdy, device=dev))
-    g = torch.Generator().manual_seed(0)
-    core.motion_ids[:] = torch.randint(0, 64, (n,), generator=g).to(dev)
-    core.motion_xy_offset[:] = torch.tensor(offs[:, 0]).to(dev)[core.motion_ids]
-    core.motion_time_offsets[:] = (torch.rand(n, generator=g) * 3.0).to(dev)
-    core.time_buf[:] = (torch.randint(1, 60, (n,), generator=g).float() / 30.0).to(dev)
-    # put the simulated character on its reference pose
-    core.post_step(_hip.POST_REF)
-    core.root_state[:, 0:3] = core.ref_root_pos
-    core.root_state[:, 3:7] = core.ref_root_rot
-    core.dof_state.view(n, 28, 2)[..., 0] = core.ref_dof_pos
-    core.rigid_body_state.view(n, 15, 13)[..., 0:3] = core.ref_body_pos
+def bench_post_step(n, iters, workload="boxes_64clips"):
+    """Fused post-physics pass on a named synthetic workload (default: the 64-clip box terrains of BASELINE configs[2]; --workload=
+    iter0_1024clips: the configs[3] stand-in whose clip database and heightfield do not fit in L2)."""
+    from parc_amd import workloads
+    core, clips, (hf, mn, dxdy, offs) = workloads.build_core(workload, n, "cuda:0")
+    M = len(clips)
     full = _hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS      # the product step's flags
     abl = [int(a.split("=")[1], 0) for a in sys.argv if a.startswith("--ablate=")]
     if abl:                      # PMC runs of one role ablation: every launch of the process uses it
@@ -132,7 +108,8 @@ def bench_post_step(n, iters):
         print(json.dumps({"ablation": name, "us": time_loop(lambda: core.post_step(full | bits), iters)}))
     # algorithmic bytes per env: K5 3544 + K3 7*760 + state 456 + obs cols [0,871) 3484 + bodies 780 + 8 out
     alg = n * (3544 + 7 * 760 + 456 + 3484 + 780 + 8)
-    print(json.dumps({"kernel": "track_post_kernel(fused hf)", "envs": n, "us_per_launch": us_fused, "algorithmic_bytes": alg,
+    print(json.dumps({"kernel": "track_post_kernel(fused hf)", "workload": workload, "clips": M, "hf_cells": list(hf.shape),
+                      "clip_row_bytes": int(sum(c["frames"].shape[0] for c in clips)) * 448, "envs": n, "us_per_launch": us_fused, "algorithmic_bytes": alg,
                       "GBps": alg / us_fused / 1e3, "us_without_hf": us_nohf, "mean_reward": core.reward.mean().item(),
                       "done_frac": (core.done != 0).float().mean().item()}))
 
@@ -169,7 +146,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--post" in sys.argv:
         ns = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--envs=")] or [4096]
+        wl = [a.split("=")[1] for a in sys.argv if a.startswith("--workload=")] or ["boxes_64clips"]
         for nn in ns:
-            bench_post_step(nn, 300 if nn <= 8192 else 60)
+            bench_post_step(nn, 300 if nn <= 8192 else 60, wl[0])
         sys.exit(0)
     main()
