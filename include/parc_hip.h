@@ -313,6 +313,8 @@ int parc_points_hf_sdf(void *stream, int batch, int n_points, int dim_x, int dim
  * parc_tune_hf_ablation(0..5): timing-only variants of it (outputs wrong for != 0);
  * bits 16/17/18 of `what` in parc_track_post_step drop the target / reference / character waves (timing only). */
 int parc_tune_hf_envs_per_block(int envs_per_block);
+/* 128-thread env groups per workgroup (1|2|4|8; 2 envs per group): fewer, fatter workgroups for the same number of waves */
+int parc_tune_hf_groups(int groups);
 int parc_tune_hf_ablation(int variant);
 
 int parc_abi_version(void);

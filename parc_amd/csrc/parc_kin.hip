@@ -75,13 +75,16 @@ PARC_DEV hf_env_prm hf_env_params(int e, const float *__restrict__ root, const f
     return p;
 }
 
-template <bool FROM_STATE, int HF_EPB, int ABL = 0>
-__global__ __launch_bounds__(HF_THREADS) void hf_gather_kernel(int n_envs, const float *__restrict__ ray_xy, int n_points,
-                                                               const float *__restrict__ root, const float *__restrict__ aux,
-                                                               parc_terrain_t ter, float min_h, float max_h,
-                                                               float *__restrict__ out, int64_t out_stride, int head) {
-    const int tid = threadIdx.x;
-    const int e0 = blockIdx.x * HF_EPB;
+// HF_G: groups of HF_THREADS threads per workgroup, each group working on its own HF_EPB envs (fewer, fatter workgroups for the
+// same number of waves: at 4096 envs the launch is dispatch-bound)
+template <bool FROM_STATE, int HF_EPB, int ABL = 0, int HF_G = 1>
+__global__ __launch_bounds__(HF_THREADS *HF_G) void hf_gather_kernel(int n_envs, const float *__restrict__ ray_xy, int n_points,
+                                                                      const float *__restrict__ root, const float *__restrict__ aux,
+                                                                      parc_terrain_t ter, float min_h, float max_h,
+                                                                      float *__restrict__ out, int64_t out_stride, int head) {
+    const int tid = threadIdx.x % HF_THREADS;
+    const int e0 = (blockIdx.x * HF_G + threadIdx.x / HF_THREADS) * HF_EPB;
+    if (HF_G > 1 && e0 >= n_envs) return;
     const float inv_dx = 1.0f / ter.dx, inv_dy = 1.0f / ter.dy;
     const float max_i = (float)(ter.dim_x - 1), max_j = (float)(ter.dim_y - 1);
     hf_env_prm prm[HF_EPB];
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(256) void hf_gather_scalar_kernel(int n_envs, const
 }
 
 static int g_hf_epb = 2;
+static int g_hf_groups = 1;   // 128-thread env groups per workgroup (1, 2, 4, 8): tuning knob
 static int g_hf_abl = 0;  // diagnostic ablations (timing only, outputs wrong): 1 no gather, 2 no stores
 
 static int launch_hf(bool from_state, void *stream, int n_envs, const float *ray_xy, int n_points, const float *root,
@@ -212,6 +216,18 @@ static int launch_hf(bool from_state, void *stream, int n_envs, const float *ray
     hipLaunchKernelGGL((hf_gather_kernel<FS, EPB>), dim3((n_envs + EPB - 1) / EPB), dim3(HF_THREADS), 0, st, n_envs, ray_xy, \
                        n_points, root, aux, ter, min_h, max_h, out, out_stride, head)
     const int epb = g_hf_epb;
+#define HF_LAUNCH_G(AB, G)                                                                                                              \
+    hipLaunchKernelGGL((hf_gather_kernel<true, 2, AB, G>), dim3((n_envs + 2 * G - 1) / (2 * G)), dim3(HF_THREADS * G), 0, st, n_envs, ray_xy, \
+                       n_points, root, aux, ter, min_h, max_h, out, out_stride, head)
+    if (from_state && g_hf_groups > 1) {
+        const bool empty = g_hf_abl == 5;
+        if (g_hf_groups == 2) { if (empty) HF_LAUNCH_G(5, 2); else HF_LAUNCH_G(0, 2); }
+        else if (g_hf_groups == 4) { if (empty) HF_LAUNCH_G(5, 4); else HF_LAUNCH_G(0, 4); }
+        else { if (empty) HF_LAUNCH_G(5, 8); else HF_LAUNCH_G(0, 8); }
+        PARC_CHECK_LAUNCH();
+        return PARC_OK;
+    }
+#undef HF_LAUNCH_G
     if (from_state && g_hf_abl == 1) HF_LAUNCH3(true, 2, 1);
     else if (from_state && g_hf_abl == 2) HF_LAUNCH3(true, 2, 2);
     else if (from_state && g_hf_abl == 3) HF_LAUNCH3(true, 2, 3);
@@ -234,6 +250,11 @@ static int launch_hf(bool from_state, void *stream, int n_envs, const float *ray
 }
 
 // tuning knob (envs per workgroup of the heightmap kernel: 1, 2, 4 or 8); not part of the stable ABI
+extern "C" int parc_tune_hf_groups(int g) {
+    if (g != 1 && g != 2 && g != 4 && g != 8) return PARC_EINVAL;
+    g_hf_groups = g;
+    return PARC_OK;
+}
 extern "C" int parc_tune_hf_ablation(int a) {
     g_hf_abl = a;
     return PARC_OK;
