@@ -29,6 +29,10 @@ class DeepMimicEnv:
         self._rand_root_pos_offset_scale = env_config["rand_root_pos_offset_scale"]
         self._root_pos_offset = None
         self._root_rot_offset = None
+        self._root_vel_offset = None
+        self._root_ang_vel_offset = None
+        self._dof_pos_offset = None
+        self._dof_vel_offset = None
         self._max_obs_h = env_config["max_obs_h"]
         self._min_obs_h = env_config["min_obs_h"]
         self._random_reset_pos = dm.get("random_reset_pos", False)
@@ -306,11 +310,34 @@ class DeepMimicEnv:
     def set_rand_root_pos_offset_scale(self, val):
         self._rand_root_pos_offset_scale = val
 
+    # fixed per-env offsets applied to the character state at reset (RefCharEnv.set_*_offset / apply_offsets_to_char_state,
+    # mgdm_dm_util.py:138-157,236-276; the GUI caller sets position and heading offsets, ig_parkour_env.py:414-427)
+    def _set_offset(self, name, val, width):
+        if isinstance(val, torch.Tensor):
+            assert val.shape[0] == self._num_envs and val.shape[1] == width
+        setattr(self, name, val)
+
     def set_root_pos_offset(self, val=None):
-        self._root_pos_offset = val
+        self._set_offset("_root_pos_offset", val, 3)
 
     def set_root_rot_offset(self, val=None):
-        self._root_rot_offset = val
+        self._set_offset("_root_rot_offset", val, 4)
+
+    def set_root_vel_offset(self, val=None):
+        self._set_offset("_root_vel_offset", val, 3)
+
+    def set_root_ang_vel_offset(self, val=None):
+        self._set_offset("_root_ang_vel_offset", val, 3)
+
+    def set_dof_pos_offset(self, val=None):
+        self._set_offset("_dof_pos_offset", val, self._kin_char_model.get_dof_size())
+
+    def set_dof_vel_offset(self, val=None):
+        self._set_offset("_dof_vel_offset", val, self._kin_char_model.get_dof_size())
+
+    def has_state_offsets(self):
+        return any(getattr(self, n) is not None for n in ("_root_pos_offset", "_root_rot_offset", "_root_vel_offset", "_root_ang_vel_offset",
+                                                          "_dof_pos_offset", "_dof_vel_offset"))
 
     def set_demo_mode(self, val=None):
         self._demo_mode = (not self._demo_mode) if val is None else val

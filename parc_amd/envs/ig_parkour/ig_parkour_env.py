@@ -224,7 +224,7 @@ class IGParkourEnv(base_env.BaseEnv):
         def sig(v):
             return ("tensor", v.data_ptr()) if torch.is_tensor(v) else v        # device-resident values are read by the graph itself
         return (float(self._cfg.struct.episode_length), dm._rand_reset, dm._demo_mode, sig(dm._rand_root_pos_offset_scale),
-                sig(dm._motion_start_time_fraction), sig(dm._root_pos_offset), sig(dm._root_rot_offset))
+                sig(dm._motion_start_time_fraction), dm.has_state_offsets())
 
     def set_rand_reset(self, val=None):
         val = (not self._dm_env._rand_reset) if val is None else val
@@ -264,10 +264,19 @@ class IGParkourEnv(base_env.BaseEnv):
             if dm._rand_root_pos_offset_scale != 0.0:
                 noise = torch.rand((env_ids.shape[0], 2), device=self._device, dtype=torch.float32) * 2.0 - 1.0
                 self._char_root_pos[env_ids, 0:2] += dm._rand_root_pos_offset_scale * noise
+            # RefCharEnv.apply_offsets_to_char_state (mgdm_dm_util.py:138-157): fixed offsets on top of the reference state
             if dm._root_pos_offset is not None:
                 self._char_root_pos[env_ids] += dm._root_pos_offset[env_ids]
             if dm._root_rot_offset is not None:
-                raise NotImplementedError("root rotation offsets at reset")
+                self._char_root_rot[env_ids] = torch_util.quat_mul(dm._root_rot_offset[env_ids], self._char_root_rot[env_ids])
+            if dm._root_vel_offset is not None:
+                self._char_root_vel[env_ids] += dm._root_vel_offset[env_ids]
+            if dm._root_ang_vel_offset is not None:
+                self._char_root_ang_vel[env_ids] += dm._root_ang_vel_offset[env_ids]
+            if dm._dof_pos_offset is not None:
+                self._char_dof_pos[env_ids] += dm._dof_pos_offset[env_ids]
+            if dm._dof_vel_offset is not None:
+                self._char_dof_vel[env_ids] += dm._dof_vel_offset[env_ids]
             self._next_target_xy_time[env_ids] = 0.0
             # publish body poses of the new state, then observations for these envs only
             _hip.check(_hip.lib().parc_sim_refresh_bodies(_hip.stream(), self._sim_model.device_ptr(self._device), self._num_envs,
@@ -283,7 +292,7 @@ class IGParkourEnv(base_env.BaseEnv):
     # ------------------------------------------------------------------ device-side reset of finished envs
     def supports_device_reset(self):
         dm = self._dm_env
-        return dm._root_pos_offset is None and dm._root_rot_offset is None and dm._dm_motion_offsets is not None
+        return not dm.has_state_offsets() and dm._dm_motion_offsets is not None
 
     def reset_done(self, done=None):
         """reset(nonzero(done)) without the nonzero: the same state changes as ``reset(env_ids)`` for every env whose

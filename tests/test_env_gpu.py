@@ -546,3 +546,43 @@ def test_baseline_config_workloads_at_full_size(workload, num_envs):
     agent._init_train()
     tinfo = agent._train_iter()
     assert np.isfinite(tinfo["critic_loss"].item()) and np.isfinite(tinfo["actor_loss"].item())
+
+
+def test_reset_state_offsets(env):
+    """RefCharEnv.apply_offsets_to_char_state (mgdm_dm_util.py:138-157): fixed per-env offsets on the character state at reset --
+    position, heading quaternion (quat_multiply(offset, root_rot)), velocities and dofs -- as the GUI caller sets them
+    (ig_parkour_env.py:414-427).  With offsets set, the device-side reset path steps aside."""
+    from parc_amd.util import torch_util
+    dm = env.get_dm_env()
+    N = env.get_num_envs()
+    scale = dm._rand_root_pos_offset_scale
+    dm.set_rand_root_pos_offset_scale(0.0)
+    try:
+        pos = torch.tensor([0.5, -0.25, 0.1], device=DEV).expand(N, 3).contiguous()
+        yaw = torch.linspace(-1.0, 1.0, N, device=DEV)
+        rot = torch_util.heading_to_quat(yaw)
+        dm.set_root_pos_offset(pos)
+        dm.set_root_rot_offset(rot)
+        dm.set_root_vel_offset(torch.full((N, 3), 0.2, device=DEV))
+        dm.set_dof_pos_offset(torch.full((N, 28), 0.01, device=DEV))
+        assert not env.supports_device_reset()
+        env.reset()
+        c = env._core
+        torch.testing.assert_close(env._char_root_pos, c.ref_root_pos + pos, atol=1e-6, rtol=0)
+        torch.testing.assert_close(env._char_root_rot, torch_util.quat_mul(rot, c.ref_root_rot), atol=1e-6, rtol=0)
+        torch.testing.assert_close(env._char_root_vel, c.ref_root_vel + 0.2, atol=1e-6, rtol=0)
+        torch.testing.assert_close(env._char_dof_pos, c.ref_dof_pos + 0.01, atol=1e-6, rtol=0)
+        torch.testing.assert_close(env._char_dof_vel, c.ref_dof_vel, atol=0, rtol=0)
+        # the published body poses follow the offset state (the root body is the root)
+        torch.testing.assert_close(c.rigid_body_state.view(N, 15, 13)[:, 0, 0:3], env._char_root_pos, atol=1e-6, rtol=0)
+        assert torch.isfinite(env._obs_buf).all()
+        import pytest as _pt
+        with _pt.raises(AssertionError):
+            dm.set_root_rot_offset(torch.zeros((N, 3), device=DEV))
+    finally:
+        for setter in (dm.set_root_pos_offset, dm.set_root_rot_offset, dm.set_root_vel_offset, dm.set_root_ang_vel_offset, dm.set_dof_pos_offset,
+                       dm.set_dof_vel_offset):
+            setter(None)
+        dm.set_rand_root_pos_offset_scale(scale)
+    assert env.supports_device_reset()
+    env.reset()
