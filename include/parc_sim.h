@@ -43,6 +43,8 @@ typedef struct {
     float gravity;                               /* 9.81 */
     float contact_kn, contact_cn, contact_ct, friction_mu, contact_max_pen;
     float limit_kp, limit_kd, max_angular_velocity;
+    float angular_damping;                       /* 1/s, per link (asset_options.angular_damping, envs/ig_char_env.py:141): a couple
+                                                    -c * I_com * omega on every body, i.e. d(omega)/dt = -c * omega for a free body */
 } parc_sim_model_t;
 
 /* One control step for n_envs environments: n_substeps semi-implicit Euler substeps of length h with PD

@@ -39,3 +39,27 @@ extern "C" int sim_host_refresh_bodies(const parc_sim_model_t *model, int n_envs
     }
     return 0;
 }
+
+// Penetration depth of every collision sample sphere at a given kinematic state (0 = no contact): the geometric half of the
+// contact model alone, used by the kinematic-replay test (a reference clip replayed on its own terrain must not sink into it).
+extern "C" int sim_host_penetration(const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, const float *root_state,
+                                    const float *dof_state, const float *env_offsets, float *depth_out) {
+    const int D = model->dof_size, S = model->num_spheres;
+    float zero[PARC_SIM_MAX_DOFS] = {0}, lo[PARC_SIM_MAX_DOFS], hi[PARC_SIM_MAX_DOFS];
+    for (int d = 0; d < PARC_SIM_MAX_DOFS; ++d) { lo[d] = -1.f; hi[d] = 1.f; }
+    for (int e = 0; e < n_envs; ++e) {
+        parc_sim::State x;
+        parc_sim::Scratch s;
+        parc_sim::load_state(*model, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e, zero, lo, hi, x);
+        parc_sim::V3 off = parc_sim::ld(env_offsets + 3 * (size_t)e);
+        parc_sim::pass1(*model, terrain, off, x, s, 1.0f / 120.0f);
+        for (int k = 0; k < S; ++k) {
+            const int b = model->sph_body[k];
+            parc_sim::V3 pw = s.P[b] + parc_sim::mul(s.R[b], parc_sim::ld(model->sph_pos[k]));
+            float depth;
+            parc_sim::V3 n;
+            depth_out[(size_t)e * S + k] = parc_sim::sphere_vs_columns(terrain, pw + off, model->sph_radius[k], depth, n) ? depth : 0.f;
+        }
+    }
+    return 0;
+}

@@ -66,3 +66,9 @@ class HostSim:
     def refresh_bodies(self):
         lib().sim_host_refresh_bodies(ctypes.byref(self.m), self.n, _p(self.root_state), _p(self.dof_state), _p(self.rigid_body_state),
                                       _p(self.contact_forces))
+
+    def penetration(self):
+        """[n, num_spheres] penetration depth of every collision sample sphere at the current root / dof state (0 = free)."""
+        out = np.zeros((self.n, int(self.m.num_spheres)), np.float32)
+        lib().sim_host_penetration(ctypes.byref(self.m), self.ter, self.n, _p(self.root_state), _p(self.dof_state), _p(self.env_offsets), _p(out))
+        return out

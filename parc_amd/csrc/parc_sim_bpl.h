@@ -172,6 +172,8 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
         V3 fg = mulT(k.R, v3(0.f, 0.f, -m.gravity * L.mass));
         pA.a = pA.a - cross(L.com, fg);
         pA.l = pA.l - fg;
+        // per-link angular damping: the couple -c I_com w, with I_com w = I_o w + m c x (c x w)
+        pA.a = pA.a + m.angular_damping * (mul(IA.A, k.v.a) + L.mass * cross(L.com, cross(L.com, k.v.a)));
     }
     // ---- contacts of this body's sample spheres: implicit spring-damper + regularised friction
     int n_hit = 0;                    // active contacts of this body; the first BPL_CC_SLOTS are parked in LDS for the report

@@ -368,6 +368,9 @@ PARC_HD void pass1(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_
         V3 fg = mulT(s.R[i], v3(0.f, 0.f, -m.gravity * mass));   // gravity at the centre of mass
         p.a = p.a - cross(ld(m.com[i]), fg);
         p.l = p.l - fg;
+        // per-link angular damping: the couple -c I_com w, with I_com w = I_o w + m c x (c x w)
+        V3 cm = ld(m.com[i]);
+        p.a = p.a + m.angular_damping * (mul(I.A, v.a) + mass * cross(cm, cross(cm, v.a)));
         s.IA[i] = I;
         s.pA[i] = p;
     }

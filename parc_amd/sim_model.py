@@ -31,7 +31,7 @@ class SimModelS(ctypes.Structure):
                 ("sph_body", c_i32 * MAX_SPHERES), ("sph_pos", (c_f * 3) * MAX_SPHERES), ("sph_radius", c_f * MAX_SPHERES),
                 ("gravity", c_f),
                 ("contact_kn", c_f), ("contact_cn", c_f), ("contact_ct", c_f), ("friction_mu", c_f), ("contact_max_pen", c_f),
-                ("limit_kp", c_f), ("limit_kd", c_f), ("max_angular_velocity", c_f)]
+                ("limit_kp", c_f), ("limit_kd", c_f), ("max_angular_velocity", c_f), ("angular_damping", c_f)]
 
 
 def _quat_to_mat(q):
@@ -100,7 +100,7 @@ def geom_sample_spheres(g):
 
 class SimModel:
     def __init__(self, kin_char_model, gravity=9.81, contact_kn=4.0e4, contact_cn=1.0e3, contact_ct=3.0e3, friction_mu=1.0,
-                 contact_max_pen=0.04, limit_kp=2.0e3, limit_kd=50.0, max_angular_velocity=100.0):
+                 contact_max_pen=0.04, limit_kp=2.0e3, limit_kd=50.0, max_angular_velocity=100.0, angular_damping=0.01):
         km = kin_char_model
         B, D = km.get_num_joints(), km.get_dof_size()
         assert B <= MAX_BODIES and D <= MAX_DOFS
@@ -172,6 +172,7 @@ class SimModel:
         s.contact_kn, s.contact_cn, s.contact_ct = contact_kn, contact_cn, contact_ct
         s.friction_mu, s.contact_max_pen = friction_mu, contact_max_pen
         s.limit_kp, s.limit_kd, s.max_angular_velocity = limit_kp, limit_kd, max_angular_velocity
+        s.angular_damping = angular_damping          # envs/ig_char_env.py:141-142: angular_damping 0.01, max_angular_velocity 100
         self.struct = s
         self.total_mass = float(self.body_mass.sum())
         self._device_copy = None

@@ -100,7 +100,7 @@ def test_free_fall_closed_form(model):
 
 def _momentum_drift(model, h, n_sub, steps=60):
     rng = np.random.default_rng(0)
-    sim = make(model, gravity=0.0)
+    sim = make(model, gravity=0.0, angular_damping=0.0)        # (link damping is an external couple: off for a conservation law)
     sim.root_state[0, 0:3] = [0.1, -0.3, 2.0]
     sim.root_state[0, 7:13] = rng.standard_normal(6) * 0.5
     sim.dof_state[0, :, 0] = rng.standard_normal(28) * 0.3
@@ -129,7 +129,7 @@ def test_energy_without_drives(model):
     """No gravity, no PD, no limits, no contact: kinetic energy is conserved up to the integrator's O(h) drift."""
     rng = np.random.default_rng(1)
     km, sm = model
-    sim = make(model, gravity=0.0, limit_kp=0.0, limit_kd=0.0)
+    sim = make(model, gravity=0.0, limit_kp=0.0, limit_kd=0.0, angular_damping=0.0)
     for d in range(28):
         sim.m.kp[d] = 0.0
         sim.m.kd[d] = 0.0
@@ -286,3 +286,84 @@ print("identical")
     env = dict(os.environ, PARC_SIM_HOST_LIB=os.path.join(here, "_build", "libparc_sim_host_poison.so"))
     res = subprocess.run([__import__("sys").executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert res.returncode == 0 and "identical" in res.stdout, res.stderr[-3000:]
+
+
+@pytest.mark.parametrize("clip,terrain,max_pen", [(0, "g5_hf_civ", 0.002), (1, "g5_hf_teaser", 0.03)])
+def test_kinematic_replay_of_the_shipped_clips_does_not_penetrate(model, clip, terrain, max_pen):
+    """the authors' two clips (data/terrains/civilization.pkl, TEASER_TERRAIN.pkl; frames in fixture G3, heightfields in
+    G5) replayed kinematically on their own terrains.  The collision geometry built from the MJCF (sample spheres on every geom, box
+    corners for the feet) against the column terrain must report essentially no penetration, contacts on the feet only, and none
+    at all in frames the clip labels as airborne -- evidence that geometry and contact detection agree with the data the reference
+    was built around, independent of Isaac Gym."""
+    from conftest import golden
+    from oracle.sim_host import HostSim
+    km, sm = model
+    z3, z5 = golden("g3_motion"), golden(terrain)
+    fr, con = z3["frames_%d" % clip], z3["contacts_%d" % clip]
+    F = fr.shape[0]
+    sim = HostSim(copy.deepcopy(sm.struct), F, z5["hf"], z5["min_point"], z5["dxdy"])
+    ang = np.linalg.norm(fr[:, 3:6], axis=-1, keepdims=True)
+    sim.root_state[:, 0:3] = fr[:, 0:3]
+    sim.root_state[:, 3:6] = fr[:, 3:6] * np.where(ang > 1e-8, np.sin(ang / 2) / np.maximum(ang, 1e-8), 0.5)
+    sim.root_state[:, 6] = np.cos(ang[:, 0] / 2)
+    sim.dof_state[:, :, 0] = fr[:, 6:]
+    pen = sim.penetration()
+    body = np.array(list(sm.struct.sph_body)[:sm.struct.num_spheres])
+    # measured: 0.6 mm over the 254 frames of the civilization clip; the 58-frame teaser clip (a kinematic generator's output, a drop
+    # onto a lower platform) sinks its feet by up to 2.4 cm in the 3-4 frames after each of its three landings, 0 elsewhere
+    assert pen.max() < max_pen, pen.max()
+    assert np.mean(pen.max(axis=1) > 0.01) < 0.2
+    # (a touch = more than 1 mm: the clips' feet graze the surface within fp32 noise in a few more frames)
+    touching = np.stack([(pen[:, body == b].max(axis=1) > 1e-3) if np.any(body == b) else np.zeros(F, bool) for b in range(15)], axis=1)
+    assert not (pen[:, ~np.isin(body, [11, 14])] > 0).any()
+    feet = [km.get_body_id("right_foot"), km.get_body_id("left_foot")]
+    assert not touching[:, [b for b in range(15) if b not in feet]].any()       # only the feet ever reach the ground
+    labelled = con > 0.5
+    near = labelled.copy()                                   # the clip's own contact labels, widened by two frames (they are per-frame
+    for k in (1, 2):                                         # annotations of a 30 fps clip; the geometry can touch a frame earlier / later)
+        near[k:] |= labelled[:-k]
+        near[:-k] |= labelled[k:]
+    airborne = ~near.any(axis=1)
+    assert airborne.sum() >= 0 and not touching[airborne].any()      # no contact (hence no contact force) where the clip is airborne
+    for b in feet:                                           # a geometric touch happens only where the clip says that foot is in contact
+        assert not (touching[:, b] & ~near[:, b]).any(), np.nonzero(touching[:, b] & ~near[:, b])
+    assert (pen > 0).any()
+
+
+def spin_momentum(model, sim, e=0):
+    """sum over the links of I_com,i w_i (world frame): the part of the angular momentum that link damping acts on"""
+    _, sm = model
+    S = np.zeros(3)
+    for b in range(sim.B):
+        bs = sim.rigid_body_state[e, b].astype(np.float64)
+        R = rotm(bs[3:7])
+        S += R @ sm.body_inertia_com[b] @ R.T @ bs[10:13]
+    return S
+
+
+def test_link_angular_damping_is_a_couple_on_every_link(model):
+    """asset_options.angular_damping = 0.01 (envs/ig_char_env.py:141): every link feels the couple -c I_com,i w_i (a free body then
+    obeys dw/dt = -c w).  For the whole character, held rigid by its drives and spinning freely (no gravity, no contact), the
+    total angular momentum therefore changes at the rate dL/dt = -c sum_i I_com,i w_i -- not at -c L: the orbital part of L is
+    untouched -- and not at all without damping."""
+    km, sm = model
+    c, T = 0.05, 1.0
+    res = {}
+    for damp in (0.0, c):
+        sim = make(model, gravity=0.0, angular_damping=damp)
+        sim.root_state[0, 2] = 3.0
+        sim.root_state[0, 10:13] = [0.3, -0.2, 1.5]
+        sim.refresh_bodies()
+        _, L0, _ = momentum(model, sim)
+        S0 = spin_momentum(model, sim)
+        for _ in range(int(T * 30)):
+            sim.step(np.zeros((1, 28)), n_sub=4, h=1.0 / 120.0)
+        _, L1, _ = momentum(model, sim)
+        res[damp] = (L0, L1, S0, spin_momentum(model, sim))
+    L0, L1_free, S0, S1 = res[0.0]
+    assert np.linalg.norm(L1_free - L0) / np.linalg.norm(L0) < 1e-2          # the integrator's own O(h) drift, no damping
+    dL = res[c][1] - L1_free                                                  # what the damping did
+    expect = -c * T * 0.5 * (S0 + S1)
+    assert np.linalg.norm(dL - expect) < 0.1 * np.linalg.norm(expect), (dL, expect)
+    assert np.linalg.norm(S0) < 0.5 * np.linalg.norm(L0)                      # (most of L is orbital: the decay is slower than e^{-ct})
+    assert sm.struct.angular_damping == pytest.approx(0.01) and sm.struct.max_angular_velocity == pytest.approx(100.0)
