@@ -308,6 +308,12 @@ int parc_points_hf_sdf(void *stream, int batch, int n_points, int dim_x, int dim
                        const float *min_box_center, const float *x_points, const float *y_points, float half_x, float half_y,
                        float base_z, int inverted, float radius, float *out, int32_t *out_cell);
 
+/* Backward of a Linear + ReLU layer between its two GEMMs (the derivative of learning/nets/fc_3layers_2048units.py:4-22): in one pass
+ * gy[r, c] <- gy[r, c] * (y[r, c] > 0) (in place) and db[c] <- sum_r of the result (overwritten, fixed summation order).
+ * gy, y: [rows, dim] row-major, dim % 4 == 0, 16-byte aligned; workspace: parc_relu_bwd_workspace_floats(rows, dim) floats. */
+int64_t parc_relu_bwd_workspace_floats(int64_t rows, int dim);
+int parc_relu_bwd_bias_grad(void *stream, int64_t rows, int dim, float *gy, const float *y, float *db, float *workspace);
+
 /* ---- measurement knobs (exported for tools/bench_kernels.py; not part of the stable ABI, defaults are the product path) ----
  * parc_tune_hf_envs_per_block(1|2|4|8): envs per workgroup of the standalone heightmap kernel;
  * parc_tune_hf_ablation(0..5): timing-only variants of it (outputs wrong for != 0);

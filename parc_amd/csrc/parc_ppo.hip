@@ -424,6 +424,69 @@ extern "C" int parc_moments_accumulate(void *stream, int64_t rows, int dim, cons
 }
 
 // =============================================================================================
+// Backward of y = relu(x W^T + b) between the two GEMMs: g = gy * (y > 0), written over gy, and the bias gradient db = column sums
+// of g, in ONE pass over the [rows, dim] activations (autograd runs threshold_backward, then a separate reduction that re-reads g,
+// then an accumulate into .grad).  256 columns x RB_ROWS rows per workgroup, float4 lanes, the 4 waves take rows round-robin and fold
+// their column sums through LDS; stage 2 adds the per-chunk partial rows in chunk order (fixed summation order, no atomics) and
+// OVERWRITES db.  The forward pass is learning/nets/fc_3layers_2048units.py:4-22 of the reference; this is its derivative.
+// =============================================================================================
+#define RB_ROWS 128
+__global__ __launch_bounds__(256) void relu_bwd_bias_partial_kernel(int rows, int dim4, float4 *__restrict__ gy, const float4 *__restrict__ y,
+                                                                    float4 *__restrict__ partial) {
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * RB_ROWS, r1 = min(r0 + RB_ROWS, rows);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < dim4) {
+#pragma unroll 4
+        for (int r = r0 + rg; r < r1; r += 4) {
+            const size_t i = (size_t)r * dim4 + c;
+            float4 g = gy[i];
+            const float4 a = y[i];
+            g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f; g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+            gy[i] = g;
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+        }
+    }
+    red[rg][lane] = s;
+    __syncthreads();
+    if (rg == 0 && c < dim4) {
+        const float4 a = red[0][lane], b = red[1][lane], d = red[2][lane], e = red[3][lane];
+        float4 o;
+        o.x = (a.x + b.x) + (d.x + e.x); o.y = (a.y + b.y) + (d.y + e.y); o.z = (a.z + b.z) + (d.z + e.z); o.w = (a.w + b.w) + (d.w + e.w);
+        partial[(size_t)blockIdx.y * dim4 + c] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(int chunks, int dim, const float *__restrict__ partial, float *__restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= dim) return;
+    float t = 0.f;
+#pragma unroll 16
+    for (int k = 0; k < chunks; ++k) t += partial[(size_t)k * dim + c];
+    out[c] = t;
+}
+
+extern "C" int64_t parc_relu_bwd_workspace_floats(int64_t rows, int dim) {
+    if (rows < 0 || dim <= 0) return -1;
+    return ((rows + RB_ROWS - 1) / RB_ROWS) * (int64_t)dim;
+}
+
+extern "C" int parc_relu_bwd_bias_grad(void *stream, int64_t rows, int dim, float *gy, const float *y, float *db, float *workspace) {
+    if (rows < 0 || dim <= 0 || (dim & 3) || !gy || !y || !db || !workspace || (((uintptr_t)gy | (uintptr_t)y | (uintptr_t)workspace) & 15))
+        return PARC_EINVAL;
+    if (rows > (int64_t)RB_ROWS * 65535) return PARC_EUNSUPPORTED;
+    const int dim4 = dim / 4, chunks = (int)((rows + RB_ROWS - 1) / RB_ROWS);
+    if (rows > 0)
+        hipLaunchKernelGGL(relu_bwd_bias_partial_kernel, dim3((dim4 + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, (int)rows, dim4,
+                           (float4 *)gy, (const float4 *)y, (float4 *)workspace);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, chunks, dim, workspace, db);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}
+
+// =============================================================================================
 // K14 action head of the rollout: PPOAgent._decide_action (learning/ppo_agent.py:87-119) after the actor MLP.
 // norm_a = mean + std * noise where the env explores (mask 1), the mode otherwise; a_logp = log N(norm_a; mean, std);
 // action = a_mean + a_std * norm_a (Normalizer.unnormalize).  One thread per env.

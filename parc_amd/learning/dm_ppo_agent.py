@@ -76,6 +76,7 @@ class DMPPOAgent(torch.nn.Module):
         self._curr_obs = None
         self._curr_info = None
         self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self._device)
+        self._ppo_cfg = None
         if str(self._device).startswith("cuda") and config.get("tuned_gemms", True):
             enable_tuned_gemms()
         # hipGraph rollout: the fixed-shape part of one env step (policy forward, record, simulator, post-step kernel,
@@ -164,6 +165,7 @@ class DMPPOAgent(torch.nn.Module):
         add("next_char_contact_forces", [B, 3])
         add("env_id", [], torch.int64)
         add("norm_obs", obs_dim)          # not in the reference's buffer set: update-phase cache, see _LOSS_KEYS
+        add("norm_action", a_dim)         # likewise: Normalizer.normalize(action) of ppo_agent.py:214, once per iteration instead of per minibatch
         self._env_ids = torch.arange(0, N, 1, device=dev, dtype=torch.int64)
         if self._is_terrain_runner:
             add("replan_timer", [])
@@ -484,6 +486,8 @@ class DMPPOAgent(torch.nn.Module):
         norm_adv, mean_std = rl_util.normalize_advantage(new_vals, vals, mask, self._norm_adv_clip)            # K17 (HIP)
         eb.set_data("tar_val", new_vals)
         eb.set_data("adv", norm_adv)
+        if eb.has_buffer("norm_action"):          # (the action normaliser is constant: bounds of the action space)
+            self._a_norm.normalize(eb.get_data("action"), out=eb.get_data("norm_action"))
         return {"adv_mean": mean_std[0], "adv_std": mean_std[1]}
 
     # ------------------------------------------------------------------ update (ppo_agent.py:186-330)
@@ -554,6 +558,33 @@ class DMPPOAgent(torch.nn.Module):
         self._nan_flag |= torch.isnan(out[0]).to(torch.int32)      # NaN trap, checked once per iteration
         return {"loss": loss, "_packed": out, "_slots": slots}
 
+    def _explicit_update_ok(self):
+        return (str(self._device).startswith("cuda") and self._config.get("explicit_backward", True) and self._config.get("fused_ppo_loss", True)
+                and self._model.supports_explicit_backward())
+
+    def _minibatch_step_explicit(self, batch, acc):
+        """One PPO minibatch (ppo_agent.py:195-204: loss, backward, optimizer step) without an autograd graph: forward GEMMs, the fused
+        loss kernel (value + dLoss/d outputs), DMPPOModel.train_backward writing every gradient once into the optimizer's flat buffer,
+        clip + SGD.  Same arithmetic as _compute_loss + MPOptimizer.step (tests compare the two)."""
+        norm_obs = batch["norm_obs"]
+        norm_a = batch["norm_action"] if "norm_action" in batch else self._a_norm.normalize(batch["action"])
+        mean, logstd, pred, saved = self._model.train_forward(norm_obs)
+        if self._ppo_cfg is None:
+            self._ppo_cfg = rl_util.ppo_cfg(self._ppo_clip_ratio, self._action_bound_weight, self._action_entropy_weight, self._action_reg_weight,
+                                            self._critic_loss_weight, 20.0, self._critic_loss_type != "L2")
+        out, g_mean, g_logstd, g_pred = rl_util.ppo_loss_and_grads(mean, logstd, pred, norm_a, batch["a_logp"], batch["adv"],
+                                                                    batch["rand_action_mask"], batch["tar_val"], self._ppo_cfg)
+        write = lambda grad_of, done: self._model.train_backward(saved, g_mean, g_logstd, g_pred, grad_of, done)
+        if self._clip_grad_norm:
+            self._optimizer.step_explicit(write, model=self._model, max_norm=self._max_grad_norm)
+        else:
+            self._optimizer.step_explicit(write)
+        # logged scalars: one add of the packed vector per minibatch; a NaN loss stays NaN in the sum, which _train_iter checks once
+        if "_packed" in acc:
+            acc["_packed"] += out
+        else:
+            acc["_packed"] = out.clone()
+
     def _update_model(self):
         self.train()
         N = self.get_num_envs()
@@ -561,6 +592,20 @@ class DMPPOAgent(torch.nn.Module):
         batch_size = self._batch_size * N
         num_batches = int(np.ceil(float(num_samples) / batch_size))
         acc = dict()
+        if self._explicit_update_ok():
+            slots = {"loss": 0, "critic_loss": 1, "actor_loss": 2, "clip_frac": 3, "imp_ratio": 4}
+            for name, w, i in (("action_bound_loss", self._action_bound_weight, 5), ("action_entropy", self._action_entropy_weight, 6),
+                               ("action_reg_loss", self._action_reg_weight, 7)):
+                if w != 0:
+                    slots[name] = i
+            keys = [k for k in _LOSS_KEYS if k != "action"] + (["norm_action"] if self._exp_buffer.has_buffer("norm_action") else ["action"])
+            for _ in range(self._update_epochs):
+                for _ in range(num_batches):
+                    self._minibatch_step_explicit(self._exp_buffer.sample(batch_size, keys=keys), acc)
+                self._optimizer.end_epoch()
+            packed = acc["_packed"] / (self._update_epochs * num_batches)
+            self._nan_flag |= torch.isnan(packed[0:3]).any().to(torch.int32)
+            return {k: packed[i] for k, i in slots.items()}
         for _ in range(self._update_epochs):
             for _ in range(num_batches):
                 batch = self._exp_buffer.sample(batch_size, keys=_LOSS_KEYS)

@@ -161,5 +161,81 @@ class DMPPOModel(torch.nn.Module):
     def eval_actor(self, obs):
         return self._action_dist(self._actor_layers(obs))
 
+    # ------------------------------------------------------------------ explicit training step (no autograd graph)
+    # The update phase runs the same two fixed MLPs 40 times per iteration.  Going through autograd costs, per minibatch, a
+    # threshold_backward + a separate bias reduction per layer, an accumulate-into-.grad per parameter and the zeroing of the flat
+    # gradient first.  Spelled out, every weight / bias gradient is written ONCE, straight into its slice of the optimizer's flat
+    # gradient (GEMM with out=), and the ReLU mask + bias gradient of a layer are one pass (parc_relu_bwd_bias_grad).  Same GEMMs,
+    # same values as autograd (tests/test_learner_gpu.py compares the two paths); used by DMPPOAgent when the policy's log-std is
+    # not state dependent.
+    def supports_explicit_backward(self):
+        def plain(seq):
+            mods = list(seq)
+            return len(mods) % 2 == 0 and all(isinstance(m, torch.nn.Linear) for m in mods[0::2]) and all(isinstance(m, torch.nn.ReLU) for m in mods[1::2]) \
+                and all(m.out_features % 4 == 0 for m in mods[0::2])
+        return plain(self._actor_layers) and plain(self._critic_layers) and self._action_dist._std_type != StdType.VARIABLE
+
+    @staticmethod
+    def _trunk_forward(seq, x):
+        acts = [x]
+        for lin in list(seq)[0::2]:
+            x = torch._addmm_activation(lin.bias, x, lin.weight.t(), use_gelu=False)
+            acts.append(x)
+        return acts
+
+    @torch.no_grad()
+    def train_forward(self, norm_obs):
+        """-> (mean [B, A], logstd [A], pred [B], saved activations)"""
+        a = self._trunk_forward(self._actor_layers, norm_obs)
+        c = self._trunk_forward(self._critic_layers, norm_obs)
+        mnet = self._action_dist._mean_net
+        mean = torch.addmm(mnet.bias, a[-1], mnet.weight.t())
+        pred = torch.addmm(self._critic_out.bias, c[-1], self._critic_out.weight.t()).squeeze(-1)
+        return mean, self._action_dist._logstd_net, pred, (a, c)
+
+    def _relu_bwd(self, d, y, db):
+        from .. import _hip
+        L = _hip.lib()
+        need = int(L.parc_relu_bwd_workspace_floats(d.shape[0], d.shape[1]))
+        ws = getattr(self, "_relu_ws", None)
+        if ws is None or ws.numel() < need or ws.device != d.device:
+            ws = self._relu_ws = torch.empty(max(need, 1), dtype=torch.float32, device=d.device)
+        _hip.check(L.parc_relu_bwd_bias_grad(_hip.stream(), d.shape[0], d.shape[1], _hip.ptr(d), _hip.ptr(y), _hip.ptr(db), _hip.ptr(ws)),
+                   "parc_relu_bwd_bias_grad")
+
+    def _trunk_backward(self, seq, acts, d, grad_of, done):
+        """d = dLoss/d(last activation) [B, h]; writes every layer's weight / bias gradient, last layer first."""
+        lins = list(seq)[0::2]
+        for k in range(len(lins) - 1, -1, -1):
+            lin = lins[k]
+            self._relu_bwd(d, acts[k + 1], grad_of(lin.bias))           # d <- d * (y > 0) in place, bias gradient
+            torch.mm(d.t(), acts[k], out=grad_of(lin.weight))
+            done(lin.weight)
+            done(lin.bias)
+            if k > 0:
+                d = torch.mm(d, lin.weight)
+
+    @torch.no_grad()
+    def train_backward(self, saved, g_mean, g_logstd, g_pred, grad_of, done=lambda p: None):
+        """Gradients of the loss w.r.t. every parameter, given dLoss/d(mean, logstd, pred) from the fused loss kernel.  grad_of(p) = the
+        tensor to write p's gradient into (overwritten); done(p) is called once p's gradient is complete, in the order autograd
+        would finish them (actor before critic, last layer first) -- the data-parallel optimizer starts bucket exchanges from it."""
+        a, c = saved
+        mnet = self._action_dist._mean_net
+        torch.mm(g_mean.t(), a[-1], out=grad_of(mnet.weight))
+        torch.sum(g_mean, dim=0, out=grad_of(mnet.bias))
+        done(mnet.weight)
+        done(mnet.bias)
+        if self._action_dist._std_type == StdType.CONSTANT:
+            grad_of(self._action_dist._logstd_net).copy_(g_logstd)
+            done(self._action_dist._logstd_net)
+        self._trunk_backward(self._actor_layers, a, torch.mm(g_mean, mnet.weight), grad_of, done)
+        gp = g_pred.unsqueeze(-1)
+        torch.mm(gp.t(), c[-1], out=grad_of(self._critic_out.weight))
+        torch.sum(gp, dim=0, out=grad_of(self._critic_out.bias))
+        done(self._critic_out.weight)
+        done(self._critic_out.bias)
+        self._trunk_backward(self._critic_layers, c, torch.mm(gp, self._critic_out.weight), grad_of, done)
+
     def eval_critic(self, obs):
         return self._critic_out(self._critic_layers(obs))

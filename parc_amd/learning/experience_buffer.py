@@ -17,6 +17,9 @@ class ExperienceBuffer:
         self._sample_buf_head = 0
         self._device_head = None
 
+    def has_buffer(self, name):
+        return name in self._buffers
+
     def add_buffer(self, name, buffer):
         assert len(buffer.shape) >= 2 and buffer.shape[0] == self._buffer_length and buffer.shape[1] == self._batch_size
         assert name not in self._buffers

@@ -101,9 +101,54 @@ class MPOptimizer:
             torch.distributed.all_reduce(self._flat_grad, op=torch.distributed.ReduceOp.SUM)
             self._flat_grad /= mp_util.get_num_procs()
 
+    def step_explicit(self, write_grads, **kwargs):
+        """The same step when the caller computes the gradients itself: write_grads(grad_of, done) must OVERWRITE the gradient of
+        every parameter (grad_of(p) = p's slice of the flat gradient) and call done(p) when p's gradient is complete, in the order a
+        backward pass would (the bucketed exchange is started from it exactly like from autograd's hooks).  Nothing is zeroed or
+        accumulated: a step costs the gradient kernels themselves."""
+        mp = mp_util.enable_mp() and self._cadence == "minibatch"
+        written = set()
+
+        def grad_of(p):
+            written.add(id(p))
+            return p.grad
+        if mp and self._overlap:
+            if not hasattr(self, "_bucket_of"):
+                self._bucket_of, b, seen = dict(), 0, 0
+                for p in self._param_list:
+                    self._bucket_of[id(p)] = self._buckets[b]
+                    seen += 1
+                    if seen == self._buckets[b]["n"]:
+                        b, seen = b + 1, 0
+            for bk in self._buckets:
+                bk["pending"], bk["work"] = bk["n"], None
+            self._in_backward = True
+            try:
+                write_grads(grad_of, lambda p: self._grad_ready(self._bucket_of[id(p)]))
+            finally:
+                self._in_backward = False
+            for bk in self._buckets:
+                if bk["work"] is None:
+                    torch.distributed.all_reduce(self._flat_grad[bk["lo"]:bk["hi"]], op=torch.distributed.ReduceOp.SUM)
+                else:
+                    bk["work"].wait()
+            self._flat_grad /= mp_util.get_num_procs()
+        else:
+            write_grads(grad_of, lambda p: None)
+            if mp:
+                torch.distributed.all_reduce(self._flat_grad, op=torch.distributed.ReduceOp.SUM)
+                self._flat_grad /= mp_util.get_num_procs()
+        if self._steps == 0:
+            missing = [i for i, p in enumerate(self._param_list) if id(p) not in written]
+            assert not missing, "explicit backward left parameters {} without a gradient".format(missing)
+        self._finish_step(**kwargs)
+
     def step(self, loss, **kwargs):
         self._flat_grad.zero_()
         self._backward_and_exchange(loss)
+        self._finish_step(**kwargs)
+
+    def _finish_step(self, **kwargs):
         if "model" in kwargs:
             # the gradient norm of the flat buffer == norm over model parameters (all trainable params are in it)
             max_norm = kwargs["max_norm"]

@@ -42,24 +42,36 @@ def normalize_advantage(ret, vals, rand_action_mask, clip):
     return out, ms
 
 
+def ppo_loss_and_grads(mean, logstd, pred, norm_a, old_logp, adv, mask, tar_val, cfg):
+    """parc_ppo_loss without autograd: -> (info[16] with info[0] = loss, dLoss/d mean [B, A], dLoss/d logstd [A], dLoss/d pred [B])"""
+    from .. import _hip
+    B, A = mean.shape
+    mean, norm_a = mean.contiguous(), norm_a.contiguous()
+    g_mean = torch.empty_like(mean)
+    g_logstd = torch.empty_like(logstd)
+    g_pred = torch.empty(B, dtype=torch.float32, device=mean.device)
+    out = torch.empty(16, dtype=torch.float32, device=mean.device)
+    ws = torch.empty(_hip.lib().parc_ppo_workspace_floats(B), dtype=torch.float32, device=mean.device)
+    p = _hip.ptr
+    _hip.check(_hip.lib().parc_ppo_loss(_hip.stream(), B, A, p(mean), p(logstd.contiguous()), p(norm_a), p(old_logp.contiguous()),
+                                        p(adv.contiguous()), p(mask.contiguous()), p(pred.contiguous()), p(tar_val.contiguous()), cfg,
+                                        p(g_mean), p(g_logstd), p(g_pred), p(out), p(ws)), "parc_ppo_loss")
+    return out, g_mean, g_logstd, g_pred
+
+
+def ppo_cfg(clip_ratio, bound_w, entropy_w, reg_w, critic_w, large_critic_loss=20.0, critic_l1=False):
+    from .. import _hip
+    return _hip.PPOCfgS(float(clip_ratio), float(bound_w), float(entropy_w), float(reg_w), float(critic_w), float(large_critic_loss),
+                        int(bool(critic_l1)))
+
+
 class _PPOLossFn(torch.autograd.Function):
     """loss, info = ppo_loss(mean, logstd, pred | norm_a, old_logp, adv, mask, tar_val, cfg): forward runs the three
     kernels of parc_ppo_loss, which also produce dloss/d(mean, logstd, pred); backward hands them out."""
 
     @staticmethod
     def forward(ctx, mean, logstd, pred, norm_a, old_logp, adv, mask, tar_val, cfg):
-        from .. import _hip
-        B, A = mean.shape
-        mean, norm_a = mean.contiguous(), norm_a.contiguous()
-        g_mean = torch.empty_like(mean)
-        g_logstd = torch.empty_like(logstd)
-        g_pred = torch.empty(B, dtype=torch.float32, device=mean.device)
-        out = torch.empty(16, dtype=torch.float32, device=mean.device)
-        ws = torch.empty(_hip.lib().parc_ppo_workspace_floats(B), dtype=torch.float32, device=mean.device)
-        p = _hip.ptr
-        _hip.check(_hip.lib().parc_ppo_loss(_hip.stream(), B, A, p(mean), p(logstd.contiguous()), p(norm_a), p(old_logp.contiguous()),
-                                            p(adv.contiguous()), p(mask.contiguous()), p(pred.contiguous()), p(tar_val.contiguous()), cfg,
-                                            p(g_mean), p(g_logstd), p(g_pred), p(out), p(ws)), "parc_ppo_loss")
+        out, g_mean, g_logstd, g_pred = ppo_loss_and_grads(mean, logstd, pred, norm_a, old_logp, adv, mask, tar_val, cfg)
         ctx.save_for_backward(g_mean, g_logstd, g_pred)
         ctx.mark_non_differentiable(out)
         return out[0], out
@@ -74,7 +86,5 @@ def ppo_loss(mean, logstd, pred, norm_a, old_logp, adv, mask, tar_val, clip_rati
              large_critic_loss=20.0, critic_l1=False):
     """Fused PPO loss of PPOAgent._compute_loss (learning/ppo_agent.py:186-330) on the GPU: returns (loss, info[11]) with
     info = loss, critic_loss, actor_loss, clip_frac, imp_ratio, action_bound_loss, entropy, reg_loss, cnt, ..."""
-    from .. import _hip
-    cfg = _hip.PPOCfgS(float(clip_ratio), float(bound_w), float(entropy_w), float(reg_w), float(critic_w), float(large_critic_loss),
-                       int(bool(critic_l1)))
+    cfg = ppo_cfg(clip_ratio, bound_w, entropy_w, reg_w, critic_w, large_critic_loss, critic_l1)
     return _PPOLossFn.apply(mean, logstd, pred, norm_a, old_logp, adv, mask, tar_val, cfg)

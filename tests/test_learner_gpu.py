@@ -154,3 +154,88 @@ def test_g19_recorded_clip_loads_like_in_the_reference(km):
     close(rr.cpu().numpy() * sign, z["frame_root_rot"], atol=1e-4)
     t = ml._terrains[0]
     np.testing.assert_array_equal(np.asarray(t.hf.cpu()), z["ter_hf"])
+
+
+def test_explicit_backward_equals_autograd():
+    """The update phase's explicit training step (DMPPOModel.train_forward / train_backward: every gradient written once into the flat
+    buffer, ReLU mask + bias gradient in one kernel, no autograd graph) against the autograd path it replaces, on a real minibatch:
+    same loss terms, same flat gradient; and a whole _update_model from identical weights ends at the same parameters."""
+    import copy
+    from parc_amd import workloads
+    from parc_amd.learning.dm_ppo_agent import _LOSS_KEYS
+    torch.manual_seed(0)
+    env, _, _ = workloads.build_env("boxes_64clips", 256, DEV, seed=0)
+    agent = workloads.build_agent(env, DEV, steps_per_iter=8, update_epochs=2, batch_size=2)
+    assert agent._explicit_update_ok()
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    agent._exp_buffer.reset()
+    agent.eval()
+    agent._rollout_train(8)
+    agent._build_train_data()
+    eb = agent._exp_buffer
+    idx = torch.randperm(8 * 256, device=DEV)[:512]
+    batch = {k: eb.get_data_flat(k)[idx] for k in _LOSS_KEYS + ["norm_action"]}
+    # a spread of value targets / advantages so that every term of the loss is active
+    flat = agent._optimizer._flat_grad
+    agent.train()
+    info = agent._compute_loss(batch)
+    flat.zero_()
+    info["loss"].backward()
+    g_ref = flat.clone()
+    flat.fill_(7.0)                                   # stale content must be overwritten, not accumulated into
+    acc = {}
+    sd = copy.deepcopy(agent.state_dict())
+    mean, logstd, pred, saved = agent._model.train_forward(batch["norm_obs"])
+    from parc_amd.learning import rl_util
+    cfg = rl_util.ppo_cfg(agent._ppo_clip_ratio, agent._action_bound_weight, agent._action_entropy_weight, agent._action_reg_weight,
+                          agent._critic_loss_weight, 20.0, agent._critic_loss_type != "L2")
+    out, g_mean, g_logstd, g_pred = rl_util.ppo_loss_and_grads(mean, logstd, pred, batch["norm_action"], batch["a_logp"], batch["adv"],
+                                                                batch["rand_action_mask"], batch["tar_val"], cfg)
+    agent._model.train_backward(saved, g_mean, g_logstd, g_pred, lambda p: p.grad)
+    torch.cuda.synchronize()
+    assert abs(out[0].item() - info["loss"].item()) <= 1e-6 * max(1.0, abs(info["loss"].item()))
+    scale = float(g_ref.abs().max())
+    assert scale > 0 and float((flat - g_ref).abs().max()) <= 2e-5 * scale, (float((flat - g_ref).abs().max()), scale)
+    # per parameter, relative to that parameter's own gradient size (the critic head's is much larger than the first layers')
+    for p in agent._optimizer._param_list:
+        ref = g_ref[(p.grad.data_ptr() - flat.data_ptr()) // 4:][:p.numel()].view_as(p)
+        s_ = float(ref.abs().max())
+        assert float((p.grad - ref).abs().max()) <= 5e-5 * s_ + 1e-12, (tuple(p.shape), float((p.grad - ref).abs().max()), s_)
+    # whole update phase, both paths from the same weights / optimizer state / sampling order
+    results = []
+    for explicit in (False, True):
+        agent.load_state_dict(sd)
+        agent._optimizer._optimizer.state.clear()
+        agent._config["explicit_backward"] = explicit
+        eb._reset_sample_buf()
+        torch.manual_seed(5)
+        eb._sample_buf[:] = torch.randperm(eb._sample_buf.shape[0], device=DEV)
+        eb._sample_buf_head = 0
+        tinfo = agent._update_model()
+        results.append((tinfo, torch.cat([p.detach().reshape(-1) for p in agent._optimizer._param_list]).clone()))
+    (ia, pa), (ib, pb) = results
+    for k in ("loss", "critic_loss", "actor_loss", "clip_frac", "imp_ratio"):
+        assert abs(ia[k].item() - ib[k].item()) <= 1e-5 * max(1.0, abs(ia[k].item())), k
+    step = float((pa - torch.cat([v.reshape(-1) for k, v in sd.items() if k.startswith("_model") and "logstd" not in k]).to(DEV)).abs().max())
+    assert step > 0 and float((pa - pb).abs().max()) <= 1e-3 * step + 1e-9
+    agent._config["explicit_backward"] = True
+
+
+def test_relu_bwd_bias_grad_kernel():
+    """parc_relu_bwd_bias_grad against threshold_backward + column sum, ragged row count, in-place update."""
+    from parc_amd import _hip
+    g = torch.Generator().manual_seed(2)
+    for rows, dim in ((1000, 512), (16384, 2048), (7, 28 * 4)):
+        gy = torch.randn(rows, dim, generator=g).to(DEV)
+        y = torch.relu(torch.randn(rows, dim, generator=g)).to(DEV)
+        ref = torch.ops.aten.threshold_backward(gy, y, 0.0)
+        db_ref = ref.sum(dim=0, dtype=torch.float64)
+        db = torch.full((dim,), 3.0, device=DEV)
+        L = _hip.lib()
+        ws = torch.empty(int(L.parc_relu_bwd_workspace_floats(rows, dim)), device=DEV)
+        _hip.check(L.parc_relu_bwd_bias_grad(_hip.stream(), rows, dim, _hip.ptr(gy), _hip.ptr(y), _hip.ptr(db), _hip.ptr(ws)), "relu_bwd")
+        torch.cuda.synchronize()
+        assert torch.equal(gy, ref)
+        assert float((db.double() - db_ref).abs().max()) <= 1e-5 * max(1.0, float(db_ref.abs().max())) * (rows ** 0.5)
+    assert L.parc_relu_bwd_bias_grad(_hip.stream(), 4, 6, _hip.ptr(gy), _hip.ptr(y), _hip.ptr(db), _hip.ptr(ws)) == -1       # dim % 4
