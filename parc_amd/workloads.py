@@ -17,7 +17,24 @@ WORKLOADS = {
 }
 
 
+def shipped_clip(which=0):
+    """One of the two real clips the reference ships (data/terrains/civilization.pkl = 0, TEASER_TERRAIN.pkl = 1) with its own
+    terrain, read from the committed fixtures tests/golden/g3_motion.npz + g5_hf_*.npz (the reference itself is not on the GPU box)."""
+    import os
+    import numpy as np
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    z3 = np.load(os.path.join(gold, "g3_motion.npz"))
+    z5 = np.load(os.path.join(gold, ("g5_hf_civ", "g5_hf_teaser")[which] + ".npz"))
+    return dict(frames=z3["frames_%d" % which].astype(np.float32), contacts=z3["contacts_%d" % which].astype(np.float32), fps=30.0, loop=0,
+                weight=1.0, hf=z5["hf"].astype(np.float32), min_point=z5["min_point"].astype(np.float32), dxdy=z5["dxdy"].astype(np.float32),
+                name=("civilization", "teaser")[which])
+
+
 def build_env(name, num_envs, device, seed=0):
+    if name in ("civ_clip", "teaser_clip"):          # the authors' own clip on its own terrain (learning evidence on real data)
+        clips = [shipped_clip(0 if name == "civ_clip" else 1)]
+        tiled = synthetic.tile_square(clips)
+        return IGParkourEnv(default_env_config(), num_envs, device, False, motion_input=clips, tiled_terrain=tiled), clips, tiled
     spec = WORKLOADS[name]
     clips = synthetic.make_dataset(num_clips=spec["num_clips"], seed=seed, tile_cells=spec["tile_cells"], frames_range=spec["frames_range"],
                                    flat=spec["flat"], terrain_kind=spec.get("terrain_kind", "boxes"),
