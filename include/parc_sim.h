@@ -45,6 +45,11 @@ typedef struct {
     float limit_kp, limit_kd, max_angular_velocity;
     float angular_damping;                       /* 1/s, per link (asset_options.angular_damping, envs/ig_char_env.py:141): a couple
                                                     -c * I_com * omega on every body, i.e. d(omega)/dt = -c * omega for a free body */
+    /* self-collision (Isaac Gym creates the actor with collision filter 0, envs/ig_char_env.py:105-113: links of one character
+     * collide with each other except across a joint): one capsule per body (segment cap_p0..cap_p1 in the body frame, radius
+     * cap_radius; <= 0 = none) and, per body, the set of bodies it is tested against (bit j of self_mask[b]) */
+    float cap_p0[PARC_SIM_MAX_BODIES][3], cap_p1[PARC_SIM_MAX_BODIES][3], cap_radius[PARC_SIM_MAX_BODIES];
+    uint32_t self_mask[PARC_SIM_MAX_BODIES];
 } parc_sim_model_t;
 
 /* One control step for n_envs environments: n_substeps semi-implicit Euler substeps of length h with PD

@@ -242,6 +242,7 @@ struct Scratch {
     M3 Dinv[PARC_SIM_MAX_BODIES];
     V3 u[PARC_SIM_MAX_BODIES];
     SV a[PARC_SIM_MAX_BODIES];   // spatial acceleration
+    V3 flink[PARC_SIM_MAX_BODIES];   // sum of the link-link contact forces on the body this substep, body coordinates
 };
 
 // Per-env dynamic state kept in registers/scratch across the substeps of one env step
@@ -321,6 +322,105 @@ PARC_HD bool sphere_vs_columns(const parc_terrain_t &t, V3 p, float rho, float &
     return hit;
 }
 
+PARC_HD float clampf01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+
+// ---- link-link contact (self-collision) -----------------------------------------------------------------------------------
+// Every body carries one capsule (model.cap_*).  Two capsules of bodies not joined by a joint that overlap push each other apart
+// along the line between their closest points with a spring-damper force (no friction between links).  Unlike a terrain contact
+// the force is EXPLICIT and applied to the two bodies with opposite signs: an implicit one-sided impedance (what the terrain
+// contact uses, the ground being immovable) would act on each link like added mass anchored in the world and let a character
+// change its total momentum by rubbing its limbs together.  Both bodies evaluate the pair themselves from the same closest points
+// and the same gains, so the two forces are equal and opposite and momentum is conserved exactly.  The gains are limited by the
+// pair's reduced mass so that the explicit spring-damper stays inside the stability range of the semi-implicit Euler step:
+// k <= mu / h^2, c <= 0.5 mu / h (mu from the two LINK masses, a lower bound of the effective masses of the articulated bodies).
+struct CapsuleW {   // a body's capsule and motion in the world (env) frame
+    V3 a, b;        // segment end points
+    float r;
+    V3 o, v, w;     // body origin, its linear velocity, angular velocity
+};
+
+// closest points of two segments (clamped quadratic minimisation; degenerate segments = points are handled)
+PARC_HD void seg_seg_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3 &c1, V3 &c2) {
+    const V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+    const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+    float s, t;
+    const float eps = 1e-9f;
+    if (a <= eps && e <= eps) {
+        s = t = 0.f;
+    } else if (a <= eps) {
+        s = 0.f;
+        t = clampf01(f * p_rcp(e));
+    } else {
+        const float c = dot(d1, r);
+        if (e <= eps) {
+            t = 0.f;
+            s = clampf01(-c * p_rcp(a));
+        } else {
+            const float b = dot(d1, d2), den = a * e - b * b;
+            s = den > eps ? clampf01((b * f - c * e) * p_rcp(den)) : 0.f;
+            t = (b * s + f) * p_rcp(e);
+            if (t < 0.f) {
+                t = 0.f;
+                s = clampf01(-c * p_rcp(a));
+            } else if (t > 1.f) {
+                t = 1.f;
+                s = clampf01((b - c) * p_rcp(a));
+            }
+        }
+    }
+    c1 = p1 + s * d1;
+    c2 = p2 + t * d2;
+}
+
+struct LinkHit {
+    V3 rc, F;          // contact point and force on this body, in the body's coordinates
+};
+
+// Contact of body A's capsule with body B's, as felt by A (R = A's rotation, mass_a / mass_b the two link masses).  Returns false
+// when they do not touch or separate faster than the spring pushes.
+PARC_HD bool link_contact(const parc_sim_model_t &m, const CapsuleW &A, const M3 &R, float mass_a, const CapsuleW &B, float mass_b, float h,
+                          LinkHit &hit) {
+    V3 ca, cb;
+    seg_seg_closest(A.a, A.b, B.a, B.b, ca, cb);
+    V3 d = ca - cb;
+    const float dist2 = dot(d, d), reach = A.r + B.r;
+    if (dist2 >= reach * reach) return false;
+    const float dist = p_sqrt(dist2);
+    // coincident axes: push along the line between the body origins (a direction both bodies agree on, mirrored)
+    V3 n = dist > 1e-6f ? p_rcp(dist) * d : v3(0.f, 0.f, 0.f);
+    if (!(dist > 1e-6f)) {
+        V3 oo = A.o - B.o;
+        float l = p_sqrt(dot(oo, oo));
+        n = l > 1e-6f ? p_rcp(l) * oo : v3(0.f, 0.f, 1.f);
+    }
+    const float pen = reach - dist;
+    const V3 pa = ca - A.r * n, pb = cb + B.r * n;            // surface points
+    const V3 va = A.v + cross(A.w, pa - A.o), vb = B.v + cross(B.w, pb - B.o);
+    const float vn = dot(va - vb, n);
+    const float mu = mass_a * mass_b * p_rcp(mass_a + mass_b);
+    const float ih = p_rcp(h);
+    const float kcap = mu * ih * ih, ccap = 0.5f * mu * ih;
+    const float kn = m.contact_kn < kcap ? m.contact_kn : kcap;
+    const float cn = vn < 0.f ? (m.contact_cn < ccap ? m.contact_cn : ccap) : 0.f;
+    const float d_eff = pen < m.contact_max_pen ? pen : m.contact_max_pen;
+    const float fn = kn * d_eff - cn * vn;
+    if (fn <= 0.f) return false;
+    hit.rc = mulT(R, pa - A.o);
+    hit.F = fn * mulT(R, n);
+    return true;
+}
+
+PARC_HD CapsuleW capsule_world(const parc_sim_model_t &m, int b, const M3 &R, V3 P, SV v_body) {
+    CapsuleW c;
+    c.a = P + mul(R, ld(m.cap_p0[b]));
+    c.b = P + mul(R, ld(m.cap_p1[b]));
+    c.r = m.cap_radius[b];
+    c.o = P;
+    c.v = mul(R, v_body.l);
+    c.w = mul(R, v_body.a);
+    return c;
+}
+
 // Forward kinematics + velocities + bias terms (ABA pass 1) and per-body contact impedance.
 // After this call s.IA / s.pA hold the rigid-body inertia + contact augmentation and the bias force minus
 // external forces; contact bookkeeping needed to report forces afterwards is recomputed in report_contacts().
@@ -373,6 +473,20 @@ PARC_HD void pass1(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_
         p.a = p.a + m.angular_damping * (mul(I.A, v.a) + mass * cross(cm, cross(cm, v.a)));
         s.IA[i] = I;
         s.pA[i] = p;
+    }
+    // link-link contacts: explicit, equal and opposite (see link_contact)
+    for (int i = 0; i < B; ++i) {
+        s.flink[i] = v3(0.f, 0.f, 0.f);
+        if (!(m.cap_radius[i] > 0.f) || m.self_mask[i] == 0u) continue;
+        const CapsuleW ci = capsule_world(m, i, s.R[i], s.P[i], s.v[i]);
+        for (int j = 0; j < B; ++j) {
+            if (!((m.self_mask[i] >> j) & 1u) || !(m.cap_radius[j] > 0.f)) continue;
+            LinkHit hit;
+            if (!link_contact(m, ci, s.R[i], m.mass[i], capsule_world(m, j, s.R[j], s.P[j], s.v[j]), m.mass[j], h, hit)) continue;
+            s.pA[i].a = s.pA[i].a - cross(hit.rc, hit.F);
+            s.pA[i].l = s.pA[i].l - hit.F;
+            s.flink[i] = s.flink[i] + hit.F;
+        }
     }
     // contacts: implicit spring-damper + regularised friction per penetrating sample sphere
     PARC_LOOP(2)
@@ -445,6 +559,8 @@ PARC_HD void report_contacts(const parc_sim_model_t &m, const parc_terrain_t &te
         if (fnn < 0.f) F = F - fnn * nb;   // no adhesion in what is reported
         x.cforce[b] = x.cforce[b] + weight * mul(s.R[b], F);
     }
+    // link-link contacts count in the net contact force of a body like any other contact (Isaac Gym's net_contact_force tensor)
+    for (int i = 0; i < m.num_bodies; ++i) x.cforce[i] = x.cforce[i] + weight * mul(s.R[i], s.flink[i]);
 }
 
 PARC_HD float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }

@@ -31,7 +31,9 @@ class SimModelS(ctypes.Structure):
                 ("sph_body", c_i32 * MAX_SPHERES), ("sph_pos", (c_f * 3) * MAX_SPHERES), ("sph_radius", c_f * MAX_SPHERES),
                 ("gravity", c_f),
                 ("contact_kn", c_f), ("contact_cn", c_f), ("contact_ct", c_f), ("friction_mu", c_f), ("contact_max_pen", c_f),
-                ("limit_kp", c_f), ("limit_kd", c_f), ("max_angular_velocity", c_f), ("angular_damping", c_f)]
+                ("limit_kp", c_f), ("limit_kd", c_f), ("max_angular_velocity", c_f), ("angular_damping", c_f),
+                ("cap_p0", (c_f * 3) * MAX_BODIES), ("cap_p1", (c_f * 3) * MAX_BODIES), ("cap_radius", c_f * MAX_BODIES),
+                ("self_mask", ctypes.c_uint32 * MAX_BODIES)]
 
 
 def _quat_to_mat(q):
@@ -98,9 +100,41 @@ def geom_sample_spheres(g):
     raise NotImplementedError(g._shape_type)
 
 
+def body_capsule(geoms):
+    """One collision capsule per body for link-link contact: (p0[3], p1[3], radius) in the body frame.  A single capsule / sphere geom
+    is taken as it is; a box becomes the capsule along its longest axis; a body made of several geoms (pelvis: two spheres, torso:
+    chest sphere + clavicles) gets the segment from its largest sphere to the centroid of the other geoms, with that sphere's radius."""
+    def ends(g):
+        if g._shape_type == GeomType.SPHERE:
+            return g._offset.copy(), g._offset.copy(), float(np.atleast_1d(g._dims)[0])
+        if g._shape_type == GeomType.CAPSULE:
+            return g._offset.copy(), g._offset + g._dims, float(g._radius)
+        if g._shape_type == GeomType.BOX:
+            R = _quat_to_mat(g._quat) if g._quat is not None else np.eye(3)
+            half = np.asarray(g._dims, np.float64)
+            k = int(np.argmax(half))
+            r = float(np.sort(half)[1])                   # the middle half extent: covers the box's width, overshoots its height a little
+            d = R[:, k] * max(half[k] - r, 0.0)
+            return g._offset - d, g._offset + d, r
+        raise NotImplementedError(g._shape_type)
+    if len(geoms) == 0:
+        return np.zeros(3), np.zeros(3), 0.0
+    if len(geoms) == 1:
+        return ends(geoms[0])
+    spheres = [g for g in geoms if g._shape_type == GeomType.SPHERE]
+    if spheres:
+        big = max(spheres, key=lambda g: float(np.atleast_1d(g._dims)[0]))
+        rest = [g for g in geoms if g is not big]
+        cen = np.mean([0.5 * (ends(g)[0] + ends(g)[1]) for g in rest], axis=0)
+        return big._offset.copy(), cen, float(np.atleast_1d(big._dims)[0])
+    pts = [e for g in geoms for e in ends(g)[:2]]
+    i, j = max(((i, j) for i in range(len(pts)) for j in range(i + 1, len(pts))), key=lambda ij: np.linalg.norm(pts[ij[0]] - pts[ij[1]]))
+    return pts[i], pts[j], max(ends(g)[2] for g in geoms)
+
+
 class SimModel:
     def __init__(self, kin_char_model, gravity=9.81, contact_kn=4.0e4, contact_cn=1.0e3, contact_ct=3.0e3, friction_mu=1.0,
-                 contact_max_pen=0.04, limit_kp=2.0e3, limit_kd=50.0, max_angular_velocity=100.0, angular_damping=0.01):
+                 contact_max_pen=0.04, limit_kp=2.0e3, limit_kd=50.0, max_angular_velocity=100.0, angular_damping=0.01, self_collision=True):
         km = kin_char_model
         B, D = km.get_num_joints(), km.get_dof_size()
         assert B <= MAX_BODIES and D <= MAX_DOFS
@@ -161,6 +195,19 @@ class SimModel:
             for g in km.get_geoms(b):
                 for c, r in geom_sample_spheres(g):
                     spheres.append((b, c, r))
+        # link-link contact: every pair of bodies that is not joined by a joint (collision filter 0, envs/ig_char_env.py:105-113)
+        self.capsules = []
+        for b in range(B):
+            p0, p1, r = body_capsule(km.get_geoms(b))
+            self.capsules.append((p0, p1, r))
+            for k in range(3):
+                s.cap_p0[b][k], s.cap_p1[b][k] = float(p0[k]), float(p1[k])
+            s.cap_radius[b] = float(r)
+            mask = 0
+            for j in range(B):
+                if self_collision and j != b and int(par[b]) != j and int(par[j]) != b:
+                    mask |= 1 << j
+            s.self_mask[b] = mask
         assert len(spheres) <= MAX_SPHERES, len(spheres)
         s.num_spheres = len(spheres)
         for k, (b, c, r) in enumerate(spheres):

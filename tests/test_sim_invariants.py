@@ -36,6 +36,9 @@ def make(model, n=1, hf=None, **over):
     from oracle.sim_host import HostSim
     km, sm = model
     s = copy.deepcopy(sm.struct)
+    if over.pop("self_collision", True) is False:
+        for b in range(16):
+            s.self_mask[b] = 0
     for k, v in over.items():
         setattr(s, k, v)
     if hf is None:
@@ -129,7 +132,8 @@ def test_energy_without_drives(model):
     """No gravity, no PD, no limits, no contact: kinetic energy is conserved up to the integrator's O(h) drift."""
     rng = np.random.default_rng(1)
     km, sm = model
-    sim = make(model, gravity=0.0, limit_kp=0.0, limit_kd=0.0, angular_damping=0.0)
+    # (no link-link contact either: without drives and limits the limbs swing through each other, and contact damping dissipates)
+    sim = make(model, gravity=0.0, limit_kp=0.0, limit_kd=0.0, angular_damping=0.0, self_collision=False)
     for d in range(28):
         sim.m.kp[d] = 0.0
         sim.m.kd[d] = 0.0
@@ -367,3 +371,112 @@ def test_link_angular_damping_is_a_couple_on_every_link(model):
     assert np.linalg.norm(dL - expect) < 0.1 * np.linalg.norm(expect), (dL, expect)
     assert np.linalg.norm(S0) < 0.5 * np.linalg.norm(L0)                      # (most of L is orbital: the decay is slower than e^{-ct})
     assert sm.struct.angular_damping == pytest.approx(0.01) and sm.struct.max_angular_velocity == pytest.approx(100.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# link-link contact (self-collision): Isaac Gym creates the character with collision filter 0 (envs/ig_char_env.py:105-113),
+# so links that are not joined by a joint collide
+# ---------------------------------------------------------------------------------------------------------------
+def capsule_gap(model, sim, bi, bj, e=0):
+    """distance between the capsule surfaces of two bodies (negative = overlapping)"""
+    _, sm = model
+
+    def world(b):
+        bs = sim.rigid_body_state[e, b].astype(np.float64)
+        R = rotm(bs[3:7])
+        p0, p1, r = sm.capsules[b]
+        return bs[0:3] + R @ p0, bs[0:3] + R @ p1, r
+    a0, a1, ra = world(bi)
+    b0, b1, rb = world(bj)
+    ts = np.linspace(0, 1, 41)
+    pa = a0[None] + ts[:, None] * (a1 - a0)[None]
+    pb = b0[None] + ts[:, None] * (b1 - b0)[None]
+    return np.linalg.norm(pa[:, None] - pb[None], axis=-1).min() - ra - rb
+
+
+def test_self_collision_set_and_rest_poses(model):
+    """Every pair of bodies not joined by a joint is in the collision set (91 pairs for the 15-body humanoid), symmetric; the zero
+    pose and the authors' two clips are free of link-link contact (no contact force when replayed away from any terrain)."""
+    from conftest import golden
+    from oracle.sim_host import HostSim
+    km, sm = model
+    par = [int(p) for p in km._parent_indices]
+    pairs = 0
+    for b in range(15):
+        for j in range(15):
+            on = bool((sm.struct.self_mask[b] >> j) & 1)
+            assert on == bool((sm.struct.self_mask[j] >> b) & 1)
+            assert on == (j != b and par[b] != j and par[j] != b)
+            pairs += on
+    assert pairs == 2 * 91 and all(r > 0 for _, _, r in sm.capsules)
+    z3 = golden("g3_motion")
+    for clip in (0, 1):
+        fr = z3["frames_%d" % clip]
+        F = fr.shape[0]
+        sim = HostSim(copy.deepcopy(sm.struct), F, np.full((20, 20), -100.0, np.float32), [-4.0, -4.0], [0.4, 0.4])
+        ang = np.linalg.norm(fr[:, 3:6], axis=-1, keepdims=True)
+        sim.root_state[:, 0:3] = fr[:, 0:3]
+        sim.root_state[:, 3:6] = fr[:, 3:6] * np.where(ang > 1e-8, np.sin(ang / 2) / np.maximum(ang, 1e-8), 0.5)
+        sim.root_state[:, 6] = np.cos(ang[:, 0] / 2)
+        sim.dof_state[:, :, 0] = fr[:, 6:]
+        sim.step(fr[:, 6:].copy(), n_sub=1, h=1.0 / 120.0)
+        assert np.abs(sim.contact_forces).max() == 0.0
+    sim = make(model)
+    sim.root_state[0, 2] = 5.0
+    sim.step(np.zeros((1, 28)), n_sub=4, h=1.0 / 120.0)
+    assert np.abs(sim.contact_forces).max() == 0.0
+
+
+def test_self_collision_keeps_crossing_legs_apart(model):
+    """Both hips are driven into adduction so that the legs cross.  Without link-link contact the thigh capsules end up 11 cm inside
+    each other; with it they are held at the surface (about a centimetre of spring compression against the drives), both bodies report the
+    contact force, and the two forces are equal and opposite."""
+    km, sm = model
+    rt, lt, rs, ls = [km.get_body_id(n) for n in ("right_thigh", "left_thigh", "right_shin", "left_shin")]
+    res = {}
+    for on in (True, False):
+        sim = make(model, gravity=0.0, self_collision=on)
+        sim.root_state[0, 2] = 3.0
+        act = np.zeros((1, 28), np.float32)
+        act[0, 14] = 0.9                     # right hip, rotation about x
+        act[0, 21] = -0.9                    # left hip, mirrored
+        gaps, forces = [], []
+        for _ in range(45):
+            sim.step(act, n_sub=4, h=1.0 / 120.0)
+            gaps.append(min(capsule_gap(model, sim, i, j) for i, j in ((rt, lt), (rs, ls), (rt, ls), (rs, lt))))
+            forces.append(sim.contact_forces[0].copy())
+        res[on] = (np.array(gaps), np.array(forces))
+    gap_on, f_on = res[True]
+    gap_off, f_off = res[False]
+    assert gap_off.min() < -0.08                      # without contact: the legs pass through each other
+    assert gap_on.min() > -0.03 and gap_on[-1] > -0.015       # with contact: a brief overshoot at impact, then held near the surface
+    # (the pair's explicit spring is limited by the links' reduced mass, here 34 kN/m: ~1 cm under the ~300 N of the two hip drives)
+    assert np.abs(f_off).max() == 0.0
+    legs = [rt, lt, rs, ls, km.get_body_id("right_foot"), km.get_body_id("left_foot")]
+    assert np.linalg.norm(f_on[:, legs], axis=-1).max() > 50.0
+    # action = reaction: the contact forces of the whole character sum to zero in every frame (there is no terrain in this scene)
+    tot = f_on.sum(axis=1)
+    assert np.abs(tot).max() < 2e-3 * max(np.abs(f_on).max(), 1.0)
+
+
+def test_momentum_is_conserved_through_link_contacts(model):
+    """Link-link contact forces are internal: with the arms driven into the body in zero gravity, linear and angular momentum keep
+    their values to the integrator's O(h) accuracy, exactly as without contacts."""
+    km, sm = model
+    sim = make(model, gravity=0.0, angular_damping=0.0)
+    rng = np.random.default_rng(2)
+    sim.root_state[0, 0:3] = [0.0, 0.0, 3.0]
+    sim.root_state[0, 7:13] = rng.standard_normal(6) * 0.3
+    sim.refresh_bodies()
+    P0, L0, _ = momentum(model, sim)
+    act = np.zeros((1, 28), np.float32)
+    act[0, 14] = 0.9                         # the legs are driven across each other
+    act[0, 21] = -0.9
+    touched = False
+    for _ in range(60):
+        sim.step(act, n_sub=4, h=1.0 / 120.0)
+        touched |= bool(np.abs(sim.contact_forces).max() > 1.0)
+    P1, L1, _ = momentum(model, sim)
+    assert touched
+    assert np.abs(P1 - P0).max() < 0.02 * max(np.linalg.norm(P0), 1.0)
+    assert np.abs(L1 - L0).max() < 0.05 * max(np.linalg.norm(L0), 1.0)
