@@ -177,7 +177,7 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
     }
     int n_hit = 0;                    // active contacts of this body; the first BPL_CC_SLOTS are parked in LDS for the report
     unsigned long long overflow = 0ull;
-    // ---- link-link contacts: every lane publishes its body's capsule and motion in the env frame (17 floats in the LDS exchange
+    // ---- link-link contacts: every lane publishes its body's capsule and motion in the env frame (21 floats in the LDS exchange
     // buffer, free until the inward sweep), then tests it against the bodies of its self-collision set: the same pair is evaluated
     // by both lanes from the same closest points and gains, so the explicit forces are equal and opposite (link_contact)
     V3 flink = v3(0.f, 0.f, 0.f);
@@ -187,14 +187,21 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
         o[0] = mine.a.x; o[1] = mine.a.y; o[2] = mine.a.z; o[3] = mine.b.x; o[4] = mine.b.y; o[5] = mine.b.z; o[6] = valid ? mine.r : 0.f;
         o[7] = mine.o.x; o[8] = mine.o.y; o[9] = mine.o.z; o[10] = mine.v.x; o[11] = mine.v.y; o[12] = mine.v.z;
         o[13] = mine.w.x; o[14] = mine.w.y; o[15] = mine.w.z; o[16] = L.mass;
+        o[17] = mine.c.x; o[18] = mine.c.y; o[19] = mine.c.z; o[20] = mine.ext;
         __syncthreads();
         for (unsigned mm = (valid && mine.r > 0.f) ? m.self_mask[b] : 0u; mm; mm &= mm - 1) {
             const float *q = lds + (__ffs((int)mm) - 1) * BPL_CONTRIB;
             CapsuleW other;
+            other.c = v3(q[17], q[18], q[19]); other.ext = q[20];
+            {
+                const V3 cc = mine.c - other.c;
+                const float far = mine.ext + other.ext;
+                if (!(q[6] > 0.f) || dot(cc, cc) >= far * far) continue;         // reject before touching the other 16 floats
+            }
             other.a = v3(q[0], q[1], q[2]); other.b = v3(q[3], q[4], q[5]); other.r = q[6];
             other.o = v3(q[7], q[8], q[9]); other.v = v3(q[10], q[11], q[12]); other.w = v3(q[13], q[14], q[15]);
             LinkHit hit;
-            if (!(other.r > 0.f) || !link_contact(m, mine, k.R, L.mass, other, q[16], h, hit)) continue;
+            if (!link_contact(m, mine, k.R, L.mass, other, q[16], h, hit)) continue;
             pA.a = pA.a - cross(hit.rc, hit.F);
             pA.l = pA.l - hit.F;
             flink = flink + hit.F;

@@ -337,6 +337,8 @@ struct CapsuleW {   // a body's capsule and motion in the world (env) frame
     V3 a, b;        // segment end points
     float r;
     V3 o, v, w;     // body origin, its linear velocity, angular velocity
+    V3 c;           // segment mid point
+    float ext;      // half length + radius: the capsule lies inside the sphere (c, ext) - cheap rejection of distant pairs
 };
 
 // closest points of two segments (clamped quadratic minimisation; degenerate segments = points are handled)
@@ -380,6 +382,11 @@ struct LinkHit {
 // when they do not touch or separate faster than the spring pushes.
 PARC_HD bool link_contact(const parc_sim_model_t &m, const CapsuleW &A, const M3 &R, float mass_a, const CapsuleW &B, float mass_b, float h,
                           LinkHit &hit) {
+    {
+        const V3 cc = A.c - B.c;
+        const float far = A.ext + B.ext;
+        if (dot(cc, cc) >= far * far) return false;        // bounding spheres apart (most pairs, most of the time)
+    }
     V3 ca, cb;
     seg_seg_closest(A.a, A.b, B.a, B.b, ca, cb);
     V3 d = ca - cb;
@@ -418,6 +425,9 @@ PARC_HD CapsuleW capsule_world(const parc_sim_model_t &m, int b, const M3 &R, V3
     c.o = P;
     c.v = mul(R, v_body.l);
     c.w = mul(R, v_body.a);
+    c.c = 0.5f * (c.a + c.b);
+    const V3 ax = c.b - c.a;
+    c.ext = 0.5f * p_sqrt(dot(ax, ax)) + c.r;
     return c;
 }
 
