@@ -507,6 +507,45 @@ def test_device_recorder_equals_per_step_host_lists(env, tmp_path):
         env.set_write_agent_states_flag(False)
 
 
+def test_config4_parkour_8192_envs_with_record_rollout(tmp_path):
+    """BASELINE.json configs[4] at its per-GPU size: 8192 envs on the parkour terrains (stairs / curvy paths / boxes from the reference's
+    generators), training rollout with oracle parity on a slice, then the parc_4_phys_record loop (deterministic policy, device
+    recorder on all 8192 envs, finished clips written in the reference's motion format)."""
+    import smoke_impl
+    from parc_amd import workloads
+    from parc_amd.util import safe_pickle
+    torch.manual_seed(0)
+    n = 8192
+    env, clips, tiled = workloads.build_env("parkour_32clips", n, DEV, seed=0)
+    agent = workloads.build_agent(env, DEV, steps_per_iter=4, update_epochs=1, batch_size=2)
+    obs, info = env.reset()
+    for _ in range(3):
+        a, _ = agent._decide_action(obs, info)
+        obs, r, done, info = env.step(a)
+    torch.cuda.synchronize()
+    assert obs.shape == (n, 1312) and torch.isfinite(obs).all() and torch.isfinite(r).all()
+    ids = np.linspace(0, n - 1, 64).astype(np.int64)
+    assert smoke_impl.oracle_compare(env, clips, tiled, obs, r, ids) == 64
+    hfcols = obs[:, 871:]
+    assert float(hfcols.min()) >= -3.0 and float(hfcols.max()) <= 3.0 and float(hfcols.std()) > 0.05
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    tinfo = agent._train_iter()
+    assert np.isfinite(tinfo["critic_loss"].item())
+    # record mode on all 8192 envs (256 envs per clip in demo mode); an untrained policy falls early: bypass the tracked-to-the-end
+    # filter so that the writer runs, and stop after 25 steps
+    env._output_motion_dir = str(tmp_path / "recorded")
+    env._bypass_record_fail = True
+    ok = agent.record_motions(max_steps=25)
+    assert len(ok) == n
+    files = sorted((tmp_path / "recorded").glob("*.pkl"))
+    assert len(files) >= 1
+    d = safe_pickle.load_motion_file_safe(str(files[0]))
+    T = d["frames"].shape[0]
+    assert d["frames"].shape == (T, 34) and d["contacts"].shape == (T, 15) and d["obs"].shape == (T, 1312) and d["fps"] == 30
+    assert d["terrain"]["__class__"] == "util.terrain_util.SubTerrain"
+
+
 @pytest.mark.parametrize("workload,num_envs", [("flat_1clip", 1024), ("iter0_1024clips", 4096)])
 def test_baseline_config_workloads_at_full_size(workload, num_envs):
     """BASELINE.json configs[1] (1024 envs, flat terrain, one clip) and configs[3]'s single-GPU share (4096 envs on the iter-0 stand-in:
