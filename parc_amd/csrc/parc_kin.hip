@@ -912,18 +912,21 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             }
         }
     }
-        // Everything of the reward / termination that does not need another wave's results runs BEFORE the reference wave's arrival at
-        // B1 (it has slack there: the target waves arrive later), so that what is left after the barrier - the only part the workgroup
-        // still waits for once the other waves have copied the rows out - is the pose term (it reads the character wave's joint
-        // rotations from LDS), the 16-lane reductions and the final scalars.
-        float pose_e = 0.f, vel_e = 0.f, key_e = 0.f, cpen = 0.f;
-        int pose_fail = 0, fall_contact = 0, fall_height = 0;
-        v3 sim_root = mk3(0.f, 0.f, 0.f);
-        if (what & PARC_POST_REWARD_DONE) {
+      if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) __syncthreads();   // B1 (reference wave's arrival)
+        if (what & (PARC_POST_REF | PARC_POST_REWARD_DONE)) {
+            if (what & PARC_POST_REWARD_DONE) {
                 // compute_deepmimic_reward  mgdm_dm_util.py:327-390 (track_root, track_root_h)
+                float pose_e = 0.f, vel_e = 0.f, key_e = 0.f, cpen = 0.f;
+                int pose_fail = 0, fall_contact = 0, fall_height = 0;
                 const v3 sim_pos = ld3(rbuf.rigid_body_state + ((size_t)e * B + (valid ? b : 0)) * 13);
-                sim_root = shfl16(sim_pos, 0);          // body 0 is the root
+                const v3 sim_root = shfl16(sim_pos, 0);          // body 0 is the root
                 const v3 sim_f = ld3(rbuf.contact_forces + ((size_t)e * B + (valid ? b : 0)) * 3);
+                if (valid && b > 0) {
+                    const float4 cq = *reinterpret_cast<const float4 *>(cjq[le][b]);    // from the character wave (before B1)
+                    q4 cj = mk4(cq.x, cq.y, cq.z, cq.w);
+                    float da = quat_diff_angle(cj, rq);
+                    pose_e = rcfg.joint_err_w[b - 1] * da * da;
+                }
                 #pragma unroll 1
                 for (int d = b; d < D; d += GRP) {
                     float dv = fq.row0[ml.off_dof_vel + d] - dofs[2 * d + 1];
@@ -951,16 +954,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                         float th = hf_lookup(ter, sim_pos.x + rbuf.env_offsets[3 * e], sim_pos.y + rbuf.env_offsets[3 * e + 1]) + rcfg.termination_height;
                         fall_height = sim_pos.z < th;
                     }
-                }
-        }
-      if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) __syncthreads();   // B1 (reference wave's arrival)
-        if (what & (PARC_POST_REF | PARC_POST_REWARD_DONE)) {
-            if (what & PARC_POST_REWARD_DONE) {
-                if (valid && b > 0) {
-                    const float4 cq = *reinterpret_cast<const float4 *>(cjq[le][b]);    // from the character wave (before B1)
-                    q4 cj = mk4(cq.x, cq.y, cq.z, cq.w);
-                    float da = quat_diff_angle(cj, rq);
-                    pose_e = rcfg.joint_err_w[b - 1] * da * da;
                 }
                 pose_e = sum16(pose_e);
                 vel_e = sum16(vel_e);
