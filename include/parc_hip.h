@@ -254,6 +254,11 @@ int parc_ppo_loss(void *stream, int B, int A, const float *mean, const float *lo
                   const float *adv, const float *mask, const float *pred, const float *tar_val, parc_ppo_cfg_t cfg, float *g_mean,
                   float *g_logstd, float *g_pred, float *out, float *workspace);
 int parc_ppo_workspace_floats(int B);
+/* The same loss on packed per-sample records rec[B, rec_stride] = [norm_action (A) | a_logp | adv | rand_action_mask | tar_val | pad]
+ * (rec_stride >= A + 4): one row gather per minibatch delivers all per-sample inputs of PPOAgent._compute_loss. */
+int parc_ppo_loss_packed(void *stream, int B, int A, const float *mean, const float *logstd, const float *rec, int rec_stride,
+                         const float *pred, parc_ppo_cfg_t cfg, float *g_mean, float *g_logstd, float *g_pred, float *out,
+                         float *workspace);
 
 /* ---- K15 experience record: ExperienceBuffer.record  learning/experience_buffer.py:55-59 for a group of buffers at once.
  * Field f copies src [N, row_bytes] into row *head of dst [T, N, row_bytes] (row_bytes a multiple of 4; 16-byte vector copies

@@ -23,7 +23,8 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_sample_kernel(int B, int A, c
                                                                  const float *__restrict__ norm_a, const float *__restrict__ old_logp,
                                                                  const float *__restrict__ adv, const float *__restrict__ mask,
                                                                  const float *__restrict__ pred, const float *__restrict__ tar_val,
-                                                                 parc_ppo_cfg_t cfg, float *g_mean, float *g_pred, float *ws) {
+                                                                 parc_ppo_cfg_t cfg, float *g_mean, float *g_pred, float *ws, int a_stride,
+                                                                 int s_stride) {
     __shared__ float s_istd[PPO_MAX_A];
     __shared__ float s_part[PPO_THREADS / 64][PPO_W];
     const int tid = threadIdx.x, i = blockIdx.x * PPO_THREADS + tid;
@@ -33,8 +34,11 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_sample_kernel(int B, int A, c
     for (int j = 0; j < A; ++j) sum_logstd += logstd[j];
     const bool live = i < B;
     const int ii = live ? i : 0;
-    const float m = live ? (mask[ii] == 1.0f ? 1.f : 0.f) : 0.f;
-    const float *mu = mean + (size_t)ii * A, *ac = norm_a + (size_t)ii * A;
+    // (a_stride / s_stride: row stride of norm_a and element stride of the four per-sample scalars; A and 1 for separate dense arrays,
+    //  the record width for the packed layout of parc_ppo_loss_packed)
+    const size_t si = (size_t)ii * s_stride;
+    const float m = live ? (mask[si] == 1.0f ? 1.f : 0.f) : 0.f;
+    const float *mu = mean + (size_t)ii * A, *ac = norm_a + (size_t)ii * a_stride;
     float zz = 0.f, viol = 0.f, reg = 0.f;
     for (int j = 0; j < A; ++j) {
         float mj = mu[j];
@@ -45,8 +49,8 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_sample_kernel(int B, int A, c
         reg = fmaf(mj, mj, reg);
     }
     const float logp = -0.5f * zz + (-0.5f * (float)A * 1.8378770664093453f - sum_logstd);     // log(2 pi)
-    const float ratio = __expf(logp - old_logp[ii]);
-    const float ad = adv[ii];
+    const float ratio = __expf(logp - old_logp[si]);
+    const float ad = adv[si];
     const float lo = 1.0f - cfg.clip_ratio, hi = 1.0f + cfg.clip_ratio;
     const float rc = fminf(fmaxf(ratio, lo), hi);
     const float l0 = ad * ratio, l1 = ad * rc;
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_sample_kernel(int B, int A, c
     // d surr / d ratio: torch.minimum sends the gradient to l0 when l0 <= l1, else to l1, whose clamp passes it inside [lo, hi]
     const float dsurr = (l0 <= l1) ? ad : ((ratio >= lo && ratio <= hi) ? ad : 0.f);
     const float c = -m * dsurr * ratio;                       // d(-sum m surr)/d logp_i   (x 1/cnt later)
-    const float diff = tar_val[ii] - pred[ii];
+    const float diff = tar_val[si] - pred[ii];
     if (live) {
         g_pred[i] = cfg.critic_l1 ? (diff > 0.f ? -1.f : (diff < 0.f ? 1.f : 0.f)) : -2.0f * diff;
         float *gm = g_mean + (size_t)i * A;
@@ -101,7 +105,10 @@ __global__ __launch_bounds__(128) void ppo_reduce_kernel(int B, int A, int nblk,
     __shared__ float s[PPO_W];
     const int tid = threadIdx.x;
     if (tid < PPO_NSCAL + A) {
+        // block partials added in block order (fixed, deterministic); unrolled so that the loads of 16 blocks are in flight together
+        // instead of one dependent load per step (this loop was most of the kernel's 26 us)
         double v = 0.0;
+#pragma unroll 16
         for (int b = 0; b < nblk; ++b) v += (double)ws[(size_t)b * PPO_W + tid];
         s[tid] = (float)v;
     }
@@ -145,14 +152,34 @@ __global__ __launch_bounds__(256) void ppo_scale_kernel(int n_mean, int n_pred, 
     if (i < n_pred) g_pred[i] *= sp;
 }
 
+static int ppo_loss_impl(void *stream, int B, int A, const float *mean, const float *logstd, const float *norm_a, const float *old_logp,
+                         const float *adv, const float *mask, const float *pred, const float *tar_val, parc_ppo_cfg_t cfg, float *g_mean,
+                         float *g_logstd, float *g_pred, float *out, float *workspace, int a_stride, int s_stride);
+
 extern "C" int parc_ppo_loss(void *stream, int B, int A, const float *mean, const float *logstd, const float *norm_a, const float *old_logp,
                              const float *adv, const float *mask, const float *pred, const float *tar_val, parc_ppo_cfg_t cfg, float *g_mean,
                              float *g_logstd, float *g_pred, float *out, float *workspace) {
+    return ppo_loss_impl(stream, B, A, mean, logstd, norm_a, old_logp, adv, mask, pred, tar_val, cfg, g_mean, g_logstd, g_pred, out, workspace, A, 1);
+}
+
+// the same loss on PACKED per-sample records rec[B, rec_stride] = [norm_action (A) | a_logp | adv | rand_action_mask | tar_val | pad]:
+// what one row gather of a minibatch delivers (the update phase gathers two arrays per minibatch instead of six)
+extern "C" int parc_ppo_loss_packed(void *stream, int B, int A, const float *mean, const float *logstd, const float *rec, int rec_stride,
+                                    const float *pred, parc_ppo_cfg_t cfg, float *g_mean, float *g_logstd, float *g_pred, float *out,
+                                    float *workspace) {
+    if (!rec || rec_stride < A + 4) return PARC_EINVAL;
+    return ppo_loss_impl(stream, B, A, mean, logstd, rec, rec + A, rec + A + 1, rec + A + 2, pred, rec + A + 3, cfg, g_mean, g_logstd, g_pred, out,
+                         workspace, rec_stride, rec_stride);
+}
+
+static int ppo_loss_impl(void *stream, int B, int A, const float *mean, const float *logstd, const float *norm_a, const float *old_logp,
+                         const float *adv, const float *mask, const float *pred, const float *tar_val, parc_ppo_cfg_t cfg, float *g_mean,
+                         float *g_logstd, float *g_pred, float *out, float *workspace, int a_stride, int s_stride) {
     if (B <= 0 || A <= 0 || A > PPO_MAX_A) return PARC_EINVAL;
     const int nblk = (B + PPO_THREADS - 1) / PPO_THREADS;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ppo_sample_kernel, dim3(nblk), dim3(PPO_THREADS), 0, st, B, A, mean, logstd, norm_a, old_logp, adv, mask, pred, tar_val, cfg,
-                       g_mean, g_pred, workspace);
+                       g_mean, g_pred, workspace, a_stride, s_stride);
     hipLaunchKernelGGL(ppo_reduce_kernel, dim3(1), dim3(128), 0, st, B, A, nblk, logstd, cfg, workspace, g_logstd, out);
     const int n = B * A;
     hipLaunchKernelGGL(ppo_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, B, out, g_mean, g_pred);

@@ -165,7 +165,10 @@ class DMPPOAgent(torch.nn.Module):
         add("next_char_contact_forces", [B, 3])
         add("env_id", [], torch.int64)
         add("norm_obs", obs_dim)          # not in the reference's buffer set: update-phase cache, see _LOSS_KEYS
-        add("norm_action", a_dim)         # likewise: Normalizer.normalize(action) of ppo_agent.py:214, once per iteration instead of per minibatch
+        # likewise: the per-sample inputs of the loss as ONE record per sample, [Normalizer.normalize(action) of ppo_agent.py:214 (A) | a_logp |
+        # adv | rand_action_mask | tar_val | pad], written once per iteration: a minibatch then gathers two arrays instead of six
+        self._loss_rec_w = ((a_dim[0] if isinstance(a_dim, (list, tuple)) else int(a_dim)) + 4 + 3) // 4 * 4
+        add("loss_rec", [self._loss_rec_w])
         self._env_ids = torch.arange(0, N, 1, device=dev, dtype=torch.int64)
         if self._is_terrain_runner:
             add("replan_timer", [])
@@ -486,8 +489,14 @@ class DMPPOAgent(torch.nn.Module):
         norm_adv, mean_std = rl_util.normalize_advantage(new_vals, vals, mask, self._norm_adv_clip)            # K17 (HIP)
         eb.set_data("tar_val", new_vals)
         eb.set_data("adv", norm_adv)
-        if eb.has_buffer("norm_action"):          # (the action normaliser is constant: bounds of the action space)
-            self._a_norm.normalize(eb.get_data("action"), out=eb.get_data("norm_action"))
+        if eb.has_buffer("loss_rec"):             # (the action normaliser is constant: bounds of the action space)
+            rec = eb.get_data("loss_rec")
+            A = eb.get_data("action").shape[-1]
+            self._a_norm.normalize(eb.get_data("action"), out=rec[..., 0:A])
+            rec[..., A] = eb.get_data("a_logp")
+            rec[..., A + 1] = norm_adv
+            rec[..., A + 2] = mask
+            rec[..., A + 3] = new_vals
         return {"adv_mean": mean_std[0], "adv_std": mean_std[1]}
 
     # ------------------------------------------------------------------ update (ppo_agent.py:186-330)
@@ -567,13 +576,15 @@ class DMPPOAgent(torch.nn.Module):
         loss kernel (value + dLoss/d outputs), DMPPOModel.train_backward writing every gradient once into the optimizer's flat buffer,
         clip + SGD.  Same arithmetic as _compute_loss + MPOptimizer.step (tests compare the two)."""
         norm_obs = batch["norm_obs"]
-        norm_a = batch["norm_action"] if "norm_action" in batch else self._a_norm.normalize(batch["action"])
         mean, logstd, pred, saved = self._model.train_forward(norm_obs)
         if self._ppo_cfg is None:
             self._ppo_cfg = rl_util.ppo_cfg(self._ppo_clip_ratio, self._action_bound_weight, self._action_entropy_weight, self._action_reg_weight,
                                             self._critic_loss_weight, 20.0, self._critic_loss_type != "L2")
-        out, g_mean, g_logstd, g_pred = rl_util.ppo_loss_and_grads(mean, logstd, pred, norm_a, batch["a_logp"], batch["adv"],
-                                                                    batch["rand_action_mask"], batch["tar_val"], self._ppo_cfg)
+        if "loss_rec" in batch:
+            out, g_mean, g_logstd, g_pred = rl_util.ppo_loss_and_grads_packed(mean, logstd, pred, batch["loss_rec"], self._ppo_cfg)
+        else:
+            out, g_mean, g_logstd, g_pred = rl_util.ppo_loss_and_grads(mean, logstd, pred, self._a_norm.normalize(batch["action"]), batch["a_logp"],
+                                                                        batch["adv"], batch["rand_action_mask"], batch["tar_val"], self._ppo_cfg)
         write = lambda grad_of, done: self._model.train_backward(saved, g_mean, g_logstd, g_pred, grad_of, done)
         if self._clip_grad_norm:
             self._optimizer.step_explicit(write, model=self._model, max_norm=self._max_grad_norm)
@@ -598,7 +609,7 @@ class DMPPOAgent(torch.nn.Module):
                                ("action_reg_loss", self._action_reg_weight, 7)):
                 if w != 0:
                     slots[name] = i
-            keys = [k for k in _LOSS_KEYS if k != "action"] + (["norm_action"] if self._exp_buffer.has_buffer("norm_action") else ["action"])
+            keys = ["norm_obs", "loss_rec"] if self._exp_buffer.has_buffer("loss_rec") else _LOSS_KEYS
             for _ in range(self._update_epochs):
                 for _ in range(num_batches):
                     self._minibatch_step_explicit(self._exp_buffer.sample(batch_size, keys=keys), acc)

@@ -116,4 +116,7 @@ class ExperienceBuffer:
             self._reset_sample_buf()
             idx = torch.cat([head, self._sample_buf[:rem]], dim=0)
             self._sample_buf_head = rem
-        return torch.remainder(idx, self.get_sample_count())
+        count = self.get_sample_count()
+        if count == L:                      # full buffer (every training iteration): the permutation already indexes it
+            return idx
+        return torch.remainder(idx, count)

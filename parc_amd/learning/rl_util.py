@@ -59,6 +59,23 @@ def ppo_loss_and_grads(mean, logstd, pred, norm_a, old_logp, adv, mask, tar_val,
     return out, g_mean, g_logstd, g_pred
 
 
+def ppo_loss_and_grads_packed(mean, logstd, pred, rec, cfg):
+    """ppo_loss_and_grads on packed per-sample records rec[B, W] = [norm_action (A) | a_logp | adv | rand_action_mask | tar_val | pad]"""
+    from .. import _hip
+    B, A = mean.shape
+    assert rec.dim() == 2 and rec.shape[0] == B and rec.shape[1] >= A + 4 and rec.is_contiguous()
+    mean = mean.contiguous()
+    g_mean = torch.empty_like(mean)
+    g_logstd = torch.empty_like(logstd)
+    g_pred = torch.empty(B, dtype=torch.float32, device=mean.device)
+    out = torch.empty(16, dtype=torch.float32, device=mean.device)
+    ws = torch.empty(_hip.lib().parc_ppo_workspace_floats(B), dtype=torch.float32, device=mean.device)
+    p = _hip.ptr
+    _hip.check(_hip.lib().parc_ppo_loss_packed(_hip.stream(), B, A, p(mean), p(logstd.contiguous()), p(rec), int(rec.shape[1]), p(pred.contiguous()),
+                                               cfg, p(g_mean), p(g_logstd), p(g_pred), p(out), p(ws)), "parc_ppo_loss_packed")
+    return out, g_mean, g_logstd, g_pred
+
+
 def ppo_cfg(clip_ratio, bound_w, entropy_w, reg_w, critic_w, large_critic_loss=20.0, critic_l1=False):
     from .. import _hip
     return _hip.PPOCfgS(float(clip_ratio), float(bound_w), float(entropy_w), float(reg_w), float(critic_w), float(large_critic_loss),

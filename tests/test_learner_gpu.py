@@ -175,7 +175,11 @@ def test_explicit_backward_equals_autograd():
     agent._build_train_data()
     eb = agent._exp_buffer
     idx = torch.randperm(8 * 256, device=DEV)[:512]
-    batch = {k: eb.get_data_flat(k)[idx] for k in _LOSS_KEYS + ["norm_action"]}
+    batch = {k: eb.get_data_flat(k)[idx] for k in _LOSS_KEYS + ["loss_rec"]}
+    A = batch["action"].shape[1]
+    rec = batch["loss_rec"]                            # the packed per-sample record holds what the six separate arrays hold
+    assert torch.equal(rec[:, 0:A], agent._a_norm.normalize(batch["action"])) and torch.equal(rec[:, A], batch["a_logp"])
+    assert torch.equal(rec[:, A + 1], batch["adv"]) and torch.equal(rec[:, A + 2], batch["rand_action_mask"]) and torch.equal(rec[:, A + 3], batch["tar_val"])
     # a spread of value targets / advantages so that every term of the loss is active
     flat = agent._optimizer._flat_grad
     agent.train()
@@ -190,8 +194,10 @@ def test_explicit_backward_equals_autograd():
     from parc_amd.learning import rl_util
     cfg = rl_util.ppo_cfg(agent._ppo_clip_ratio, agent._action_bound_weight, agent._action_entropy_weight, agent._action_reg_weight,
                           agent._critic_loss_weight, 20.0, agent._critic_loss_type != "L2")
-    out, g_mean, g_logstd, g_pred = rl_util.ppo_loss_and_grads(mean, logstd, pred, batch["norm_action"], batch["a_logp"], batch["adv"],
-                                                                batch["rand_action_mask"], batch["tar_val"], cfg)
+    out, g_mean, g_logstd, g_pred = rl_util.ppo_loss_and_grads_packed(mean, logstd, pred, rec, cfg)
+    out2, g_mean2, _, g_pred2 = rl_util.ppo_loss_and_grads(mean, logstd, pred, rec[:, 0:A].contiguous(), batch["a_logp"], batch["adv"],
+                                                            batch["rand_action_mask"], batch["tar_val"], cfg)
+    assert torch.equal(out[:9], out2[:9]) and torch.equal(g_mean, g_mean2) and torch.equal(g_pred, g_pred2)      # packed == separate arrays
     agent._model.train_backward(saved, g_mean, g_logstd, g_pred, lambda p: p.grad)
     torch.cuda.synchronize()
     assert abs(out[0].item() - info["loss"].item()) <= 1e-6 * max(1.0, abs(info["loss"].item()))
