@@ -231,7 +231,11 @@ class DMPPOModel(torch.nn.Module):
             done(self._action_dist._logstd_net)
         self._trunk_backward(self._actor_layers, a, torch.mm(g_mean, mnet.weight), grad_of, done)
         gp = g_pred.unsqueeze(-1)
-        torch.mm(gp.t(), c[-1], out=grad_of(self._critic_out.weight))
+        if self._critic_out.weight.shape[0] == 1:
+            # a [1, h] weight gradient is a matrix-vector product (as a GEMM with M = 1 the library takes 62 us for it, as a gemv ~10)
+            torch.mv(c[-1].t(), g_pred, out=grad_of(self._critic_out.weight).view(-1))
+        else:
+            torch.mm(gp.t(), c[-1], out=grad_of(self._critic_out.weight))
         torch.sum(gp, dim=0, out=grad_of(self._critic_out.bias))
         done(self._critic_out.weight)
         done(self._critic_out.bias)
