@@ -318,6 +318,9 @@ int parc_points_hf_sdf(void *stream, int batch, int n_points, int dim_x, int dim
  * gy, y: [rows, dim] row-major, dim % 4 == 0, 16-byte aligned; workspace: parc_relu_bwd_workspace_floats(rows, dim) floats. */
 int64_t parc_relu_bwd_workspace_floats(int64_t rows, int dim);
 int parc_relu_bwd_bias_grad(void *stream, int64_t rows, int dim, float *gy, const float *y, float *db, float *workspace);
+/* out[c] <- sum_r w[r] * x[r, c] (x [rows, dim] row-major, dim % 4 == 0, 16-byte aligned; workspace as above): the weight gradient of
+ * a Linear layer with one output (the value head `_critic_out`, learning/ppo_model.py:14-22), fixed summation order. */
+int parc_weighted_colsum(void *stream, int64_t rows, int dim, const float *x, const float *w, float *out, float *workspace);
 
 /* ---- measurement knobs (exported for tools/bench_kernels.py; not part of the stable ABI, defaults are the product path) ----
  * parc_tune_hf_envs_per_block(1|2|4|8): envs per workgroup of the standalone heightmap kernel;

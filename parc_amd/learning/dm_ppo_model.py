@@ -203,6 +203,16 @@ class DMPPOModel(torch.nn.Module):
         _hip.check(L.parc_relu_bwd_bias_grad(_hip.stream(), d.shape[0], d.shape[1], _hip.ptr(d), _hip.ptr(y), _hip.ptr(db), _hip.ptr(ws)),
                    "parc_relu_bwd_bias_grad")
 
+    def _weighted_colsum(self, x, w, out):
+        from .. import _hip
+        L = _hip.lib()
+        need = int(L.parc_relu_bwd_workspace_floats(x.shape[0], x.shape[1]))
+        ws = getattr(self, "_relu_ws", None)
+        if ws is None or ws.numel() < need or ws.device != x.device:
+            ws = self._relu_ws = torch.empty(max(need, 1), dtype=torch.float32, device=x.device)
+        _hip.check(L.parc_weighted_colsum(_hip.stream(), x.shape[0], x.shape[1], _hip.ptr(x), _hip.ptr(w.contiguous()), _hip.ptr(out), _hip.ptr(ws)),
+                   "parc_weighted_colsum")
+
     def _trunk_backward(self, seq, acts, d, grad_of, done):
         """d = dLoss/d(last activation) [B, h]; writes every layer's weight / bias gradient, last layer first."""
         lins = list(seq)[0::2]
@@ -232,8 +242,8 @@ class DMPPOModel(torch.nn.Module):
         self._trunk_backward(self._actor_layers, a, torch.mm(g_mean, mnet.weight), grad_of, done)
         gp = g_pred.unsqueeze(-1)
         if self._critic_out.weight.shape[0] == 1:
-            # a [1, h] weight gradient is a matrix-vector product (as a GEMM with M = 1 the library takes 62 us for it, as a gemv ~10)
-            torch.mv(c[-1].t(), g_pred, out=grad_of(self._critic_out.weight).view(-1))
+            # a [1, h] weight gradient is a weighted column sum (as a GEMM with M = 1 the library takes 62 us for it, as a gemv 311 us)
+            self._weighted_colsum(c[-1], g_pred, grad_of(self._critic_out.weight).view(-1))
         else:
             torch.mm(gp.t(), c[-1], out=grad_of(self._critic_out.weight))
         torch.sum(gp, dim=0, out=grad_of(self._critic_out.bias))
