@@ -99,6 +99,84 @@ __global__ __launch_bounds__(PPO_THREADS) void ppo_sample_kernel(int B, int A, c
     }
 }
 
+// pass 1 for A <= 32 (the humanoid has 28 actuated dofs): 32 lanes per sample, lane j = action dimension j, so the [B, A] rows of mean /
+// action / gradient are read and written coalesced (one thread per sample walks them with a 112-byte stride between lanes: 22 us for
+// 16384 samples).  A block takes 64 samples in 8 passes; the per-sample scalars accumulate on lane 0 of each group and the log-std
+// gradient of dimension j on lane j, folded over the 8 groups through LDS at the end (fixed order).
+#define PPO32_SPB 64
+__global__ __launch_bounds__(256) void ppo_sample32_kernel(int B, int A, const float *__restrict__ mean, const float *__restrict__ logstd,
+                                                           const float *__restrict__ norm_a, const float *__restrict__ old_logp,
+                                                           const float *__restrict__ adv, const float *__restrict__ mask,
+                                                           const float *__restrict__ pred, const float *__restrict__ tar_val, parc_ppo_cfg_t cfg,
+                                                           float *g_mean, float *g_pred, float *ws, int a_stride, int s_stride) {
+    __shared__ float s_part[8][PPO_W];
+    const int tid = threadIdx.x, g = tid >> 5, j = tid & 31;
+    const bool vj = j < A;
+    const float ls = vj ? logstd[j] : 0.f;
+    const float istd = __expf(-ls);
+    float sum_logstd = ls;
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) sum_logstd += __shfl_xor(sum_logstd, o, 32);
+    float acc[PPO_NSCAL];
+#pragma unroll
+    for (int k = 0; k < PPO_NSCAL; ++k) acc[k] = 0.f;
+    float acc_ls = 0.f;
+    const float lo = 1.0f - cfg.clip_ratio, hi = 1.0f + cfg.clip_ratio;
+#pragma unroll 2
+    for (int it = 0; it < PPO32_SPB / 8; ++it) {
+        const int i = blockIdx.x * PPO32_SPB + it * 8 + g;
+        const bool live = i < B;
+        const int ii = live ? i : 0;
+        const size_t si = (size_t)ii * s_stride;
+        const float m = live ? (mask[si] == 1.0f ? 1.f : 0.f) : 0.f;
+        const float mj = vj ? mean[(size_t)ii * A + j] : 0.f;
+        const float aj = vj ? norm_a[(size_t)ii * a_stride + j] : 0.f;
+        const float z = (aj - mj) * istd;
+        const float vmin = fminf(mj + 1.0f, 0.f), vmax = fmaxf(mj - 1.0f, 0.f);
+        float zz = vj ? z * z : 0.f, viol = vj ? vmin * vmin + vmax * vmax : 0.f, reg = vj ? mj * mj : 0.f;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) {
+            zz += __shfl_xor(zz, o, 32);
+            viol += __shfl_xor(viol, o, 32);
+            reg += __shfl_xor(reg, o, 32);
+        }
+        const float logp = -0.5f * zz + (-0.5f * (float)A * 1.8378770664093453f - sum_logstd);
+        const float ratio = __expf(logp - old_logp[si]);
+        const float ad = adv[si];
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float l0 = ad * ratio, l1 = ad * rc;
+        const float surr = fminf(l0, l1);
+        const float dsurr = (l0 <= l1) ? ad : ((ratio >= lo && ratio <= hi) ? ad : 0.f);
+        const float c = -m * dsurr * ratio;
+        const float diff = tar_val[si] - pred[ii];
+        if (live) {
+            if (j == 0) g_pred[i] = cfg.critic_l1 ? (diff > 0.f ? -1.f : (diff < 0.f ? 1.f : 0.f)) : -2.0f * diff;
+            if (vj) g_mean[(size_t)i * A + j] = c * z * istd + m * (cfg.bound_w * 2.0f * (vmin + vmax) + cfg.reg_w * 2.0f * mj);
+        }
+        // (every lane of the group holds the same scalars; lane 0's copy is the one that is kept)
+        acc[0] += m;
+        acc[1] += live ? (cfg.critic_l1 ? fabsf(diff) : diff * diff) : 0.f;
+        acc[2] += m * surr;
+        acc[3] += m * (fabsf(ratio - 1.0f) > cfg.clip_ratio ? 1.f : 0.f);
+        acc[4] += m * ratio;
+        acc[5] += m * viol;
+        acc[6] += m * reg;
+        acc_ls += (live && vj) ? c * (z * z - 1.0f) : 0.f;
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int k = 0; k < PPO_NSCAL; ++k) s_part[g][k] = acc[k];
+    }
+    if (vj) s_part[g][PPO_NSCAL + j] = acc_ls;
+    __syncthreads();
+    if (tid < PPO_NSCAL + A) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += s_part[w][tid];
+        ws[(size_t)blockIdx.x * PPO_W + tid] = v;
+    }
+}
+
 // pass 2: one small block reduces the block partials in order and produces the scalars, the log-std gradient and the scale factors
 __global__ __launch_bounds__(128) void ppo_reduce_kernel(int B, int A, int nblk, const float *__restrict__ logstd, parc_ppo_cfg_t cfg,
                                                          const float *__restrict__ ws, float *g_logstd, float *out) {
@@ -176,10 +254,16 @@ static int ppo_loss_impl(void *stream, int B, int A, const float *mean, const fl
                          const float *adv, const float *mask, const float *pred, const float *tar_val, parc_ppo_cfg_t cfg, float *g_mean,
                          float *g_logstd, float *g_pred, float *out, float *workspace, int a_stride, int s_stride) {
     if (B <= 0 || A <= 0 || A > PPO_MAX_A) return PARC_EINVAL;
-    const int nblk = (B + PPO_THREADS - 1) / PPO_THREADS;
+    int nblk = (B + PPO_THREADS - 1) / PPO_THREADS;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ppo_sample_kernel, dim3(nblk), dim3(PPO_THREADS), 0, st, B, A, mean, logstd, norm_a, old_logp, adv, mask, pred, tar_val, cfg,
-                       g_mean, g_pred, workspace, a_stride, s_stride);
+    if (A <= 32) {
+        nblk = (B + PPO32_SPB - 1) / PPO32_SPB;
+        hipLaunchKernelGGL(ppo_sample32_kernel, dim3(nblk), dim3(256), 0, st, B, A, mean, logstd, norm_a, old_logp, adv, mask, pred, tar_val, cfg,
+                           g_mean, g_pred, workspace, a_stride, s_stride);
+    } else {
+        hipLaunchKernelGGL(ppo_sample_kernel, dim3(nblk), dim3(PPO_THREADS), 0, st, B, A, mean, logstd, norm_a, old_logp, adv, mask, pred, tar_val,
+                           cfg, g_mean, g_pred, workspace, a_stride, s_stride);
+    }
     hipLaunchKernelGGL(ppo_reduce_kernel, dim3(1), dim3(128), 0, st, B, A, nblk, logstd, cfg, workspace, g_logstd, out);
     const int n = B * A;
     hipLaunchKernelGGL(ppo_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, B, out, g_mean, g_pred);
@@ -187,7 +271,7 @@ static int ppo_loss_impl(void *stream, int B, int A, const float *mean, const fl
     return e == hipSuccess ? PARC_OK : (int)e;
 }
 
-extern "C" int parc_ppo_workspace_floats(int B) { return ((B + PPO_THREADS - 1) / PPO_THREADS) * PPO_W; }
+extern "C" int parc_ppo_workspace_floats(int B) { return ((B + PPO32_SPB - 1) / PPO32_SPB) * PPO_W; }      // (the finer of the two block sizes)
 
 // =============================================================================================
 // K15 experience record: ExperienceBuffer.record (learning/experience_buffer.py:55-59) for a whole group of named buffers in one
