@@ -11,7 +11,7 @@ python3 - <<'PY'
 import csv
 rows=list(csv.DictReader(open('gpurun_out/updtrace/trace.csv')))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if r['Kernel_Name'].startswith('ppo_sample_kernel')]
+idx=[i for i,r in enumerate(rows) if r['Kernel_Name'].startswith('ppo_sample')]
 a,b=idx[-3],idx[-2]
 t0=int(rows[a]['Start_Timestamp'])
 small=0; smallt=0
