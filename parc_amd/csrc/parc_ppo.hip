@@ -178,18 +178,27 @@ __global__ __launch_bounds__(256) void ppo_sample32_kernel(int B, int A, const f
 }
 
 // pass 2: one small block reduces the block partials in order and produces the scalars, the log-std gradient and the scale factors
-__global__ __launch_bounds__(128) void ppo_reduce_kernel(int B, int A, int nblk, const float *__restrict__ logstd, parc_ppo_cfg_t cfg,
-                                                         const float *__restrict__ ws, float *g_logstd, float *out) {
+#define PPO_RED_THREADS (4 * PPO_W)
+__global__ __launch_bounds__(PPO_RED_THREADS) void ppo_reduce_kernel(int B, int A, int nblk, const float *__restrict__ logstd, parc_ppo_cfg_t cfg,
+                                                                    const float *__restrict__ ws, float *g_logstd, float *out) {
     __shared__ float s[PPO_W];
+    __shared__ double s4[PPO_W][4];
     const int tid = threadIdx.x;
-    if (tid < PPO_NSCAL + A) {
-        // block partials added in block order (fixed, deterministic); unrolled so that the loads of 16 blocks are in flight together
-        // instead of one dependent load per step (this loop was most of the kernel's 26 us)
-        double v = 0.0;
+    {
+        // value v of the block partials: four threads add a quarter of the blocks each, in block order, their sums are then added in
+        // quarter order (fixed summation order, deterministic); unrolled so that 16 loads are in flight instead of one dependent load
+        // per step (that loop was most of the kernel's 26 us)
+        const int v = tid >> 2, part = tid & 3;
+        const int per = (nblk + 3) >> 2, b0 = part * per, b1 = min(b0 + per, nblk);
+        double acc = 0.0;
+        if (v < PPO_NSCAL + A) {
 #pragma unroll 16
-        for (int b = 0; b < nblk; ++b) v += (double)ws[(size_t)b * PPO_W + tid];
-        s[tid] = (float)v;
+            for (int b = b0; b < b1; ++b) acc += (double)ws[(size_t)b * PPO_W + v];
+        }
+        s4[v][part] = acc;
     }
+    __syncthreads();
+    if (tid < PPO_NSCAL + A) s[tid] = (float)((s4[tid][0] + s4[tid][1]) + (s4[tid][2] + s4[tid][3]));
     __syncthreads();
     const float msum = s[0];
     // no random-action sample in the batch: the reference takes means over an empty selection, which are NaN, and its NaN trap
@@ -264,7 +273,7 @@ static int ppo_loss_impl(void *stream, int B, int A, const float *mean, const fl
         hipLaunchKernelGGL(ppo_sample_kernel, dim3(nblk), dim3(PPO_THREADS), 0, st, B, A, mean, logstd, norm_a, old_logp, adv, mask, pred, tar_val,
                            cfg, g_mean, g_pred, workspace, a_stride, s_stride);
     }
-    hipLaunchKernelGGL(ppo_reduce_kernel, dim3(1), dim3(128), 0, st, B, A, nblk, logstd, cfg, workspace, g_logstd, out);
+    hipLaunchKernelGGL(ppo_reduce_kernel, dim3(1), dim3(PPO_RED_THREADS), 0, st, B, A, nblk, logstd, cfg, workspace, g_logstd, out);
     const int n = B * A;
     hipLaunchKernelGGL(ppo_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, B, out, g_mean, g_pred);
     hipError_t e = hipGetLastError();
