@@ -285,6 +285,13 @@ int parc_return_tracker_update(void *stream, int n_envs, int K, const float *rew
 /* ---- gradient clipping by global norm over a flat buffer (MPOptimizer.step, learning/mp_optimizer.py:24-40 with
  * torch.nn.utils.clip_grad_norm_): x[0..n) *= min(max_norm / (norm[0] + 1e-6), 1); norm is a device scalar. */
 int parc_scale_by_clipped_norm(void *stream, int64_t n, float *x, const float *norm, float max_norm);
+/* K20 in two passes over flat buffers (MPOptimizer.step, learning/mp_optimizer.py:20-40: clip_grad_norm_ then SGD with momentum):
+ * norm = |grad|_2 (fixed summation order), coef = min(max_norm / (norm + 1e-6), 1) (max_norm <= 0: no clipping), g' = coef grad
+ * (+ weight_decay * p), momentum_buf = momentum * momentum_buf + g', params -= lr * momentum_buf.  grad is left as it was.
+ * grad 16-byte aligned; workspace: parc_sgd_workspace_floats() floats; norm_out (may be NULL): the gradient norm. */
+int64_t parc_sgd_workspace_floats(void);
+int parc_sgd_momentum_step(void *stream, int64_t n, float *params, const float *grad, float *momentum_buf, float max_norm, float lr,
+                           float momentum, float weight_decay, float *workspace, float *norm_out);
 
 /* ---- K12: Normalizer.normalize  learning/normalizer.py:60-63 in one pass: out = clamp((x - mean) / std, -clip, clip).
  * x, out [rows, dim] row-major, mean / std [dim]; dim a multiple of 4, 16-byte aligned pointers; out may alias x. */

@@ -175,6 +175,10 @@ def _declare(L):
     L.parc_relu_bwd_bias_grad.restype = c_int
     L.parc_weighted_colsum.argtypes = [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]
     L.parc_weighted_colsum.restype = c_int
+    L.parc_sgd_workspace_floats.argtypes = []
+    L.parc_sgd_workspace_floats.restype = c_i64
+    L.parc_sgd_momentum_step.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_f, c_f, c_f, c_f, c_vp, c_vp]
+    L.parc_sgd_momentum_step.restype = c_int
     L.parc_return_tracker_update.argtypes = [c_vp, c_int, c_int, c_vp, c_i64] + [c_vp] * 8
     L.parc_return_tracker_workspace_floats.argtypes = [c_int]
     L.parc_return_tracker_workspace_floats.restype = c_i64
@@ -198,7 +202,7 @@ EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hf
             "parc_forward_kinematics", "parc_calc_motion_frame", "parc_motion_lib_build", "parc_track_post_step",
             "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize", "parc_reset_apply", "parc_ppo_loss", "parc_ppo_workspace_floats", "parc_record_step", "parc_return_tracker_update", "parc_normalize_clamp",
             "parc_action_head", "parc_points_hf_sdf", "parc_moments_workspace_floats", "parc_moments_accumulate", "parc_reset_sample_apply", "parc_return_tracker_workspace_floats", "parc_scale_by_clipped_norm", "parc_relu_bwd_workspace_floats",
-            "parc_relu_bwd_bias_grad", "parc_ppo_loss_packed", "parc_weighted_colsum"]
+            "parc_relu_bwd_bias_grad", "parc_ppo_loss_packed", "parc_weighted_colsum", "parc_sgd_workspace_floats", "parc_sgd_momentum_step"]
 
 
 def check(rc, what):

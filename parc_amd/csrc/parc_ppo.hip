@@ -448,6 +448,79 @@ extern "C" int parc_scale_by_clipped_norm(void *stream, int64_t n, float *x, con
 }
 
 // =============================================================================================
+// K20 optimizer step over flat buffers: MPOptimizer.step (learning/mp_optimizer.py:20-40) = clip_grad_norm_ + SGD with momentum, as
+// TWO passes over the 10.6 M parameters instead of four (norm, scale, multi-tensor SGD, + a zero fill): pass 1 the squared norm of
+// the flat gradient (1024 block partials), pass 2 every block first adds the partials in block order (fixed order, the same value
+// in every block), coef = min(max_norm / (norm + 1e-6), 1), then for its elements g' = coef g (+ wd p), m = mu m + g', p -= lr m
+// (torch.optim.SGD, dampening 0, no Nesterov; a zero momentum buffer reproduces its first-step rule buf = g').
+// =============================================================================================
+#define SGD_PARTS 1024
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(size_t n4, const float4 *__restrict__ g, size_t n, const float *__restrict__ gs,
+                                                            float *__restrict__ partial) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = g[i];
+        acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {       // tail elements beyond the last whole float4
+        const float t = gs[4 * n4 + threadIdx.x];
+        acc = fmaf(t, t, acc);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sgd_momentum_clip_kernel(size_t n, float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                                const float *__restrict__ partial, float max_norm, float lr, float mu, float wd,
+                                                                float *norm_out) {
+    __shared__ float s_red[256];
+    float coef = 1.0f;
+    if (max_norm > 0.f) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < SGD_PARTS / 256; ++k) a += partial[threadIdx.x * (SGD_PARTS / 256) + k];      // consecutive partials per thread
+        s_red[threadIdx.x] = a;
+        __syncthreads();
+        for (int w = 128; w >= 1; w >>= 1) {          // pairwise tree over the 256 per-thread sums: the same order in every block
+            if ((int)threadIdx.x < w) s_red[threadIdx.x] += s_red[threadIdx.x + w];
+            __syncthreads();
+        }
+        const float norm = sqrtf(s_red[0]);
+        coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
+        if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) norm_out[0] = norm;
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float pi = p[i];
+        float gi = coef * g[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        const float mi = fmaf(mu, m[i], gi);
+        m[i] = mi;
+        p[i] = fmaf(-lr, mi, pi);
+    }
+}
+
+extern "C" int64_t parc_sgd_workspace_floats(void) { return SGD_PARTS; }
+
+extern "C" int parc_sgd_momentum_step(void *stream, int64_t n, float *params, const float *grad, float *momentum_buf, float max_norm, float lr,
+                                      float momentum, float weight_decay, float *workspace, float *norm_out) {
+    if (n < 0 || !params || !grad || !momentum_buf || !workspace || ((uintptr_t)grad & 15)) return PARC_EINVAL;
+    if (n == 0) return PARC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (max_norm > 0.f)
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SGD_PARTS), dim3(256), 0, st, (size_t)n / 4, (const float4 *)grad, (size_t)n, grad, workspace);
+    size_t blocks = ((size_t)n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(sgd_momentum_clip_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (size_t)n, params, grad, momentum_buf, workspace, max_norm,
+                       lr, momentum, weight_decay, norm_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}
+
+// =============================================================================================
 // K12 observation normalisation: Normalizer.normalize (learning/normalizer.py:60-63)  out = clamp((x - mean) / std, -clip, clip)
 // in one pass (torch: subtract, divide, clamp = three passes).  Same fp32 operations, so the result is bit-identical.
 // =============================================================================================

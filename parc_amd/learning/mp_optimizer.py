@@ -36,6 +36,24 @@ class MPOptimizer:
         for p in param_list:
             p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
             off += p.numel()
+        # SGD on the GPU: parameters and momentum live in flat buffers too (every parameter is a view, like its gradient), and clip +
+        # momentum + update are two passes over them (parc_sgd_momentum_step) instead of norm, scale, multi-tensor SGD and a fill
+        self._flat_sgd = (config["type"] == "SGD" and param_list[0].is_cuda and param_list[0].dtype == torch.float32
+                          and bool(config.get("flat_sgd", True)))
+        if self._flat_sgd:
+            from .. import _hip
+            self._flat_param = torch.empty(n, dtype=torch.float32, device=param_list[0].device)
+            off = 0
+            with torch.no_grad():
+                for p in param_list:
+                    view = self._flat_param[off:off + p.numel()].view_as(p)
+                    view.copy_(p)
+                    p.data = view
+                    off += p.numel()
+            self._flat_mom = torch.zeros_like(self._flat_param)
+            self._sgd_ws = torch.empty(int(_hip.lib().parc_sgd_workspace_floats()), dtype=torch.float32, device=self._flat_param.device)
+            self._grad_norm = torch.zeros(1, dtype=torch.float32, device=self._flat_param.device)
+            self._lr, self._momentum, self._wd = lr, 0.9, wd
         self.sync()
         # Overlap of the per-minibatch exchange with backward: the flat gradient is cut into a few contiguous buckets at
         # parameter boundaries; a bucket's all-reduce starts (asynchronously, on RCCL's stream) as soon as the last of its
@@ -148,7 +166,24 @@ class MPOptimizer:
         self._backward_and_exchange(loss)
         self._finish_step(**kwargs)
 
+    def reset_state(self):
+        """Forget the optimizer's moments (tests restart from saved weights)."""
+        if self._flat_sgd:
+            self._flat_mom.zero_()
+        else:
+            self._optimizer.state.clear()
+
     def _finish_step(self, **kwargs):
+        if self._flat_sgd:
+            from .. import _hip
+            max_norm = float(kwargs["max_norm"]) if "model" in kwargs else -1.0
+            _hip.check(_hip.lib().parc_sgd_momentum_step(_hip.stream(), self._flat_param.numel(), _hip.ptr(self._flat_param), _hip.ptr(self._flat_grad),
+                                                         _hip.ptr(self._flat_mom), max_norm, float(self._lr), float(self._momentum), float(self._wd),
+                                                         _hip.ptr(self._sgd_ws), _hip.ptr(self._grad_norm)), "parc_sgd_momentum_step")
+            if mp_util.enable_mp() and self._cadence == "minibatch" and self._steps % self.CHECK_SYNC_STEPS == 0:
+                assert self._check_synced(), "Network parameters desynchronized"
+            self._steps += 1
+            return
         if "model" in kwargs:
             # the gradient norm of the flat buffer == norm over model parameters (all trainable params are in it)
             max_norm = kwargs["max_norm"]
@@ -168,6 +203,12 @@ class MPOptimizer:
         """Per-epoch exchange of the "epoch" cadence: average parameters and float optimizer state over the ranks with ONE
         all-reduce of a flat buffer (no-op for the per-minibatch cadence or a single process)."""
         if not (mp_util.enable_mp() and self._cadence == "epoch"):
+            return
+        if self._flat_sgd:
+            with torch.no_grad():
+                for flat in (self._flat_param, self._flat_mom):
+                    torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM)
+                    flat /= mp_util.get_num_procs()
             return
         with torch.no_grad():
             tensors = list(self._param_list)

@@ -212,7 +212,7 @@ def test_explicit_backward_equals_autograd():
     results = []
     for explicit in (False, True):
         agent.load_state_dict(sd)
-        agent._optimizer._optimizer.state.clear()
+        agent._optimizer.reset_state()
         agent._config["explicit_backward"] = explicit
         eb._reset_sample_buf()
         torch.manual_seed(5)
@@ -254,3 +254,31 @@ def test_relu_bwd_bias_grad_kernel():
         _hip.check(L.parc_weighted_colsum(_hip.stream(), rows, dim, _hip.ptr(x), _hip.ptr(w), _hip.ptr(out), _hip.ptr(ws)), "weighted_colsum")
         ref = (w.double().unsqueeze(0) @ x.double()).squeeze(0)
         assert float((out.double() - ref).abs().max()) <= 2e-5 * (rows ** 0.5)
+
+
+def test_flat_sgd_step_equals_torch_sgd_with_clipping():
+    """parc_sgd_momentum_step (clip by global norm + SGD with momentum over flat buffers, two passes) against clip_grad_norm_ +
+    torch.optim.SGD(momentum=0.9) on the same gradients, three steps, with and without the clip being active."""
+    from parc_amd.learning import mp_optimizer
+    for max_norm in (1000.0, 0.5):
+        torch.manual_seed(1)
+        ref = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.ReLU(), torch.nn.Linear(53, 5)).to(DEV)
+        mine = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.ReLU(), torch.nn.Linear(53, 5)).to(DEV)
+        mine.load_state_dict(ref.state_dict())
+        opt_ref = torch.optim.SGD(ref.parameters(), 5e-3, momentum=0.9)
+        opt = mp_optimizer.MPOptimizer({"type": "SGD", "learning_rate": 5e-3}, list(mine.parameters()))
+        assert opt._flat_sgd and all(p.data_ptr() >= opt._flat_param.data_ptr() for p in mine.parameters())
+        for step in range(3):
+            x = torch.randn(64, 37, device=DEV)
+            opt_ref.zero_grad()
+            ref(x).square().sum().backward()
+            gn = torch.nn.utils.clip_grad_norm_(ref.parameters(), max_norm)
+            opt_ref.step()
+            opt.step(mine(x).square().sum(), model=mine, max_norm=max_norm)
+            assert abs(opt._grad_norm.item() - gn.item()) <= 1e-5 * gn.item()
+            for a, b in zip(mine.parameters(), ref.parameters()):
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (step, float((a - b).abs().max()))
+        assert (gn.item() > max_norm) == (max_norm == 0.5)
+    sd = mine.state_dict()                                        # parameters are views of the flat buffer: state_dict round trip
+    mine.load_state_dict({k: v.clone() + 1.0 for k, v in sd.items()})
+    assert torch.allclose(opt._flat_param, torch.cat([p.reshape(-1) for p in mine.parameters()]))
