@@ -322,9 +322,7 @@ int parc_points_hf_sdf(void *stream, int batch, int n_points, int dim_x, int dim
 
 /* Backward of a Linear + ReLU layer between its two GEMMs (the derivative of learning/nets/fc_3layers_2048units.py:4-22): in one pass
  * gy[r, c] <- gy[r, c] * (y[r, c] > 0) (in place) and db[c] <- sum_r of the result (overwritten, fixed summation order).
- * gy, y: [rows, dim] row-major, dim % 4 == 0, 16-byte aligned; workspace: parc_relu_bwd_workspace_floats(rows, dim) floats, ZEROED
- * by the caller once before its first use (its first 64 words are arrival counters that every call leaves at zero; the same
- * workspace may serve calls of different shapes, one at a time). */
+ * gy, y: [rows, dim] row-major, dim % 4 == 0, 16-byte aligned; workspace: parc_relu_bwd_workspace_floats(rows, dim) floats. */
 int64_t parc_relu_bwd_workspace_floats(int64_t rows, int dim);
 int parc_relu_bwd_bias_grad(void *stream, int64_t rows, int dim, float *gy, const float *y, float *db, float *workspace);
 /* out[c] <- sum_r w[r] * x[r, c] (x [rows, dim] row-major, dim % 4 == 0, 16-byte aligned; workspace as above): the weight gradient of

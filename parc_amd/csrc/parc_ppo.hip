@@ -624,32 +624,9 @@ extern "C" int parc_moments_accumulate(void *stream, int64_t rows, int dim, cons
 // OVERWRITES db.  The forward pass is learning/nets/fc_3layers_2048units.py:4-22 of the reference; this is its derivative.
 // =============================================================================================
 #define RB_ROWS 128
-// Stage 2 inside the same launch: the last row-chunk workgroup of a column block to finish (atomic ticket per column block, reset on
-// the way out; the tickets sit at the start of the workspace, which the host zeroes once) adds that block's partial rows in chunk
-// order and writes the 256 column sums - the separate 5 us final launch per layer is gone, the summation order is unchanged.
-#define RB_TICKETS 64          // ints at the start of the workspace: up to 64 column blocks = 16384 columns
-__device__ __forceinline__ void colsum_finish(int *ticket, int chunks, int dim, const float *partial, float *out, bool *s_last) {
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) *s_last = atomicAdd(ticket + blockIdx.x, 1) == chunks - 1;
-    __syncthreads();
-    if (!*s_last) return;
-    __threadfence();
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < dim) {
-        const volatile float *pv = partial;
-        float t = 0.f;
-#pragma unroll 16
-        for (int k = 0; k < chunks; ++k) t += pv[(size_t)k * dim + c];
-        out[c] = t;
-    }
-    if (threadIdx.x == 0) ticket[blockIdx.x] = 0;
-}
-
 __global__ __launch_bounds__(256) void relu_bwd_bias_partial_kernel(int rows, int dim4, float4 *__restrict__ gy, const float4 *__restrict__ y,
-                                                                    float4 *__restrict__ partial, int *ticket, float *out) {
+                                                                    float4 *__restrict__ partial) {
     __shared__ float4 red[4][64];
-    __shared__ bool s_last;
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * RB_ROWS, r1 = min(r0 + RB_ROWS, rows);
@@ -673,7 +650,6 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_partial_kernel(int rows, in
         o.x = (a.x + b.x) + (d.x + e.x); o.y = (a.y + b.y) + (d.y + e.y); o.z = (a.z + b.z) + (d.z + e.z); o.w = (a.w + b.w) + (d.w + e.w);
         partial[(size_t)blockIdx.y * dim4 + c] = o;
     }
-    colsum_finish(ticket, (int)gridDim.y, dim4 * 4, reinterpret_cast<const float *>(partial), out, &s_last);
 }
 
 __global__ __launch_bounds__(256) void colsum_final_kernel(int chunks, int dim, const float *__restrict__ partial, float *__restrict__ out) {
@@ -688,9 +664,8 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(int chunks, int dim, 
 // out[c] = sum_r w[r] * x[r, c]: the weight gradient of a Linear layer with ONE output (the value head: dW = g_pred^T h), which as
 // a GEMM with M = 1 costs the library 62 us and as its transposed gemv 311 us for 33 MB of reading; same two stages as above.
 __global__ __launch_bounds__(256) void weighted_colsum_partial_kernel(int rows, int dim4, const float4 *__restrict__ x, const float *__restrict__ w,
-                                                                      float4 *__restrict__ partial, int *ticket, float *out) {
+                                                                      float4 *__restrict__ partial) {
     __shared__ float4 red[4][64];
-    __shared__ bool s_last;
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * RB_ROWS, r1 = min(r0 + RB_ROWS, rows);
@@ -711,26 +686,23 @@ __global__ __launch_bounds__(256) void weighted_colsum_partial_kernel(int rows, 
         o.x = (a.x + b.x) + (d.x + e.x); o.y = (a.y + b.y) + (d.y + e.y); o.z = (a.z + b.z) + (d.z + e.z); o.w = (a.w + b.w) + (d.w + e.w);
         partial[(size_t)blockIdx.y * dim4 + c] = o;
     }
-    colsum_finish(ticket, (int)gridDim.y, dim4 * 4, reinterpret_cast<const float *>(partial), out, &s_last);
 }
 
 extern "C" int parc_weighted_colsum(void *stream, int64_t rows, int dim, const float *x, const float *w, float *out, float *workspace) {
     if (rows < 0 || dim <= 0 || (dim & 3) || !x || !w || !out || !workspace || (((uintptr_t)x | (uintptr_t)workspace) & 15)) return PARC_EINVAL;
     if (rows > (int64_t)RB_ROWS * 65535) return PARC_EUNSUPPORTED;
     const int dim4 = dim / 4, chunks = (int)((rows + RB_ROWS - 1) / RB_ROWS);
-    if ((dim4 + 63) / 64 > RB_TICKETS) return PARC_EUNSUPPORTED;
     if (rows > 0)
         hipLaunchKernelGGL(weighted_colsum_partial_kernel, dim3((dim4 + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, (int)rows, dim4,
-                           (const float4 *)x, w, (float4 *)(workspace + RB_TICKETS), (int *)workspace, out);
-    else
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, 0, dim, workspace, out);
+                           (const float4 *)x, w, (float4 *)workspace);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, chunks, dim, workspace, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }
 
 extern "C" int64_t parc_relu_bwd_workspace_floats(int64_t rows, int dim) {
     if (rows < 0 || dim <= 0) return -1;
-    return RB_TICKETS + ((rows + RB_ROWS - 1) / RB_ROWS) * (int64_t)dim;
+    return ((rows + RB_ROWS - 1) / RB_ROWS) * (int64_t)dim;
 }
 
 extern "C" int parc_relu_bwd_bias_grad(void *stream, int64_t rows, int dim, float *gy, const float *y, float *db, float *workspace) {
@@ -738,12 +710,10 @@ extern "C" int parc_relu_bwd_bias_grad(void *stream, int64_t rows, int dim, floa
         return PARC_EINVAL;
     if (rows > (int64_t)RB_ROWS * 65535) return PARC_EUNSUPPORTED;
     const int dim4 = dim / 4, chunks = (int)((rows + RB_ROWS - 1) / RB_ROWS);
-    if ((dim4 + 63) / 64 > RB_TICKETS) return PARC_EUNSUPPORTED;
     if (rows > 0)
         hipLaunchKernelGGL(relu_bwd_bias_partial_kernel, dim3((dim4 + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, (int)rows, dim4,
-                           (float4 *)gy, (const float4 *)y, (float4 *)(workspace + RB_TICKETS), (int *)workspace, db);
-    else
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, 0, dim, workspace, db);
+                           (float4 *)gy, (const float4 *)y, (float4 *)workspace);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, chunks, dim, workspace, db);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }

@@ -199,7 +199,7 @@ class DMPPOModel(torch.nn.Module):
         need = int(L.parc_relu_bwd_workspace_floats(d.shape[0], d.shape[1]))
         ws = getattr(self, "_relu_ws", None)
         if ws is None or ws.numel() < need or ws.device != d.device:
-            ws = self._relu_ws = torch.zeros(max(need, 1), dtype=torch.float32, device=d.device)      # (zeroed once: arrival counters)
+            ws = self._relu_ws = torch.empty(max(need, 1), dtype=torch.float32, device=d.device)
         _hip.check(L.parc_relu_bwd_bias_grad(_hip.stream(), d.shape[0], d.shape[1], _hip.ptr(d), _hip.ptr(y), _hip.ptr(db), _hip.ptr(ws)),
                    "parc_relu_bwd_bias_grad")
 
@@ -209,7 +209,7 @@ class DMPPOModel(torch.nn.Module):
         need = int(L.parc_relu_bwd_workspace_floats(x.shape[0], x.shape[1]))
         ws = getattr(self, "_relu_ws", None)
         if ws is None or ws.numel() < need or ws.device != x.device:
-            ws = self._relu_ws = torch.zeros(max(need, 1), dtype=torch.float32, device=x.device)
+            ws = self._relu_ws = torch.empty(max(need, 1), dtype=torch.float32, device=x.device)
         _hip.check(L.parc_weighted_colsum(_hip.stream(), x.shape[0], x.shape[1], _hip.ptr(x), _hip.ptr(w.contiguous()), _hip.ptr(out), _hip.ptr(ws)),
                    "parc_weighted_colsum")
 

