@@ -56,6 +56,27 @@ def _worker(rank, world, port, out):
         res_ov.append([p.detach().numpy().copy() for p in m3.parameters()])
     for a_, b_ in zip(*res_ov):
         assert (a_ == b_).all() or abs(a_ - b_).max() < 1e-7
+    # explicit-gradient step (the caller writes every gradient slice and reports completion in backward order; the bucketed exchange is
+    # started from those reports): same parameters as loss.backward() through step(), with and without buckets
+    for overlap in (True, False):
+        torch.manual_seed(300)
+        m4 = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2))
+        o4 = mp_optimizer.MPOptimizer({"type": "SGD", "learning_rate": 0.1, "overlap_allreduce": overlap, "allreduce_buckets": 3},
+                                      list(m4.parameters()))
+        for k in range(3):
+            torch.manual_seed(400 + 10 * k + rank)
+            xx = torch.randn(7, 6)
+            grads = torch.autograd.grad(torch.mean(torch.square(m4(xx) - 1.0)), list(m4.parameters()))
+
+            def write(grad_of, done, grads=grads, params=list(m4.parameters())):
+                for p_, g_ in reversed(list(zip(params, grads))):          # last layer first, like a backward pass
+                    grad_of(p_).copy_(g_)
+                    done(p_)
+            o4._flat_grad.fill_(123.0)                                     # stale content: every slice must be overwritten
+            o4.step_explicit(write)
+        assert o4._check_synced()
+        for a_, b_ in zip(res_ov[0], [p.detach().numpy() for p in m4.parameters()]):
+            assert abs(a_ - b_).max() < 1e-6
     # per-epoch cadence: local steps diverge, end_epoch() averages parameters and momentum buffers
     torch.manual_seed(200 + rank)
     m2 = torch.nn.Linear(4, 2)
