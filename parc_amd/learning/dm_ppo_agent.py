@@ -77,7 +77,6 @@ class DMPPOAgent(torch.nn.Module):
         self._curr_info = None
         self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self._device)
         self._ppo_cfg = None
-        self._prefetch_stream = None
         if str(self._device).startswith("cuda") and config.get("tuned_gemms", True):
             enable_tuned_gemms()
         # hipGraph rollout: the fixed-shape part of one env step (policy forward, record, simulator, post-step kernel,
@@ -611,32 +610,10 @@ class DMPPOAgent(torch.nn.Module):
                 if w != 0:
                     slots[name] = i
             keys = ["norm_obs", "loss_rec"] if self._exp_buffer.has_buffer("loss_rec") else _LOSS_KEYS
-            # The gathers of minibatch k + 1 depend on nothing minibatch k computes (the buffers are fixed for the whole update phase,
-            # the permutation is drawn ahead), so they are issued on a side stream while minibatch k's GEMMs run: two memory-bound
-            # launches (38 us) leave the critical path.  Same samples in the same order as sampling inside the loop.
-            main = torch.cuda.current_stream()
-            side = self._prefetch_stream
-            if side is None:
-                side = self._prefetch_stream = torch.cuda.Stream()
-            side.wait_stream(main)
-
-            def fetch():
-                with torch.cuda.stream(side):
-                    b = self._exp_buffer.sample(batch_size, keys=keys)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                for t in b.values():
-                    t.record_stream(main)                # consumed on the main stream: keep the allocator from recycling it early
-                return b, ev
-            total = self._update_epochs * num_batches
-            nxt = fetch()
-            for k in range(total):
-                batch, ev = nxt
-                nxt = fetch() if k + 1 < total else None
-                main.wait_event(ev)
-                self._minibatch_step_explicit(batch, acc)
-                if (k + 1) % num_batches == 0:
-                    self._optimizer.end_epoch()
+            for _ in range(self._update_epochs):
+                for _ in range(num_batches):
+                    self._minibatch_step_explicit(self._exp_buffer.sample(batch_size, keys=keys), acc)
+                self._optimizer.end_epoch()
             packed = acc["_packed"] / (self._update_epochs * num_batches)
             self._nan_flag |= torch.isnan(packed[0:3]).any().to(torch.int32)
             return {k: packed[i] for k, i in slots.items()}
