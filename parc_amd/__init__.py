@@ -28,9 +28,10 @@ _ALIASES = {
     "learning.dm_ppo_model": "learning.dm_ppo_model", "learning.dm_ppo_return_tracker": "learning.dm_ppo_return_tracker",
     "learning.tracking_error_tracker": "learning.tracking_error_tracker",
     "PARC.util.create_dataset": "util.create_dataset",
+    "tools.motion_opt.motion_optimization": "tools.motion_opt.motion_optimization",
 }
 # pure namespace packages of the reference that hold nothing this path needs besides the sub-module above
-_NAMESPACES = ("PARC", "PARC.util")
+_NAMESPACES = ("PARC", "PARC.util", "tools", "tools.motion_opt")
 
 
 def install_reference_aliases(strict=True):

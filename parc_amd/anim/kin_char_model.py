@@ -346,7 +346,8 @@ class KinCharModel:
             dev = self._device
             self._tt = {"hinge": (kind == 1).nonzero().flatten().to(dev), "sph": (kind == 3).nonzero().flatten().to(dev),
                         "first": first.to(dev), "axis": axis.to(dev),
-                        "levels": [(torch.tensor(l, device=dev), torch.tensor([par[b] for b in l], device=dev)) for l in levels]}
+                        # per tree level: body indices (tensor and list) and their parents' indices
+                        "levels": [(torch.tensor(l, device=dev), list(l), torch.tensor([par[b] for b in l], device=dev)) for l in levels]}
         return self._tt
 
     def dof_to_rot_torch(self, dof):
@@ -390,19 +391,15 @@ class KinCharModel:
         t = self._torch_tables()
         B = self.get_num_joints()
         lead = root_pos.shape[:-1]
-        local = torch_util.quat_mul(self._local_rotation[1:].expand(lead + (B - 1, 4)), joint_rot)       # local_rot * joint_rot
-        pos = [None] * B
-        rot = [None] * B
-        pos[0], rot[0] = root_pos, root_rot
-        for bodies, parents in t["levels"]:
-            ppos = torch.stack([pos[p] for p in parents.tolist()], dim=-2)
-            prot = torch.stack([rot[p] for p in parents.tolist()], dim=-2)
+        local = torch_util.quat_mul_compact(self._local_rotation[1:].expand(lead + (B - 1, 4)), joint_rot)       # local_rot * joint_rot
+        pos = root_pos.unsqueeze(-2).expand(lead + (B, 3))
+        rot = root_rot.unsqueeze(-2).expand(lead + (B, 4))
+        for bodies, _, parents in t["levels"]:
+            ppos, prot = pos[..., parents, :], rot[..., parents, :]
             lt = self._local_translation[bodies].expand(ppos.shape)
-            npos = ppos + torch_util.quat_rotate(prot, lt)
-            nrot = torch_util.quat_mul(prot, local[..., bodies - 1, :])
-            for k, b in enumerate(bodies.tolist()):
-                pos[b], rot[b] = npos[..., k, :], nrot[..., k, :]
-        return torch.stack(pos, dim=-2), torch.stack(rot, dim=-2)
+            pos = pos.index_copy(-2, bodies, ppos + torch_util.quat_rotate(prot, lt))
+            rot = rot.index_copy(-2, bodies, torch_util.quat_mul_compact(prot, local[..., bodies - 1, :]))
+        return pos, rot
 
     def apply_joint_dof_limits(self, joint_dofs):
         return torch.minimum(torch.maximum(joint_dofs, self._lower_dof_limits), self._upper_dof_limits)

@@ -5,67 +5,74 @@
 // geom_util.sdBox / sdRoundBox  util/geom_util.py:113-143): every heightfield cell (i, j) is a box with centre
 // (x_i + cx, y_j + cy) and half extents (dx/2, dy/2); vertically it spans [base_z, hf] - or, "inverted", the AIR column
 // [hf, -base_z] above the cell, so that after the final sign flip a point inside the ground gets its (negative) depth to the
-// nearest free surface.  The reference materialises [B, N, M, 3] tensors and takes the min over M; here a workgroup keeps a
-// tile of cells (centre + vertical half extent, 16 B each) in LDS, every thread owns one point and walks the tile with
-// broadcast LDS reads: no temporaries, one pass over the cells per 256 points.
+// nearest free surface.  The reference materialises [B, N, M, 3] tensors and takes the min over M; here every thread owns one point
+// and scans only the window of columns that can hold the minimum (see the kernel): no temporaries, exact result.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/parc_hip.h"
 
-#define SDF_THREADS 256
-#define SDF_TILE 2048        // cells per LDS tile (32 KB)
+#define SDF_THREADS 64
 
+// sdBox of one column: q = |p - centre| - half extents; |max(q, 0)| + min(max(q.x, q.y, q.z), 0), same fp32 operations as the
+// reference (:1862-1871)
+__device__ __forceinline__ float column_sd(float px, float py, float pz, float cx, float cy, float h, float half_x, float half_y, float base_z,
+                                           float top_z, int inverted) {
+    const float cz = inverted ? (h + top_z) / 2.0f : (h + base_z) / 2.0f;
+    const float hz = inverted ? (top_z - h) / 2.0f : (h - base_z) / 2.0f;
+    const float qx = fabsf(px - cx) - half_x, qy = fabsf(py - cy) - half_y, qz = fabsf(pz - cz) - hz;
+    const float ax = fmaxf(qx, 0.f), ay = fmaxf(qy, 0.f), az = fmaxf(qz, 0.f);
+    return __fsqrt_rn(ax * ax + ay * ay + az * az) + fminf(fmaxf(qx, fmaxf(qy, qz)), 0.f);
+}
+
+// One thread per point.  The minimum over ALL columns is found exactly without visiting all of them: the distance d0 to the column under
+// the point bounds the answer, and a column more than R = floor(d0 / cell) + 2 cells away in x or in y is further than d0 in that
+// coordinate alone (columns do not overlap in xy), so only the (2R+1)^2 window is scanned - in the same cell order as a full scan, so
+// "first column that attains the minimum" is the same column.  Heights come straight from L2 (a heightfield is a few hundred KB).
 __global__ __launch_bounds__(SDF_THREADS) void points_hf_sdf_kernel(int n_points, int dim_x, int dim_y, const float *__restrict__ points,
                                                                     const float *__restrict__ hf, const float *__restrict__ min_box_center,
                                                                     const float *__restrict__ x_points, const float *__restrict__ y_points,
                                                                     float half_x, float half_y, float base_z, int inverted, float radius,
                                                                     float *__restrict__ out, int32_t *__restrict__ out_cell) {
-    __shared__ float4 cells[SDF_TILE];
     const int bi = blockIdx.y;
     const int p = blockIdx.x * SDF_THREADS + threadIdx.x;
-    const int pc = min(p, n_points - 1);                       // tail threads recompute the last point, they only skip the store
-    const float *pt = points + ((size_t)bi * n_points + pc) * 3;
+    if (p >= n_points) return;
+    const float *pt = points + ((size_t)bi * n_points + p) * 3;
     const float px = pt[0], py = pt[1], pz = pt[2];
-    const int M = dim_x * dim_y;
-    const float *hfb = hf + (size_t)bi * M;
+    const float *hfb = hf + (size_t)bi * dim_x * dim_y;
     const float ox = min_box_center[2 * bi], oy = min_box_center[2 * bi + 1];
     const float top_z = -base_z;
+    const float cell_x = 2.0f * half_x, cell_y = 2.0f * half_y;
+    // NaN / inf coordinates: the comparisons below are all false for NaN, so the window degenerates to the whole field
+    const float fi = rintf((px - ox) / cell_x), fj = rintf((py - oy) / cell_y);
+    const int i0 = (int)fminf(fmaxf(fi, 0.f), (float)(dim_x - 1)), j0 = (int)fminf(fmaxf(fj, 0.f), (float)(dim_y - 1));
+    const float d0 = column_sd(px, py, pz, x_points[i0] + ox, y_points[j0] + oy, hfb[i0 * dim_y + j0], half_x, half_y, base_z, top_z, inverted);
+    int i_lo = 0, i_hi = dim_x - 1, j_lo = 0, j_hi = dim_y - 1;
+    if (d0 < 3.0e8f) {              // also false for NaN
+        const float bound = fmaxf(d0, 0.f);
+        const int rx = (int)(bound / cell_x) + 2, ry = (int)(bound / cell_y) + 2;
+        i_lo = max(i0 - rx, 0);
+        i_hi = min(i0 + rx, dim_x - 1);
+        j_lo = max(j0 - ry, 0);
+        j_hi = min(j0 + ry, dim_y - 1);
+    }
     float best = INFINITY;
     int best_cell = 0;
-    for (int t0 = 0; t0 < M; t0 += SDF_TILE) {
-        const int cnt = min(SDF_TILE, M - t0);
-        for (int c = threadIdx.x; c < cnt; c += SDF_THREADS) {
-            const int cell = t0 + c, i = cell / dim_y, j = cell - i * dim_y;
-            const float h = hfb[cell];
-            // box centre / vertical half extent, same fp32 operations as the reference (:1862-1871)
-            const float cz = inverted ? (h + top_z) / 2.0f : (h + base_z) / 2.0f;
-            const float hz = inverted ? (top_z - h) / 2.0f : (h - base_z) / 2.0f;
-            cells[c] = make_float4(x_points[i] + ox, y_points[j] + oy, cz, hz);
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int c = 0; c < cnt; ++c) {
-            const float4 cl = cells[c];
-            // sdBox: q = |p - centre| - half extents; |max(q, 0)| + min(max(q.x, q.y, q.z), 0)
-            const float qx = fabsf(px - cl.x) - half_x, qy = fabsf(py - cl.y) - half_y, qz = fabsf(pz - cl.z) - cl.w;
-            const float ax = fmaxf(qx, 0.f), ay = fmaxf(qy, 0.f), az = fmaxf(qz, 0.f);
-            const float outside = __fsqrt_rn(ax * ax + ay * ay + az * az);
-            const float inside = fminf(fmaxf(qx, fmaxf(qy, qz)), 0.f);
-            const float sd = outside + inside;
+    for (int i = i_lo; i <= i_hi; ++i) {
+        const float cx = x_points[i] + ox;
+        const float *row = hfb + (size_t)i * dim_y;
+        for (int j = j_lo; j <= j_hi; ++j) {
+            const float sd = column_sd(px, py, pz, cx, y_points[j] + oy, row[j], half_x, half_y, base_z, top_z, inverted);
             if (sd < best) {             // first column that attains the minimum
                 best = sd;
-                best_cell = t0 + c;
+                best_cell = i * dim_y + j;
             }
         }
-        __syncthreads();
     }
     if (radius > 0.f) best -= radius;           // sdRoundBox: x - r is monotone, so it commutes with the min
     if (inverted) best = -best;
-    if (p < n_points) {
-        out[(size_t)bi * n_points + p] = best;
-        if (out_cell) out_cell[(size_t)bi * n_points + p] = best_cell;
-    }
+    out[(size_t)bi * n_points + p] = best;
+    if (out_cell) out_cell[(size_t)bi * n_points + p] = best_cell;
 }
 
 extern "C" int parc_points_hf_sdf(void *stream, int batch, int n_points, int dim_x, int dim_y, const float *points, const float *hf,

@@ -136,3 +136,8 @@ def get_char_point_samples(char_model, sphere_num_subdivisions=0, box_num_slices
             body.append(torch.zeros((1, 3), dtype=torch.float32, device=device))
         out.append(torch.cat(body, dim=0).to(target_device))
     return out
+
+
+def sdSphere(p, c, r):
+    """signed distance of points p to the sphere of centre c and radius r (reference util/geom_util.py:167-171)"""
+    return torch.linalg.vector_norm(p - c, dim=-1) - r

@@ -123,14 +123,37 @@ sys.modules.setdefault("util", sys.modules[__name__.rpartition(".")[0]])
 sys.modules.setdefault(REFERENCE_MODULE, sys.modules[__name__])
 
 
+# other modules whose classes are written into motion files under a reference path: reference module name -> module
+# (tools.motion_opt.motion_optimization registers BodyConstraint here)
+_REFERENCE_PICKLE_MODULES = {}
+
+
+def register_reference_pickle_module(reference_name, module):
+    _REFERENCE_PICKLE_MODULES[reference_name] = module
+
+
 @contextlib.contextmanager
 def reference_pickle_path():
     """Inside this context ``pickle.dump`` of a SubTerrain always succeeds and writes ``util.terrain_util SubTerrain``,
     even in a process where another ``util.terrain_util`` (e.g. the reference's own) is already imported."""
-    prev = {k: sys.modules.get(k) for k in ("util", REFERENCE_MODULE)}
+    names = ["util", REFERENCE_MODULE]
+    for ref_name in _REFERENCE_PICKLE_MODULES:
+        parts = ref_name.split(".")
+        names += [".".join(parts[:k]) for k in range(1, len(parts) + 1)]
+    prev = {k: sys.modules.get(k) for k in names}
     sys.modules[REFERENCE_MODULE] = sys.modules[__name__]
     if prev["util"] is None:
         sys.modules["util"] = sys.modules[__name__.rpartition(".")[0]]
+    for ref_name, mod in _REFERENCE_PICKLE_MODULES.items():
+        parts = ref_name.split(".")
+        for k in range(1, len(parts)):
+            pkg = ".".join(parts[:k])
+            if sys.modules.get(pkg) is None:
+                import types
+                ns = types.ModuleType(pkg)
+                ns.__path__ = []
+                sys.modules[pkg] = ns
+        sys.modules[ref_name] = mod
     try:
         yield
     finally:
@@ -258,24 +281,41 @@ from .terrain_procgen import (add_boxes_to_hf2, add_stairs_to_hf, draw_box, gen_
 # forward_kinematics); `points_hf_sdf` / `motion_frames_hf_sdf_loss` are differentiable (kernel for the arg-min column, torch ops for the selected
 # branch and for the pose), the preprocessing functions are forward-only.
 # ---------------------------------------------------------------------------------------------------------------------
-def points_hf_sdf(points, hf, hf_min_box_center, hf_dxdy, base_z=-10.0, inverted=True, radius=None):
+class HfGrid:
+    """What points_hf_sdf derives from a heightfield batch before it can launch: cell-centre coordinates relative to cell (0, 0) (torch's
+    own linspace, evaluated on the host: X + Y values) and the half cell size.  Callers that query the same heightfields many times
+    (the motion optimiser: thousands of iterations, captured in a hipGraph) prepare it once and pass it as ``grid=``."""
+
+    def __init__(self, hf, hf_dxdy, device=None):
+        X, Y = int(hf.shape[-2]), int(hf.shape[-1])
+        dev = hf.device if device is None else device
+        dxdy = hf_dxdy.detach().to(torch.float32).cpu()
+        self.xs = torch.linspace(0.0, (X - 1.0) * dxdy[0].item(), X).to(dev)
+        self.ys = torch.linspace(0.0, (Y - 1.0) * dxdy[1].item(), Y).to(dev)
+        half = dxdy / 2.0
+        self.half = (float(half[0]), float(half[1]))
+        self.shape = (X, Y)
+
+
+def points_hf_sdf(points, hf, hf_min_box_center, hf_dxdy, base_z=-10.0, inverted=True, radius=None, grid=None):
     """Signed distance of points [B, N, 3] to heightfields hf [B, X, Y] made of dx x dy columns whose cell (0, 0) is centred at
     hf_min_box_center [B, 2]; inverted (default) = negative depth below the surface for points in the ground.
     Reference: util/terrain_util.py:1835-1893.  One launch, no [B, N, X*Y, 3] temporaries.
 
     Differentiable in ``points``: the kernel also reports WHICH column attains the minimum; when ``points`` requires grad the distance
     to that one column is re-evaluated with torch ops (N box distances instead of N * X * Y), so autograd sees exactly the branch
-    torch.min would have routed the gradient through."""
+    torch.min would have routed the gradient through.  With ``grid=HfGrid(...)`` the call reads nothing back from the device."""
     from .. import _hip
-    assert points.dim() == 3 and hf.dim() == 3 and hf_min_box_center.dim() == 2 and hf_dxdy.dim() == 1
+    assert points.dim() == 3 and hf.dim() == 3 and hf_min_box_center.dim() == 2
     B, N = int(points.shape[0]), int(points.shape[1])
     assert hf.shape[0] == B and hf_min_box_center.shape[0] == B
     X, Y = int(hf.shape[1]), int(hf.shape[2])
     dev = points.device
-    # cell-centre coordinates relative to cell (0, 0): torch's own linspace, evaluated on the host (X + Y values)
-    xs = torch.linspace(0.0, (X - 1.0) * hf_dxdy[0].item(), X).to(dev)
-    ys = torch.linspace(0.0, (Y - 1.0) * hf_dxdy[1].item(), Y).to(dev)
-    half = (hf_dxdy.detach().to(torch.float32) / 2.0).cpu()
+    if grid is None:
+        assert hf_dxdy.dim() == 1
+        grid = HfGrid(hf, hf_dxdy, dev)
+    assert grid.shape == (X, Y)
+    xs, ys, half = grid.xs, grid.ys, grid.half
     if radius is not None:
         assert isinstance(radius, float) and radius > 0.0
     want_grad = torch.is_grad_enabled() and (points.requires_grad or hf.requires_grad)

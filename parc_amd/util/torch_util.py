@@ -25,7 +25,7 @@ def quat_unit(a):
 
 
 def quat_conjugate(q):
-    return q * q.new_tensor([-1.0, -1.0, -1.0, 1.0])
+    return torch.cat([-q[..., :3], q[..., 3:]], dim=-1)
 
 
 quat_inv = quat_conjugate
@@ -53,6 +53,16 @@ def quat_mul(a, b):
 
 
 quat_multiply = quat_mul
+
+
+def quat_mul_compact(a, b):
+    """a * b in vector form (w = aw bw - av.bv, v = aw bv + bw av + av x bv): the same product in 10 launches instead of 29 and with
+    a matching short backward, for differentiable batch code that evaluates it thousands of times (the motion optimiser)."""
+    av, aw = a[..., :3], a[..., 3:4]
+    bv, bw = b[..., :3], b[..., 3:4]
+    w = aw * bw - (av * bv).sum(dim=-1, keepdim=True)
+    v = aw * bv + bw * av + torch.cross(av.expand_as(bv) if av.shape != bv.shape else av, bv, dim=-1)
+    return torch.cat([v, w], dim=-1)
 
 
 def quat_rotate(q, v):

@@ -1031,7 +1031,108 @@ def gen_recorded_files():
 
 
 STAGES = ["core", "voxel-mesh", "dataset-yaml", "procgen", "terrain-geometry", "done-branches", "ppo-loss", "normalizer", "trackers",
-          "action-head", "recorded-files"]
+          "action-head", "recorded-files", "motion-opt"]
+
+
+def _icosa_points(radius):
+    """12 icosahedron vertices scaled to `radius`: the generator's own sample points for sphere geoms (trimesh, which the reference
+    would ask for them, is absent); the loss functions take the point lists as an argument, so these are inputs of the fixture."""
+    g = (1.0 + 5.0 ** 0.5) / 2.0
+    v = np.array([[-1, g, 0], [1, g, 0], [-1, -g, 0], [1, -g, 0], [0, -1, g], [0, 1, g], [0, -1, -g], [0, 1, -g], [g, 0, -1], [g, 0, 1],
+                  [-g, 0, -1], [-g, 0, 1]], dtype=np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return (v * radius).astype(np.float32)
+
+
+def gen_motion_opt():
+    """G20: stage 2's motion optimiser (tools/motion_opt/motion_optimization.py): compute_approx_body_constraints (:34-181),
+    motion_terrain_contact_loss (:183-395: the nine terms, the total, and its autograd gradient with respect to the three optimised
+    tensors) and motion_contact_optimization (:404-500: 40 Adam iterations, loss per iteration and final frames), on 40 frames of
+    the civilization clip over the slice of its terrain around them.  The sample points are an input: capsule / box points from the
+    reference's geom_util, sphere geoms from _icosa_points above (get_char_point_samples would need trimesh for them)."""
+    import tools.motion_opt.motion_optimization as mo
+    rng = np.random.default_rng(20)
+    torch.manual_seed(20)
+    km = load_char()
+    # body sample points: reference sampler on a model copy without spheres, own points for the sphere geoms
+    km_ns = load_char()
+    sph = {}
+    for b in range(km_ns.get_num_joints()):
+        for g in km_ns._geoms[b]:
+            if g._shape_type == kin_char_model.GeomType.SPHERE:
+                sph.setdefault(b, []).append(t(_icosa_points(float(g._dims))) + g._offset.reshape(1, 3))
+        km_ns._geoms[b] = [g for g in km_ns._geoms[b] if g._shape_type != kin_char_model.GeomType.SPHERE]
+    pts = geom_util.get_char_point_samples(km_ns)
+    pts = [torch.cat([p.reshape(-1, 3)] + sph.get(b, []), dim=0) for b, p in enumerate(pts)]
+    assert all(p.shape[0] > 0 for p in pts)
+    civ = load_motion_file_safe(os.path.join(REF, "data/terrains/civilization.pkl"))
+    frames = np.asarray(civ["frames"], np.float32)[150:190].copy()
+    contacts = np.asarray(civ["contacts"], np.float32)[150:190].copy()
+    lh = km.get_body_id("left_hand")
+    contacts[8:15, lh] = 1.0                        # a hand contact so that the sphere-constraint branch runs
+    contacts[30, lh] = 1.0                          # ... and a one-frame group
+    ter_full = ref_terrain_from_dict(civ["terrain"])
+    ter, src = terrain_util.slice_terrain_around_motion(t(frames), ter_full, padding=0.8)
+    src = src.clone()
+    src[:, 2] -= 0.04                               # slightly into the ground: penetration term active
+    con = t(contacts)
+    out = dict(pts_count=np.array([p.shape[0] for p in pts]), pts=torch.cat(pts, dim=0), src_frames=src, contacts=con, hf=ter.hf,
+               min_point=ter.min_point, dxdy=ter.dxdy)
+    # body constraints (the reference calls its point sampler there and drops the result: bypass that one call)
+    keep = geom_util.get_char_point_samples
+    geom_util.get_char_point_samples = lambda *a, **k: []
+    try:
+        bc = mo.compute_approx_body_constraints(src[:, 0:3], torch_util.exp_map_to_quat(src[:, 3:6]), km.dof_to_rot(src[:, 6:]), con, km, ter)
+    finally:
+        geom_util.get_char_point_samples = keep
+    rows = [[b, c.start_frame_idx, c.end_frame_idx] + c.constraint_point.tolist() for b, lst in enumerate(bc) for c in lst]
+    out["body_constraints"] = np.array(rows, dtype=np.float64)
+    print("body constraints:", len(rows))
+    w = dict(w_root_pos=1.0, w_root_rot=10.0, w_joint_rot=1.0, w_smoothness=10.0, w_penetration=1000.0, w_contact=1000.0, w_sliding=10.0,
+             w_body_constraints=1000.0, w_jerk=1000.0)
+    max_jerk = 1000.0
+    out["weights"] = np.array([w[k] for k in ("w_root_pos", "w_root_rot", "w_joint_rot", "w_smoothness", "w_penetration", "w_contact", "w_sliding",
+                                              "w_body_constraints", "w_jerk")] + [max_jerk])
+    # the source-side quantities exactly as motion_contact_optimization derives them (:428-436)
+    s_rp, s_rq = src[:, 0:3], torch_util.exp_map_to_quat(src[:, 3:6])
+    s_jr = km.dof_to_rot(src[:, 6:34])
+    s_bp, s_br = km.forward_kinematics(s_rp, s_rq, s_jr)
+    s_bv = s_bp[1:] - s_bp[:-1]
+    s_brv = torch_util.quat_diff_angle(s_br[1:], s_br[:-1])
+    tgt = src + t(rng.normal(0.0, 0.02, size=src.shape))          # a perturbed target: every term non-zero
+    out["tgt_frames"] = tgt
+
+    def evaluate(tag, body_constraints, **override):
+        ww = dict(w)
+        ww.update(override)
+        a, b_, c = tgt[:, 0:3].clone().requires_grad_(True), tgt[:, 3:6].clone().requires_grad_(True), tgt[:, 6:].clone().requires_grad_(True)
+        loss, ld = mo.motion_terrain_contact_loss(a, b_, c, s_rp, s_rq, s_jr, s_bv, s_brv, con, ter, pts, km, body_constraints=body_constraints,
+                                                  max_jerk=max_jerk, **ww)
+        loss.backward()
+        out[tag + "_loss"] = loss.detach()
+        out[tag + "_terms"] = np.array([float(ld[k]) for k in mo.LossType if k in ld], dtype=np.float64)
+        out[tag + "_term_ids"] = np.array([k.value for k in mo.LossType if k in ld])
+        out[tag + "_grad"] = torch.cat([a.grad, b_.grad, c.grad], dim=-1)
+    evaluate("full", bc)
+    evaluate("nocon", None, w_contact=0.0, w_sliding=0.0)
+    # 40 iterations of the optimiser itself; the loss of every iteration is recorded through a wrapper around the loss function
+    trace = []
+    inner = mo.motion_terrain_contact_loss
+
+    def recording(**kw):
+        loss, ld = inner(**kw)
+        trace.append(loss.item())
+        return loss, ld
+    mo.motion_terrain_contact_loss = recording
+    sys.modules["wandb"].run = None                 # the logger asks the (stubbed, never connected) wandb module for its active run
+    try:
+        opt = mo.motion_contact_optimization(src_frames=src, contacts=con, body_points=pts, terrain=ter, char_model=km, num_iters=40, step_size=0.001,
+                                             body_constraints=bc, max_jerk=max_jerk, exp_name="g20", use_wandb=False, log_file=None, **w)
+    finally:
+        mo.motion_terrain_contact_loss = inner
+    out["opt_frames"] = opt
+    out["opt_loss_trace"] = np.array(trace, dtype=np.float64)
+    save("g20_motion_opt", **out)
 
 
 def gen_core():
@@ -1054,7 +1155,8 @@ def main():
     """No flag: every stage, in order (reproduces all committed fixtures).  --only-<stage>: that stage alone."""
     run = {"core": gen_core, "voxel-mesh": lambda: gen_voxel_mesh(np.random.default_rng(10)), "dataset-yaml": gen_dataset_yaml,
            "procgen": gen_procgen, "terrain-geometry": gen_terrain_geometry, "done-branches": gen_done_branches, "ppo-loss": gen_ppo_loss,
-           "normalizer": gen_normalizer, "trackers": gen_trackers, "action-head": gen_action_head, "recorded-files": gen_recorded_files}
+           "normalizer": gen_normalizer, "trackers": gen_trackers, "action-head": gen_action_head, "recorded-files": gen_recorded_files,
+           "motion-opt": gen_motion_opt}
     picked = [s_ for s_ in STAGES if "--only-" + s_ in sys.argv]
     if "--check" in sys.argv:
         # regenerate everything into a scratch directory and compare with the committed fixtures array by array

@@ -576,3 +576,31 @@ def test_g19_reference_read_our_recorded_files():
     assert e._terrains_per_motion == int(z["cache_terrains_per_motion"]) and len(verts) == int(z["cache_num_vert_lists"])
     np.testing.assert_array_equal(np.asarray(verts[0][0]), z["cache_verts_0"])
     np.testing.assert_array_equal(np.asarray(tris[0][0]), z["cache_tris_0"])
+
+
+def test_optimiser_output_file_is_reference_readable():
+    """What tools/motion_opt/optimize_motions.py:182-193 writes - a motion dict whose "opt:body_constraints" holds BodyConstraint
+    objects - names only the reference's module paths, and the run-splitting rule of the constraint builder (a trailing one-frame
+    run is dropped, extract_consecutive_trues :43-73) is the reference's."""
+    import pickle
+    import tempfile
+    import parc_amd
+    from parc_amd.tools.motion_opt import motion_optimization as mo
+    from parc_amd.util import terrain_util
+    runs = mo._consecutive_true_runs(torch.tensor([0, 1, 1, 0, 1, 0, 0, 1, 1, 1, 0, 1], dtype=torch.bool))
+    assert [r.tolist() for r in runs] == [[1, 2], [4], [7, 8, 9]]
+    assert mo._consecutive_true_runs(torch.tensor([0, 0, 1, 0], dtype=torch.bool)) == []          # the reference's rule, as is
+    assert [r.tolist() for r in mo._consecutive_true_runs(torch.tensor([1, 1, 1], dtype=torch.bool))] == [[0, 1, 2]]
+    ter = terrain_util.SubTerrain.from_arrays(np.zeros((4, 5), np.float32), np.zeros(2, np.float32), np.array([0.4, 0.4], np.float32), device="cpu")
+    c = mo.BodyConstraint()
+    c.start_frame_idx, c.end_frame_idx, c.constraint_point = 3, 9, torch.tensor([0.1, 0.2, 0.3])
+    data = {"fps": 30, "loop_mode": "CLAMP", "frames": torch.zeros((12, 34)), "contacts": torch.zeros((12, 15)), "terrain": ter,
+            "opt:body_constraints": [[c], []]}
+    path = os.path.join(tempfile.mkdtemp(prefix="parc_opt_"), "clip_opt.pkl")
+    terrain_util.dump_reference_pickle(data, path)
+    mods = {m for m, _ in pickle_globals(path)}
+    assert ("tools.motion_opt.motion_optimization", "BodyConstraint") in pickle_globals(path)
+    assert not any(m.startswith("parc_amd") for m in mods), mods
+    parc_amd.install_reference_aliases()
+    back = pickle.load(open(path, "rb"))                               # a file of our own
+    assert back["opt:body_constraints"][0][0].end_frame_idx == 9

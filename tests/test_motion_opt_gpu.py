@@ -1,0 +1,120 @@
+"""Stage 2's motion optimiser against fixture G20, which the REFERENCE's tools/motion_opt/motion_optimization.py
+produced on CPU (tests/golden/gen_golden.py stage motion-opt): body constraints from contact labels (:34-181), the nine loss terms +
+total + autograd gradient (:183-395) and a 40-iteration Adam descent (:404-500)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from test_hip_parity import DEV, T, close, km  # noqa: F401  (km is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+W_NAMES = ("w_root_pos", "w_root_rot", "w_joint_rot", "w_smoothness", "w_penetration", "w_contact", "w_sliding", "w_body_constraints", "w_jerk")
+
+
+def _problem(g):
+    from parc_amd.util import terrain_util
+    counts = g["pts_count"].tolist()
+    pts, s = [], 0
+    for n in counts:
+        pts.append(T(g["pts"][s:s + n]))
+        s += n
+    ter = terrain_util.SubTerrain.from_arrays(g["hf"], g["min_point"], g["dxdy"], device=DEV)
+    w = dict(zip(W_NAMES, [float(v) for v in g["weights"][:9]]))
+    return pts, ter, w, float(g["weights"][9])
+
+
+def _constraints_from_rows(mo, rows, num_bodies):
+    out = [[] for _ in range(num_bodies)]
+    for r in rows:
+        c = mo.BodyConstraint()
+        c.start_frame_idx, c.end_frame_idx = int(r[1]), int(r[2])
+        c.constraint_point = T(r[3:6].astype(np.float32))
+        out[int(r[0])].append(c)
+    return out
+
+
+def _source_terms(km, src):
+    from parc_amd.util import torch_util
+    rp, rq = src[:, 0:3].contiguous(), torch_util.exp_map_to_quat(src[:, 3:6])
+    jr = km.dof_to_rot(src[:, 6:].contiguous())
+    bp, br = km.forward_kinematics(rp, rq, jr)
+    return rp, rq, jr, bp[1:] - bp[:-1], torch_util.quat_diff_angle(br[1:], br[:-1])
+
+
+def test_g20_body_constraints_from_contact_labels(km):
+    from parc_amd.tools.motion_opt import motion_optimization as mo
+    from parc_amd.util import torch_util
+    g = golden("g20_motion_opt")
+    pts, ter, w, max_jerk = _problem(g)
+    src, con = T(g["src_frames"]), T(g["contacts"])
+    bc = mo.compute_approx_body_constraints(src[:, 0:3].contiguous(), torch_util.exp_map_to_quat(src[:, 3:6]), km.dof_to_rot(src[:, 6:].contiguous()),
+                                            con, km, ter)
+    rows = np.array([[b, c.start_frame_idx, c.end_frame_idx] + c.constraint_point.tolist() for b, lst in enumerate(bc) for c in lst])
+    ref = g["body_constraints"]
+    assert rows.shape == ref.shape and len(ref) >= 4
+    assert np.array_equal(rows[:, 0:3], ref[:, 0:3])                 # bodies and frame ranges: exact (incl. the dropped one-frame run)
+    # the points are the end of a 1000-step descent onto the column surfaces
+    assert np.abs(rows[:, 3:6] - ref[:, 3:6]).max() < 2e-4, np.abs(rows[:, 3:6] - ref[:, 3:6]).max()
+    assert {int(r[0]) for r in ref} >= {km.get_body_id("left_foot"), km.get_body_id("left_hand")}
+
+
+@pytest.mark.parametrize("case", ["full", "nocon"])
+def test_g20_loss_terms_and_gradient(km, case):
+    from parc_amd.tools.motion_opt import motion_optimization as mo
+    g = golden("g20_motion_opt")
+    pts, ter, w, max_jerk = _problem(g)
+    src, con, tgt = T(g["src_frames"]), T(g["contacts"]), T(g["tgt_frames"])
+    bc = _constraints_from_rows(mo, g["body_constraints"], km.get_num_joints()) if case == "full" else None
+    if case == "nocon":
+        w = dict(w, w_contact=0.0, w_sliding=0.0)
+    a, b, c = (tgt[:, 0:3].clone().requires_grad_(True), tgt[:, 3:6].clone().requires_grad_(True), tgt[:, 6:].clone().requires_grad_(True))
+    loss, ld = mo.motion_terrain_contact_loss(a, b, c, *_source_terms(km, src), con, ter, pts, km, body_constraints=bc, max_jerk=max_jerk, **w)
+    loss.backward()
+    ref_terms = dict(zip([mo.LossType(int(i)) for i in g[case + "_term_ids"]], g[case + "_terms"]))
+    for k, r in ref_terms.items():
+        assert abs(ld[k] - r) <= 2e-4 * max(abs(r), 1e-2), (k, ld[k], r)
+    if case == "full":
+        assert all(ref_terms[k] > 0 for k in ref_terms), ref_terms       # every term is exercised
+    ref_loss = float(g[case + "_loss"])
+    assert abs(loss.item() - ref_loss) <= 2e-4 * abs(ref_loss), (loss.item(), ref_loss)
+    got = torch.cat([a.grad, b.grad, c.grad], dim=-1).cpu().numpy()
+    ref = g[case + "_grad"]
+    # penalty terms are sums of |.| and clamps: a sample point within rounding of a kink (or of two columns) may take the other branch,
+    # which moves single entries by one point's weight; the bulk must agree
+    scale = np.abs(ref).max()
+    err = np.abs(got - ref)
+    assert np.median(err) < 1e-4 * scale, (np.median(err), scale)
+    assert (err > 2e-3 * scale).mean() < 0.01, ((err > 2e-3 * scale).mean(), err.max(), scale)
+    cos = float((got * ref).sum() / np.sqrt((got ** 2).sum() * (ref ** 2).sum()))
+    assert cos > 0.9995, cos
+
+
+def test_g20_descent_follows_the_reference(km):
+    """40 Adam iterations: the loss of every iteration against the reference's run, eagerly and as a replayed hipGraph.  Adam's first
+    steps move every entry by the step size whatever the size of its gradient, so entries whose gradient is rounding noise end up
+    anywhere within +-40 steps: the loss curve is the meaningful comparison, the frames are compared in the bulk."""
+    from parc_amd.tools.motion_opt import motion_optimization as mo
+    g = golden("g20_motion_opt")
+    pts, ter, w, max_jerk = _problem(g)
+    bc = _constraints_from_rows(mo, g["body_constraints"], km.get_num_joints())
+    ref = g["opt_loss_trace"]
+    assert ref[-1] < 0.5 * ref[0]                                    # the descent does reduce the loss
+    moved = np.abs(g["opt_frames"] - g["src_frames"]).max()
+    assert moved > 0.01
+    traces = {}
+    for use_graph in (False, True):
+        trace = []
+        out = mo.motion_contact_optimization(src_frames=T(g["src_frames"]), contacts=T(g["contacts"]), body_points=pts, terrain=ter, char_model=km,
+                                             num_iters=40, step_size=0.001, body_constraints=bc, max_jerk=max_jerk, exp_name="g20", use_wandb=False,
+                                             log_file=None, use_graph=use_graph, verbose=False, loss_trace=trace, **w)
+        got = trace[0].cpu().numpy()
+        assert got.shape == ref.shape == (40,)
+        rel = np.abs(got - ref) / ref
+        assert rel[0] < 2e-4 and rel.max() < 2e-2, (use_graph, rel[0], rel.max())
+        d = np.abs(out.cpu().numpy() - g["opt_frames"])
+        assert np.median(d) < 0.05 * moved and np.quantile(d, 0.9) < 0.25 * moved, (use_graph, moved, np.median(d), np.quantile(d, 0.9))
+        traces[use_graph] = got
+    # the replayed graph is the same computation as the eager launches
+    assert np.abs(traces[True] - traces[False]).max() <= 2e-3 * ref[0], np.abs(traces[True] - traces[False]).max()
