@@ -201,6 +201,10 @@ int parc_motion_lib_build(void *stream, parc_char_model_t model, parc_motion_lib
  * future_max]) + N(0, 0.05 m), written to target_xy / next_target_time (target_xy is written through its const pointer in
  * this mode only) before the task reward terms read it. */
 #define PARC_POST_TARGETS 64
+/* bit7: the rows follow generated plans (the motion-generator sub-env, mgdm_env.py): clip time = motion_time_offsets[e] alone (the
+ * global plan clock, mgdm_env.py:476-480 - not env time + offset), and no end-of-clip termination (DeepMimicEnv.update_done's rule
+ * dm_env.py:746-783 does not apply; the sub-env's termination is RefCharEnv.update_done, mgdm_dm_util.py:205-230). */
+#define PARC_POST_PLAN_CLOCK 128
 int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
                          parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
                          const float *ray_xy);

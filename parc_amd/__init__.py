@@ -18,9 +18,10 @@ _ALIASES = {
     "anim": "anim", "anim.kin_char_model": "anim.kin_char_model", "anim.motion_lib": "anim.motion_lib",
     "util": "util", "util.terrain_util": "util.terrain_util", "util.geom_util": "util.geom_util", "util.torch_util": "util.torch_util",
     "util.mp_util": "util.mp_util", "util.logger": "util.logger", "util.arg_parser": "util.arg_parser", "util.util": "util.util",
-    "util.safe_pickle": "util.safe_pickle",
+    "util.safe_pickle": "util.safe_pickle", "util.motion_util": "util.motion_util",
     "envs": "envs", "envs.base_env": "envs.base_env", "envs.env_builder": "envs.env_builder", "envs.ig_parkour": "envs.ig_parkour",
     "envs.ig_parkour.ig_parkour_env": "envs.ig_parkour.ig_parkour_env", "envs.ig_parkour.dm_env": "envs.ig_parkour.dm_env",
+    "envs.ig_parkour.mgdm_env": "envs.ig_parkour.mgdm_env",
     "learning": "learning", "learning.rl_util": "learning.rl_util", "learning.experience_buffer": "learning.experience_buffer",
     "learning.normalizer": "learning.normalizer", "learning.agent_builder": "learning.agent_builder",
     "learning.base_agent": "learning.dm_ppo_agent", "learning.ppo_agent": "learning.dm_ppo_agent",

@@ -28,6 +28,7 @@ POST_HF = 8
 POST_MASKED = 16
 POST_INIT_CHAR = 32
 POST_TARGETS = 64
+POST_PLAN_CLOCK = 128
 
 c_int = ctypes.c_int
 c_i32 = ctypes.c_int32

@@ -54,7 +54,16 @@ class MotionLib:
         if init_type == "motion_file":
             clips = self._read_motion_files(motion_input)
         elif init_type == "motion_frames":
+            if isinstance(motion_input, torch.Tensor) and motion_input.is_cuda:
+                # generated plans (the motion-generator sub-env rebuilds its library at every replan): stays on the device
+                self._motion_names = self._motion_files = None
+                self._terrains = []
+                self._build_uniform(motion_input, contacts if contact_info else None, fps, loop_mode)
+                return
             clips = self._clips_from_frames(motion_input, loop_mode, fps, contacts)
+            self._build(clips)
+            self._apply_motion_frames_dof_vel_rule(fps)
+            return
         elif init_type == "clips":
             # in-memory clip dicts (parc_amd.synthetic.make_dataset): frames, contacts, fps, loop, weight[, name, hf...]
             clips = list(motion_input)
@@ -185,6 +194,66 @@ class MotionLib:
                                                     _hip.ptr(self._motion_frames), _hip.ptr(d_contacts), _hip.ptr(d_clip),
                                                     _hip.ptr(self._motion_fps), _hip.ptr(self._rows)), "parc_motion_lib_build")
         torch.cuda.current_stream().synchronize()   # the temporaries above must outlive the launch
+
+    def _build_uniform(self, frames, contacts, fps, loop_mode):
+        """M clips of the same length from device tensors frames [M, F, 6 + D] (contacts [M, F, B] or None), reference
+        _load_motion_frames :137-203: no per-clip weights (unit), same derived quantities as file clips.  Nothing is read back."""
+        km = self._kin_char_model
+        B, D = km.get_num_joints(), km.get_dof_size()
+        dev = self._device
+        if frames.dim() == 2:
+            frames = frames.unsqueeze(0)
+        if contacts is not None and contacts.dim() == 2:
+            contacts = contacts.unsqueeze(0)
+        M, F = int(frames.shape[0]), int(frames.shape[1])
+        assert frames.shape[2] == 6 + D and F >= 1
+        total = M * F
+        f32, i64 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.long, device=dev)
+        self._motion_weights = torch.ones(M, **f32)
+        self._motion_fps = torch.full((M,), float(fps), **f32)
+        self._motion_dt = torch.full((M,), 1.0 / fps, **f32)
+        self._motion_num_frames = torch.full((M,), F, **i64)
+        self._motion_lengths = torch.full((M,), 1.0 / fps * (F - 1), **f32)
+        self._motion_loop_modes = torch.full((M,), loop_mode.value, dtype=torch.int, device=dev)
+        self._motion_start_idx = torch.arange(M, **i64) * F
+        self._motion_ids = torch.arange(M, **i64)
+        self._motion_frames = torch.empty((total, 6 + D), **f32)
+        self._motion_root_pos_delta = torch.zeros((M, 3), **f32)
+        self._d_num_frames = self._motion_num_frames.to(torch.int32).contiguous()
+        self._d_start_idx = self._motion_start_idx.to(torch.int32).contiguous()
+        self._layout = _row_layout(B, D)
+        self._rows = torch.empty((total, self._layout["row_stride"]), **f32)
+        self._d_contacts = torch.empty((total, B), **f32) if contacts is not None else None
+        self._d_clip = torch.arange(M, dtype=torch.int32, device=dev).repeat_interleave(F)
+        self._uniform_shape = (M, F)
+        self._uniform_fps = float(fps)
+        self._c_struct = None
+        self.update_frames(frames, contacts)
+
+    def _apply_motion_frames_dof_vel_rule(self, fps):
+        """Libraries built from frame tensors carry dof velocities divided by fps^2: the reference's _load_motion_frames hands `fps` to
+        compute_frame_dof_vel where the file loader hands `dt` (anim/motion_lib.py:181 against :283; kin_char_model.py:543-581 divides
+        by that argument).  Restated as it is - the velocity reward term and the re-spawn state of the generator sub-env see these values."""
+        o = self._layout["off_dof_vel"]
+        self._rows[:, o:o + self._kin_char_model.get_dof_size()] *= 1.0 / (float(fps) * float(fps))
+
+    def update_frames(self, frames, contacts=None):
+        """Replace the frames of a library built from device tensors (same [M, F, .] shape) and rebuild its rows in place: every
+        pointer a kernel or a captured graph holds stays valid."""
+        M, F = self._uniform_shape
+        km = self._kin_char_model
+        assert tuple(frames.shape[0:2]) == (M, F)
+        self._motion_frames.copy_(frames.reshape(M * F, -1))
+        if self._d_contacts is not None:
+            assert contacts is not None
+            self._d_contacts.copy_(contacts.reshape(M * F, -1))
+        d = self._motion_root_pos_delta
+        torch.sub(frames[:, -1, 0:3], frames[:, 0, 0:3], out=d)
+        d[:, 2] = 0.0
+        _hip.check(_hip.lib().parc_motion_lib_build(_hip.stream(), km.c_struct(), self.c_struct(), M * F, _hip.ptr(self._motion_frames),
+                                                    _hip.ptr(self._d_contacts), _hip.ptr(self._d_clip), _hip.ptr(self._motion_fps),
+                                                    _hip.ptr(self._rows)), "parc_motion_lib_build")
+        self._apply_motion_frames_dof_vel_rule(self._uniform_fps)
 
     # ------------------------------------------------------------------ C-ABI view
     def c_struct(self):

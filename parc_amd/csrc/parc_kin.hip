@@ -675,7 +675,9 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         const int pel = min((int)blockIdx.x * POST_EPB + ple, n_total - 1);
         const int pe = env_ids ? (int)env_ids[pel] : pel;
         const int64_t mid = buf.motion_ids[pe];
-        const float mtime = buf.time_buf[pe] + buf.motion_time_offsets[pe];   // dm_env.py:597-602
+        // dataset clips: env time + the clip time the episode started at (dm_env.py:597-602); generated plans: the plan clock itself
+        // (mgdm_env.py:476-480), handed over in the same per-env slot so that it is the exact number and not a rounded sum
+        const float mtime = (what & PARC_POST_PLAN_CLOCK) ? buf.motion_time_offsets[pe] : buf.time_buf[pe] + buf.motion_time_offsets[pe];
         if (pq == 0) {
             const float *prs = buf.root_state + (size_t)pe * 13;
             const q4 cr = ld4(prs + 3);
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         qd[0] = make_float4(__int_as_float(fq.idx0), __int_as_float(fq.idx1), fq.blend, 0.f);
         // (reference query only) env time and the motion-end flag of DeepMimicEnv.update_done, dm_env.py:746-783: the clip
         // length / loop mode were just loaded for the query, the termination code reads the result from LDS
-        const int motion_end = (pq == 0) && (mtime >= ml.length[mid]) && (ml.loop_mode[mid] != 1);
+        const int motion_end = (pq == 0) && !(what & PARC_POST_PLAN_CLOCK) && (mtime >= ml.length[mid]) && (ml.loop_mode[mid] != 1);
         qd[1] = make_float4(shift.x, shift.y, shift.z, buf.time_buf[pe]);
         qd[2] = make_float4(buf.motion_xy_offset[2 * pe] - buf.env_offsets[3 * pe], buf.motion_xy_offset[2 * pe + 1] - buf.env_offsets[3 * pe + 1],
                             __int_as_float(motion_end), 0.f);

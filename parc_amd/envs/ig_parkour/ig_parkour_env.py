@@ -7,8 +7,10 @@ attribute names the agent / recorder reach into.  Isaac Gym is re
 (include/parc_sim.h); reference-pose sampling, observations, reward and termination are one fused HIP launch
 per step (include/parc_hip.h parc_track_post_step).
 
-Only the DeepMimic sub-environment (``fraction_dm_envs: 1.0``, the tracker default) is implemented; the
-motion-generator sub-env (mgdm) is outside the hot path.
+``fraction_dm_envs`` splits the env rows like the reference (ig_parkour_env.py:65-67): rows [0, n_dm) follow dataset clips (the
+DeepMimic sub-env, the tracker default 1.0), rows [n_dm, N) follow plans of a motion generator (mgdm_env.py).  Each sub-env has its
+own clip library and heightfield; every launch of a step (simulator, fused post-step) is issued once per sub-env on its row range, so
+the default all-DeepMimic configuration runs exactly the launches it ran before.
 """
 import math
 import os
@@ -26,7 +28,7 @@ from ...sim_model import SimModel, action_bounds_pd
 from ...tracker_core import TrackerConfig, TrackerCore
 from ...util import geom_util, terrain_util, torch_util
 from .. import base_env
-from . import dm_env
+from . import dm_env, mgdm_env
 
 SIM_CHAR_IDX = 0
 
@@ -49,9 +51,9 @@ class IGParkourEnv(base_env.BaseEnv):
         self._global_obs = env_config["global_obs"]
         self._fraction_dm_envs = env_config["fraction_dm_envs"]
         self._num_dm_envs = min(int(self._fraction_dm_envs * num_envs), num_envs)
-        if self._num_dm_envs != num_envs:
-            raise NotImplementedError("fraction_dm_envs < 1 needs the motion-generator sub-env (out of the tracker hot path)")
-        self._num_mgdm_envs = 0
+        self._num_mgdm_envs = num_envs - self._num_dm_envs
+        if env_config.get("enable_replan_timer_obs", False) and self._num_mgdm_envs > 0:
+            raise NotImplementedError("enable_replan_timer_obs adds a column to the observation row the fused kernel does not write")
         self._output_motion_dir = env_config.get("output_motion_dir", "output/_motions/recorded_motions/")
         self._never_done = env_config.get("never_done", False)
         self._report_tracking_error = env_config.get("report_tracking_error", False)
@@ -91,13 +93,18 @@ class IGParkourEnv(base_env.BaseEnv):
             num_pos=env_config["ray_points_ahead"], num_rays_neg=env_config["ray_num_left"],
             num_rays_pos=env_config["ray_num_right"], angle_between_rays=env_config["ray_angle"]).to(device)
 
-        # DeepMimic sub-env: clips + terrain
-        self._dm_env = dm_env.DeepMimicEnv(config, num_envs, device, visualize, km, motion_input=motion_input)
+        # sub-envs: dataset clips on rows [0, n_dm), generated plans on rows [n_dm, N) (ig_parkour_env.py:160-163)
+        n_dm, n_mg = self._num_dm_envs, self._num_mgdm_envs
+        self._dm_env = dm_env.DeepMimicEnv(config, n_dm, device, visualize, km, motion_input=motion_input) if n_dm > 0 else None
+        self._mgdm_env = mgdm_env.MotionGenDeepMimicEnv(config, n_mg, device, visualize, km) if n_mg > 0 else None
         self._cfg = TrackerConfig(env_config, km, self._ray_xy_points.shape[0])
-        self._core = TrackerCore(num_envs, device, km, self._dm_env._motion_lib, self._cfg, self._ray_xy_points)
-        self._dm_env.attach(self._core)
+        self._core = TrackerCore(num_envs, device, km, self._dm_env._motion_lib if n_dm > 0 else None, self._cfg, self._ray_xy_points)
+        if n_dm > 0:
+            self._dm_env.attach(self._core)
+        self._dm_ids = torch.arange(n_dm, device=device, dtype=torch.long) if n_mg > 0 else None     # None: a launch covers every row
         self._build_terrains(env_config, tiled_terrain)
-        self._core.set_terrain(self._dm_env._terrain)
+        if n_dm > 0:
+            self._core.set_terrain(self._dm_env._terrain)
 
         # env placement (ig_parkour_env.py:492-501)
         n_row = int(np.sqrt(num_envs))
@@ -108,12 +115,28 @@ class IGParkourEnv(base_env.BaseEnv):
 
         self._build_sim_tensors(env_config)
         self._build_data_buffers()
+        if n_mg > 0:
+            self._mgdm_env.attach(self._core, n_dm)
+            self._mgdm_env.replan()          # the first plans exist before the first observation (ig_parkour_env.py:796-798)
         self.set_write_agent_states_flag(env_config.get("write_agent_states", False))
         if self.is_writing_agent_states():
             self.build_agent_states_dict()
 
     # ------------------------------------------------------------------ construction helpers
     def _build_terrains(self, env_config, tiled_terrain):
+        """ig_parkour_env.py:587-634: the generator's square first, the dataset tiles 30 m below it in y when both exist.  The
+        simulator collides every sub-env's rows with that sub-env's own heightfield, so the two need not share a lattice."""
+        x_off = y_off = 0.0
+        if self.has_mgdm_envs():
+            mg = self._mgdm_env
+            path = env_config["mgdm"].get("terrain_save_path")
+            if path and os.path.exists(path):
+                _, _, min_point = mg.load_terrain(path)
+            else:
+                _, _, min_point = mg.build_terrain(env_config, path)
+            x_off, y_off = min_point[0].item(), min_point[1].item() - 30.0
+        if not self.has_dm_envs():
+            return
         dm = self._dm_env
         if tiled_terrain is not None:
             dm.set_tiled(*tiled_terrain)
@@ -122,7 +145,7 @@ class IGParkourEnv(base_env.BaseEnv):
         if path and os.path.exists(path):
             dm.load_terrain(path)
         else:
-            dm.build_terrain(env_config, path)
+            dm.build_terrain(env_config, path, x_off, y_off)
 
     def _build_sim_tensors(self, env_config):
         """Views with the reference's names onto the Isaac-Gym-layout state tensors (ig_char_env.py:166-217,
@@ -181,27 +204,37 @@ class IGParkourEnv(base_env.BaseEnv):
         return Box(low=-np.inf, high=np.inf, shape=[self._cfg.obs_dim], dtype=np.float32)
 
     def has_dm_envs(self):
-        return True
+        return self._num_dm_envs > 0
 
     def has_mgdm_envs(self):
-        return False
+        return self._num_mgdm_envs > 0
 
     def get_dm_env(self):
         return self._dm_env
 
+    def get_mgdm_env(self):
+        return self._mgdm_env
+
     # (replanning belongs to the motion-generator sub-env; a pure tracker reports zeros - persistent tensors, not a fill per call)
     def get_replan_time_buf(self):
+        if self.has_mgdm_envs():
+            return self._mgdm_env._replan_time_buf
         if getattr(self, "_replan_time_zero", None) is None:
             self._replan_time_zero = torch.zeros(1, dtype=torch.float32, device=self._device)
         return self._replan_time_zero
 
     def get_replan_counter(self):
+        if self._num_dm_envs == 0:
+            return self._mgdm_env.get_replan_counter()
         if getattr(self, "_replan_counter_zero", None) is None:
-            self._replan_counter_zero = torch.zeros(self._num_envs, dtype=torch.int64, device=self._device)
-        return self._replan_counter_zero
+            self._replan_counter_zero = torch.zeros(self._num_dm_envs, dtype=torch.int64, device=self._device)
+        if not self.has_mgdm_envs():
+            return self._replan_counter_zero
+        return torch.cat([self._replan_counter_zero, self._mgdm_env.get_replan_counter()], dim=0)
 
     def apply_hard_reset(self):
-        return
+        if self.has_mgdm_envs():
+            self._mgdm_env.apply_hard_reset()
 
     # ``_episode_length`` is written by callers (dm_ppo_agent.record_motions of the reference sets it to 1000 s): the value the
     # kernels see lives in the config struct, so the attribute writes through
@@ -220,6 +253,8 @@ class IGParkourEnv(base_env.BaseEnv):
         """The host-side parameters a step / reset bakes into its kernel launches (a captured hipGraph of the step is only valid
         while they keep these values; learning/dm_ppo_agent keys its graphs by this tuple)."""
         dm = self._dm_env
+        if dm is None:
+            return (float(self._cfg.struct.episode_length),)
 
         def sig(v):
             return ("tensor", v.data_ptr()) if torch.is_tensor(v) else v        # device-resident values are read by the graph itself
@@ -227,30 +262,68 @@ class IGParkourEnv(base_env.BaseEnv):
                 sig(dm._motion_start_time_fraction), dm.has_state_offsets())
 
     def set_rand_reset(self, val=None):
-        val = (not self._dm_env._rand_reset) if val is None else val
-        self._dm_env._rand_reset = val
+        val = (not self._rand_reset) if val is None else val
+        if self.has_dm_envs():
+            self._dm_env._rand_reset = val
         self._rand_reset = val
 
     def set_demo_mode(self, val):
         self._demo_mode = val
-        self._dm_env._demo_mode = val
+        for sub in (self._dm_env, self._mgdm_env):
+            if sub is not None:
+                sub._demo_mode = val
 
     def set_rand_root_pos_offset_scale(self, val):
-        self._dm_env.set_rand_root_pos_offset_scale(val)
+        for sub in (self._dm_env, self._mgdm_env):
+            if sub is not None:
+                sub.set_rand_root_pos_offset_scale(val)
 
     def get_extra_log_info(self):
-        return self._dm_env.get_extra_log_info()
+        return self._dm_env.get_extra_log_info() if self.has_dm_envs() else {}
 
     def post_test_update(self):
-        self._dm_env.post_test_update()
+        if self.has_dm_envs():
+            self._dm_env.post_test_update()
 
     # ------------------------------------------------------------------ reset (ig_parkour_env.py:1012-1041, dm_env.py:656-684)
     def reset(self, env_ids=None):
         if env_ids is None:
             env_ids = self._all_env_ids
+        env_ids = env_ids.to(torch.long)
+        if self.has_mgdm_envs():
+            n_dm = self._num_dm_envs
+            if self.has_dm_envs():
+                self._reset_dm(env_ids[env_ids < n_dm])
+            self._reset_mgdm(env_ids[env_ids >= n_dm] - n_dm)
+        else:
+            self._reset_dm(env_ids)
+        self._update_info()
+        return self._obs_buf, self._info
+
+    def _refresh_bodies(self, env_ids):
+        c = self._core
+        _hip.check(_hip.lib().parc_sim_refresh_bodies(_hip.stream(), self._sim_model.device_ptr(self._device), self._num_envs,
+                                                      _hip.ptr(env_ids), int(env_ids.shape[0]), _hip.ptr(c.root_state),
+                                                      _hip.ptr(c.dof_state), _hip.ptr(c.rigid_body_state), _hip.ptr(c.contact_forces)),
+                   "parc_sim_refresh_bodies")
+
+    def _reset_mgdm(self, rel_ids):
+        """The sub-env decides (mgdm_env.reset: a pending replan re-plans ALL its envs, otherwise the given ones restart on their
+        plan's current frame) and flags the rows whose simulator state it rewrote; like the reference (ig_parkour_env.py:1031-1039)
+        only those rows get new body poses, new observations and an episode count."""
+        mg = self._mgdm_env
+        mg.reset(rel_ids)
+        changed = mg._need_refresh.nonzero().flatten()
+        if len(changed) > 0:
+            mg._need_refresh[:] = False
+            ids = changed + self._num_dm_envs
+            self._refresh_bodies(ids)
+            mg._post(_hip.POST_OBS | _hip.POST_HF, changed)
+            self._ep_num_buf[ids] += 1
+
+    def _reset_dm(self, env_ids):
         c = self._core
         if len(env_ids) > 0:
-            env_ids = env_ids.to(torch.long)
             dm = self._dm_env
             dm.sample_reset(env_ids)
             c.post_step(_hip.POST_REF, env_ids)                       # reference state at the sampled clip time
@@ -279,20 +352,19 @@ class IGParkourEnv(base_env.BaseEnv):
                 self._char_dof_vel[env_ids] += dm._dof_vel_offset[env_ids]
             self._next_target_xy_time[env_ids] = 0.0
             # publish body poses of the new state, then observations for these envs only
-            _hip.check(_hip.lib().parc_sim_refresh_bodies(_hip.stream(), self._sim_model.device_ptr(self._device), self._num_envs,
-                                                          _hip.ptr(env_ids), int(env_ids.shape[0]), _hip.ptr(c.root_state),
-                                                          _hip.ptr(c.dof_state), _hip.ptr(c.rigid_body_state), _hip.ptr(c.contact_forces)),
-                       "parc_sim_refresh_bodies")
+            self._refresh_bodies(env_ids)
             c.target_rand.uniform_()
             c.post_step(_hip.POST_OBS | _hip.POST_HF | _hip.POST_TARGETS, env_ids)      # + xy target resample for these envs
             self._ep_num_buf[env_ids] += 1
-        self._update_info()
-        return self._obs_buf, self._info
 
     # ------------------------------------------------------------------ device-side reset of finished envs
     def supports_device_reset(self):
         dm = self._dm_env
-        return not dm.has_state_offsets() and dm._dm_motion_offsets is not None
+        return not self.has_mgdm_envs() and not dm.has_state_offsets() and dm._dm_motion_offsets is not None
+
+    def supports_graph_step(self):
+        """a step of the generator sub-env has host decisions in it (whose target timer ran out; whether it is time to replan)"""
+        return not self.has_mgdm_envs()
 
     def reset_done(self, done=None):
         """reset(nonzero(done)) without the nonzero: the same state changes as ``reset(env_ids)`` for every env whose
@@ -355,6 +427,8 @@ class IGParkourEnv(base_env.BaseEnv):
     def step(self, action):
         c = self._core
         act = action.to(dtype=torch.float32).contiguous()
+        if self.has_mgdm_envs():
+            return self._step_sub_envs(act)
         # _pre_physics_step + _physics_step: PD targets = clipped action, sim_steps x substeps at h; _update_time (ig_env.py:862-865:
         # timestep += 1, time = timestep * dt) rides in the same launch
         L = _hip.lib()
@@ -373,6 +447,45 @@ class IGParkourEnv(base_env.BaseEnv):
         c.rand_pool_fresh = True
         c.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS)
         c.update_fail_rates(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight)
+        if self._never_done:
+            self._done_buf[:] = base_env.DoneFlags.NULL.value
+        self._update_info(step=True)
+        if self._write_agent_states_flag:
+            self.write_agent_states()
+        return self._obs_buf, self._reward_buf, self._done_buf, self._info
+
+    def _sim_rows(self, act, e0, n, terrain_struct):
+        """the simulator launch (+ env clock) for rows [e0, e0 + n) against one sub-env's heightfield"""
+        c = self._core
+        B, D = self._cfg.num_bodies, self._cfg.dof_size
+        p = _hip.ptr
+        _hip.check(_hip.lib().parc_sim_step_tick(_hip.stream(), self._sim_model.device_ptr(self._device), terrain_struct, n, p(c.root_state[e0:]),
+                                                 p(c.dof_state[e0 * D:]), p(c.rigid_body_state[e0 * B:]), p(c.contact_forces[e0 * B:]),
+                                                 p(c.env_offsets[e0:]), p(act[e0:]), p(self._action_bound_low), p(self._action_bound_high),
+                                                 self._sim_steps * self._substeps, self._sim_h, p(self._timestep_buf[e0:]), p(self._time_buf[e0:]),
+                                                 float(self._timestep)), "parc_sim_step_tick")
+
+    def _step_sub_envs(self, act):
+        """The same step when rows are split between the two sub-envs: every launch once per sub-env on its rows, in the reference's
+        order (ig_env.py:839-848 with ig_parkour_env.py:996-1010,1521-1535): pre-physics hooks, simulate, clocks, update_misc, then
+        reference pose / observations / reward / termination, then the generator sub-env's own termination rules."""
+        c, mg = self._core, self._mgdm_env
+        n_dm, n_mg = self._num_dm_envs, self._num_mgdm_envs
+        mg.pre_physics_step()
+        if n_dm > 0:
+            self._sim_rows(act, 0, n_dm, c._terrain_struct)
+        self._sim_rows(act, n_dm, n_mg, mg.terrain_struct())
+        mg.update_time(self._timestep)
+        mg.update_misc()
+        if n_dm > 0:
+            c.rand_pool.uniform_()
+            c.rand_pool_fresh = True
+            c.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS, self._dm_ids)
+            _hip.check(_hip.lib().parc_update_fail_rates(_hip.stream(), n_dm, c.mlib.num_motions(), _hip.ptr(c.motion_ids), _hip.ptr(c.done_kind),
+                                                         float(self._dm_env._ema_weight), _hip.ptr(self._dm_env._motion_id_fail_rates)),
+                       "parc_update_fail_rates")
+        mg._post(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF)
+        mg.update_done_extra()
         if self._never_done:
             self._done_buf[:] = base_env.DoneFlags.NULL.value
         self._update_info(step=True)
@@ -446,8 +559,14 @@ class IGParkourEnv(base_env.BaseEnv):
             shapes["char_contacts"] = {"use_normalizer": False, "shape": torch.Size([B])}
             shapes["hf"] = {"use_normalizer": False, "shape": torch.Size([self._ray_xy_points.shape[0]])}
             return shapes
-        ids = env_ids if env_ids is not None else None
-        self._core.post_step(_hip.POST_OBS | _hip.POST_HF, ids)
+        if self.has_mgdm_envs():
+            ids = self._all_env_ids if env_ids is None else env_ids.to(torch.long)
+            n_dm = self._num_dm_envs
+            if n_dm > 0:
+                self._core.post_step(_hip.POST_OBS | _hip.POST_HF, ids[ids < n_dm])
+            self._mgdm_env._post(_hip.POST_OBS | _hip.POST_HF, ids[ids >= n_dm] - n_dm)
+        else:
+            self._core.post_step(_hip.POST_OBS | _hip.POST_HF, env_ids)
         return self._obs_buf if env_ids is None else self._obs_buf[env_ids]
 
     # ------------------------------------------------------------------ motion recording (ig_parkour_env.py:850-995,1594-1620)

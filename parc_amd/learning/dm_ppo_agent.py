@@ -337,7 +337,8 @@ class DMPPOAgent(torch.nn.Module):
     def _graph_ok(self):
         env = self._env
         return (self._use_hip_graph and self._mode == AgentMode.TRAIN and not getattr(env, "_write_agent_states_flag", False)
-                and hasattr(env, "_char_contact_forces") and getattr(getattr(env, "_core", None), "timing_events", None) is None)
+                and hasattr(env, "_char_contact_forces") and getattr(getattr(env, "_core", None), "timing_events", None) is None
+                and getattr(env, "supports_graph_step", lambda: True)())
 
     def _train_step_graph(self, device_reset=False):
         """One rollout step through a captured hipGraph (torch.cuda.CUDAGraph = hipGraph on ROCm).  Graphs are keyed by

@@ -208,7 +208,11 @@ class TrackerCore:
                                                   self.cfg.obs_dim), "parc_refresh_obs_hfs")
 
     # ---- fused K3/K2/K4/K6-K10
-    def post_step(self, what, env_ids=None, reset_rand=False):
+    def post_step(self, what, env_ids=None, reset_rand=False, mlib=None, terrain_struct=None):
+        """mlib / terrain_struct: the clip library and heightfield of a sub-env other than the default one (the motion-generator
+        sub-env launches on its own rows with its own)"""
+        mlib = self.mlib if mlib is None else mlib
+        terrain_struct = self._terrain_struct if terrain_struct is None else terrain_struct
         if env_ids is not None:
             env_ids = env_ids.to(torch.int64).contiguous()
             n = int(env_ids.shape[0])
@@ -221,7 +225,7 @@ class TrackerCore:
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        _hip.check(_hip.lib().parc_track_post_step(_hip.stream(), self.km.c_struct(), self.mlib.c_struct(), self._terrain_struct,
+        _hip.check(_hip.lib().parc_track_post_step(_hip.stream(), self.km.c_struct(), mlib.c_struct(), terrain_struct,
                                                    self.cfg.struct, self.buffers(reset_rand), ids, n, what, _hip.ptr(self.ray_xy_points)),
                    "parc_track_post_step")
         if timed:

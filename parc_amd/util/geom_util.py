@@ -141,3 +141,13 @@ def get_char_point_samples(char_model, sphere_num_subdivisions=0, box_num_slices
 def sdSphere(p, c, r):
     """signed distance of points p to the sphere of centre c and radius r (reference util/geom_util.py:167-171)"""
     return torch.linalg.vector_norm(p - c, dim=-1) - r
+
+
+def get_xy_grid_points(center, dx, dy, num_x_neg, num_x_pos, num_y_neg, num_y_pos):
+    """[1 + x_neg + x_pos, 1 + y_neg + y_pos, 2] grid of xy points around `center`, x index first (reference util/geom_util.py:210-221;
+    the coordinates come from linspace evaluated on the host so that they are the same bits on every device)."""
+    cx, cy = float(center[0]), float(center[1])
+    xs = torch.linspace(cx - dx * num_x_neg, cx + dx * num_x_pos, num_x_neg + num_x_pos + 1)
+    ys = torch.linspace(cy - dy * num_y_neg, cy + dy * num_y_pos, num_y_neg + num_y_pos + 1)
+    x, y = torch.meshgrid(xs, ys, indexing="ij")
+    return torch.stack([x, y], dim=-1).to(center.device)

@@ -30,7 +30,8 @@ def shipped_clip(which=0):
                 name=("civilization", "teaser")[which])
 
 
-def build_env(name, num_envs, device, seed=0):
+def build_env(name, num_envs, device, seed=0, env_overrides=None):
+    """-> (env, clips, tiled).  env_overrides: keys of the env YAML's `env:` block to replace (e.g. fraction_dm_envs + mgdm)."""
     if name in ("civ_clip", "teaser_clip"):          # the authors' own clip on its own terrain (learning evidence on real data)
         clips = [shipped_clip(0 if name == "civ_clip" else 1)]
         tiled = synthetic.tile_square(clips)
@@ -41,6 +42,8 @@ def build_env(name, num_envs, device, seed=0):
                                    tile_cells_range=spec.get("tile_cells_range"))
     tiled = synthetic.tile_square(clips)
     cfg = default_env_config()
+    if env_overrides:
+        cfg["env"].update(env_overrides)
     return IGParkourEnv(cfg, num_envs, device, False, motion_input=clips, tiled_terrain=tiled), clips, tiled
 
 

@@ -1031,7 +1031,7 @@ def gen_recorded_files():
 
 
 STAGES = ["core", "voxel-mesh", "dataset-yaml", "procgen", "terrain-geometry", "done-branches", "ppo-loss", "normalizer", "trackers",
-          "action-head", "recorded-files", "motion-opt"]
+          "action-head", "recorded-files", "motion-opt", "mgdm"]
 
 
 def _icosa_points(radius):
@@ -1135,6 +1135,179 @@ def gen_motion_opt():
     save("g20_motion_opt", **out)
 
 
+def gen_mgdm():
+    """G21: the motion-generator sub-env (envs/ig_parkour/mgdm_env.py MotionGenDeepMimicEnv) driven on CPU the way
+    IGParkourEnv drives it (reset -> pre_physics_step -> [physics] -> update_time -> update_misc -> _update_ref_motion -> compute_tar_obs ->
+    refresh_obs_hfs -> update_done -> reset(done ids)), 8 envs, 27 steps, plan length 0.3 s.  The trained diffusion model is not in the
+    tree (external download): `load_mdm` / `gen_util.gen_mdm_motion` are replaced by a deterministic stand-in whose INPUTS and OUTPUTS are
+    stored per call, so a test can replay the outputs and check that the env under test hands the generator the same inputs.  "Physics" is
+    the script's own: the character is put near the reference pose with seeded noise (some envs are pushed out of pose / out of bounds /
+    too high to reach every termination branch); these states are stored as inputs.  Every torch.rand draw of the sub-env is stored in
+    call order (`rand_k`), which is what lets a GPU implementation reproduce the sampling."""
+    import random
+    import envs.ig_parkour.mgdm_env as me
+    import util.motion_util as motion_util
+    import envs.base_env as base_env
+    rng = np.random.default_rng(21)
+    torch.manual_seed(21)
+    random.seed(21)
+    km = load_char()
+    N, F, dt = 8, 16, 1.0 / 30.0
+    B, D = km.get_num_joints(), km.get_dof_size()
+    out = {}
+    calls = []
+    real_rand = torch.rand
+
+    class StubGen:
+        _num_prev_states, _sequence_fps, _device = 2, 30, "cpu"
+        _dx = _dy = 0.4
+        _num_x_neg, _num_x_pos, _num_y_neg, _num_y_pos = 2, 5, 3, 3
+        _target_type = me.mdm.TargetType.XY_DIR
+
+    def stub_generate(target_world_pos, prev_frames, terrain, mdm_model, char_model, mdm_settings, verbose=True):
+        k = len(calls)
+        n = prev_frames.root_pos.shape[0]
+        last_p, last_q, last_j = prev_frames.root_pos[:, -1], prev_frames.root_rot[:, -1], prev_frames.joint_rot[:, -1]
+        d = target_world_pos[:, 0:2] - last_p[:, 0:2]
+        d = d / torch.linalg.norm(d, dim=-1, keepdim=True).clamp(min=1e-3)
+        tt = torch.arange(F, dtype=torch.float32).reshape(1, F, 1) / 30.0
+        rp = last_p.unsqueeze(1).repeat(1, F, 1)
+        rp[..., 0:2] += 1.1 * tt * d.unsqueeze(1)
+        rp[..., 2] += 0.02 * torch.sin(6.0 * tt[..., 0])
+        yaw = 0.4 * tt[..., 0] * (0.5 - (torch.arange(n) % 2).float()).unsqueeze(-1)
+        dq = torch.stack([torch.zeros_like(yaw), torch.zeros_like(yaw), torch.sin(yaw / 2), torch.cos(yaw / 2)], dim=-1)
+        rq = torch_util.quat_mul(dq, last_q.unsqueeze(1).repeat(1, F, 1))
+        g = torch.Generator().manual_seed(1000 + k)
+        wob = torch_util.exp_map_to_quat(0.08 * torch.randn((n, 1, B - 1, 3), generator=g) * torch.sin(4.0 * tt).unsqueeze(-1))
+        jr = torch_util.quat_mul(last_j.unsqueeze(1).repeat(1, F, 1, 1), wob)
+        con = (real_rand((n, F, B), generator=g) > 0.6).float()
+        calls.append(True)
+        out.update({"gen%d_target" % k: target_world_pos.clone(), "gen%d_prev_root_pos" % k: prev_frames.root_pos.clone(),
+                    "gen%d_prev_root_rot" % k: prev_frames.root_rot.clone(), "gen%d_prev_joint_rot" % k: prev_frames.joint_rot.clone(),
+                    "gen%d_prev_contacts" % k: prev_frames.contacts.clone(),
+                    "gen%d_use_prev_state" % k: mdm_settings.use_prev_state.clone(), "gen%d_prev_state_ind_key" % k: mdm_settings.prev_state_ind_key.clone(),
+                    "gen%d_out_root_pos" % k: rp, "gen%d_out_root_rot" % k: rq, "gen%d_out_joint_rot" % k: jr, "gen%d_out_contacts" % k: con})
+        return motion_util.MotionFrames(root_pos=rp, root_rot=rq, joint_rot=jr, contacts=con)
+
+    me.load_mdm = lambda path: StubGen()
+    me.gen_util.gen_mdm_motion = stub_generate
+    rands = []
+
+    def recording_rand(*a, **k):
+        r = real_rand(*a, **k)
+        rands.append(r.clone())
+        return r
+    cfg = {"env": {"control_freq": 30, "rand_root_pos_offset_scale": 0.0, "max_obs_h": 3.0, "min_obs_h": -3.0, "demo_mode": False, "target_radius": 0.5,
+                   "mgdm": {"plan_length": 0.3, "ddim_stride": 50, "max_replans": 2, "cfg_scale": 0.7, "target_dist_max": 4.0, "target_dist_min": 1.0,
+                            "target_dur_max": 0.5, "target_dur_min": 0.2, "target_heading_scale": 0.5, "model_path": "unused",
+                            "heightmap": {"horizontal_scale": 0.4, "sq_m_per_env": 0.3, "safety_region": 2.0, "num_segments": 5,
+                                          "platform_heights": [0.4, 0.8]}}}}
+    out["config_json"] = np.frombuffer(__import__("json").dumps(cfg).encode(), dtype=np.uint8)
+    env = me.MotionGenDeepMimicEnv(cfg, N, "cpu", False, km)
+    z = torch.zeros
+    ref = dict(ref_root_pos=z(N, 3), ref_root_rot=z(N, 4), ref_root_vel=z(N, 3), ref_root_ang_vel=z(N, 3), ref_body_pos=z(N, B, 3),
+               ref_joint_rot=z(N, B - 1, 4), ref_dof_pos=z(N, D), ref_dof_vel=z(N, D), ref_contacts=z(N, B))
+    ref["ref_root_rot"][:, 3] = 1
+    ref["ref_joint_rot"][..., 3] = 1
+    ch = dict(char_root_pos=z(N, 3), char_root_rot=z(N, 4), char_root_vel=z(N, 3), char_root_ang_vel=z(N, 3), char_dof_pos=z(N, D), char_dof_vel=z(N, D),
+              char_contact_forces=z(N, B, 3), char_rigid_body_pos=z(N, B, 3), char_rigid_body_vel=z(N, B, 3), char_rigid_body_ang_vel=z(N, B, 3))
+    ch["char_root_rot"][:, 3] = 1
+    env.get_sim_tensor_views(**ref, **ch)
+    env_offsets = z(N, 3)
+    env_offsets[:, 0] = 0.3 * (torch.arange(N) % 4)
+    env_offsets[:, 1] = 0.3 * (torch.arange(N) // 4)
+    key_ids = torch.tensor([km.get_body_id(n) for n in ("right_hand", "left_hand", "right_foot", "left_foot")])
+    rays = geom_util.get_xy_points_cone(center=torch.zeros(2), dx=0.2, num_neg=1, num_pos=5, num_rays_neg=1, num_rays_pos=1, angle_between_rays=0.3)
+    bufs = dict(reward_buf=z(N), done_buf=z(N, dtype=torch.int), time_buf=z(N), timestep_buf=z(N, dtype=torch.int),
+                actors_need_reset=z(N, 1, dtype=torch.bool), target_xy=z(N, 2), next_target_xy_time=z(N), env_offsets=env_offsets,
+                key_body_ids=key_ids, ray_xy_points=rays, ray_hfs=z(N, rays.shape[0]))
+    env.get_data_buffer_views(**bufs)
+    out.update(env_offsets=env_offsets, key_body_ids=key_ids, ray_xy_points=rays)
+    tmpd = tempfile.mkdtemp(prefix="parc_golden_mgdm_")
+    verts, tris, min_pt = env.build_terrain(cfg["env"], os.path.join(tmpd, "mgdm_terrain.pkl"))
+    out.update(terrain_hf=env._terrain.hf, terrain_min_point=env._terrain.min_point, terrain_dxdy=env._terrain.dxdy,
+               spawn=np.array([env._spawn_min_x, env._spawn_max_x, env._spawn_min_y, env._spawn_max_y, env._oob_region]),
+               mesh_counts=np.array([verts.shape[0], tris.shape[0]]), local_grid=env._mgdm_local_xy_points)
+    tar_steps = torch.tensor([1, 2, 5])
+    out["tar_obs_steps"] = tar_steps
+    done_args = dict(termination_height=0.15, episode_length=0.8, contact_body_ids=torch.tensor([km.get_body_id("right_foot"), km.get_body_id("left_foot")]),
+                     pose_termination=True, pose_termination_dist=torch.tensor([0.7, 1.0, 0.7, 0.7, 0.7, 0.7, 0.7, 0.7, 1.0, 1.2, 10.0, 1.0, 1.2, 10.0]),
+                     global_obs=False, enable_early_termination=True, track_root=True, root_pos_termination_dist=0.6,
+                     root_rot_termination_angle=1.309)
+    out["pose_termination_dist"] = done_args["pose_termination_dist"]
+
+    def snap(tag):
+        out.update({tag + "_" + k: v.clone() for k, v in ref.items()})
+        out.update({tag + "_" + k: ch[k].clone() for k in ("char_root_pos", "char_root_rot", "char_root_vel", "char_root_ang_vel", "char_dof_pos", "char_dof_vel")})
+        out.update({tag + "_done": bufs["done_buf"].clone(), tag + "_time": bufs["time_buf"].clone(), tag + "_timestep": bufs["timestep_buf"].clone(),
+                    tag + "_target_xy": bufs["target_xy"].clone(), tag + "_next_target_time": bufs["next_target_xy_time"].clone(),
+                    tag + "_replan_buf": env._replan_buf.clone(), tag + "_replan_counter": env._replan_counter.clone(),
+                    tag + "_plan_time": env._mgdm_time_buf.clone(), tag + "_replan_flag": np.array([int(env._replan_flag)]),
+                    tag + "_need_reset": bufs["actors_need_reset"].clone(), tag + "_num_rand": np.array([len(rands)]),
+                    tag + "_num_gen": np.array([len(calls)]),
+                    tag + "_agent_hist_root_pos": env._agent_state_hist.root_pos.clone(), tag + "_ref_hist_root_pos": env._ref_state_hist.root_pos.clone(),
+                    tag + "_agent_hist_joint_rot": env._agent_state_hist.joint_rot.clone()})
+    me.torch.rand = recording_rand
+    try:
+        env.replan()                          # IGParkourEnv._build_data_buffers :797-798
+        snap("init")
+        bufs["actors_need_reset"][:] = False
+        env.reset(torch.arange(N))            # the agent's first reset(None): every env, no replan pending -> soft reset
+        snap("reset0")
+        bufs["actors_need_reset"][:] = False
+        K = 27
+        for k in range(K):
+            env.pre_physics_step()
+            # the script's "physics": the character lands near the reference pose one step ahead
+            nxt = env._motion_lib.calc_motion_frame(env._motion_ids, env._mgdm_time_buf.expand(N) + dt)
+            ch["char_root_pos"][:] = nxt[0] + t(rng.normal(0, 0.02, (N, 3)))
+            ch["char_root_rot"][:] = torch_util.quat_mul(torch_util.exp_map_to_quat(t(rng.normal(0, 0.03, (N, 3)))), nxt[1])
+            ch["char_root_vel"][:] = nxt[2]
+            ch["char_root_ang_vel"][:] = nxt[3]
+            ch["char_dof_pos"][:] = km.rot_to_dof(nxt[4]) + t(rng.normal(0, 0.03, (N, D)))
+            ch["char_dof_vel"][:] = nxt[5]
+            if k == 4:
+                ch["char_dof_pos"][1, 0:3] += 1.5           # out of pose
+            if k == 6:
+                ch["char_root_pos"][2, 2] = 3.4             # too high
+            if k == 12:
+                ch["char_root_pos"][3, 0] = env._terrain.min_point[0] + env._oob_region * 0.5 - env_offsets[3, 0]      # out of bounds
+            if k == 15:
+                ch["char_root_pos"][4, 1] += 0.9            # root position
+            bp, _ = km.forward_kinematics(ch["char_root_pos"], ch["char_root_rot"], km.dof_to_rot(ch["char_dof_pos"]))
+            ch["char_rigid_body_pos"][:] = bp
+            ch["char_contact_forces"][:] = t((rng.random((N, B, 1)) > 0.8) * rng.normal(0, 30.0, (N, B, 3)))
+            tag = "s%d" % k
+            out.update({tag + "_in_" + kk: ch[kk].clone() for kk in ("char_root_pos", "char_root_rot", "char_root_vel", "char_root_ang_vel", "char_dof_pos",
+                                                                     "char_dof_vel", "char_rigid_body_pos", "char_contact_forces")})
+            bufs["timestep_buf"] += 1
+            bufs["time_buf"][:] = dt * bufs["timestep_buf"]
+            env.update_time(dt)
+            env.update_misc()
+            env._update_ref_motion()
+            tar = env.compute_tar_obs(tar_steps)
+            out.update({tag + "_tar_root_pos": tar[0], tag + "_tar_root_rot": tar[1], tag + "_tar_joint_rot": tar[2], tag + "_tar_key_pos": tar[3],
+                        tag + "_tar_contacts": tar[4]})
+            gpos = ch["char_root_pos"] + env_offsets
+            env.refresh_obs_hfs(gpos, torch_util.calc_heading(ch["char_root_rot"]))
+            out.update({tag + "_ray_hfs": bufs["ray_hfs"].clone(), tag + "_mgdm_hfs": env._mgdm_hfs.clone(), tag + "_floor": env._mgdm_floor_heights.clone()})
+            env.update_done(**done_args)
+            out.update({tag + "_done_after_update": bufs["done_buf"].clone(), tag + "_replan_buf_after_update": env._replan_buf.clone(),
+                        tag + "_replan_flag_after_update": np.array([int(env._replan_flag)])})
+            ids = (bufs["done_buf"] != base_env.DoneFlags.NULL.value).nonzero().flatten()
+            env.reset(ids)
+            snap(tag)
+            bufs["actors_need_reset"][:] = False
+        out["num_steps"] = np.array([K])
+    finally:
+        me.torch.rand = real_rand
+    for i, r in enumerate(rands):
+        out["rand_%d" % i] = r
+    out["num_rand"] = np.array([len(rands)])
+    out["num_gen"] = np.array([len(calls)])
+    save("g21_mgdm", **out)
+
+
 def gen_core():
     rng = np.random.default_rng(0)
     torch.manual_seed(0)
@@ -1156,7 +1329,7 @@ def main():
     run = {"core": gen_core, "voxel-mesh": lambda: gen_voxel_mesh(np.random.default_rng(10)), "dataset-yaml": gen_dataset_yaml,
            "procgen": gen_procgen, "terrain-geometry": gen_terrain_geometry, "done-branches": gen_done_branches, "ppo-loss": gen_ppo_loss,
            "normalizer": gen_normalizer, "trackers": gen_trackers, "action-head": gen_action_head, "recorded-files": gen_recorded_files,
-           "motion-opt": gen_motion_opt}
+           "motion-opt": gen_motion_opt, "mgdm": gen_mgdm}
     picked = [s_ for s_ in STAGES if "--only-" + s_ in sys.argv]
     if "--check" in sys.argv:
         # regenerate everything into a scratch directory and compare with the committed fixtures array by array

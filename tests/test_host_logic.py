@@ -604,3 +604,53 @@ def test_optimiser_output_file_is_reference_readable():
     parc_amd.install_reference_aliases()
     back = pickle.load(open(path, "rb"))                               # a file of our own
     assert back["opt:body_constraints"][0][0].end_frame_idx == 9
+
+
+def test_mgdm_terrain_build_and_pose_containers_against_g21(tmp_path):
+    """Host side of the motion-generator sub-env against fixture G21 (the reference's mgdm_env.py on CPU): the checkerboard platform
+    terrain with the same Python RNG stream, its spawn bounds and voxel-mesh size, the generator's local grid, the cache file's class
+    paths; MotionFrames container operations."""
+    import json
+    import random
+    import parc_amd
+    from parc_amd.anim.kin_char_model import KinCharModel
+    from parc_amd.assets import humanoid_spec
+    from parc_amd.envs.ig_parkour import mgdm_env
+    from parc_amd.util import motion_util
+    g = golden("g21_mgdm")
+    km = KinCharModel("cpu")
+    km.load_char_file(humanoid_spec.write_mjcf())
+
+    class Gen:
+        _num_prev_states, _sequence_fps = 2, 30
+        _dx = _dy = 0.4
+        _num_x_neg, _num_x_pos, _num_y_neg, _num_y_pos = 2, 5, 3, 3
+    cfg = json.loads(bytes(g["config_json"]).decode())
+    env = mgdm_env.MotionGenDeepMimicEnv(cfg, 8, "cpu", False, km, generator=Gen())
+    np.testing.assert_allclose(env._mgdm_local_xy_points.numpy(), g["local_grid"], atol=1e-6)
+    random.seed(21)
+    path = str(tmp_path / "mgdm_terrain.pkl")
+    verts, tris, min_point = env.build_terrain(cfg["env"], path)
+    np.testing.assert_array_equal(env._terrain.hf.numpy(), g["terrain_hf"])
+    np.testing.assert_allclose(env._terrain.min_point.numpy(), g["terrain_min_point"], atol=0)
+    np.testing.assert_allclose([env._spawn_min_x, env._spawn_max_x, env._spawn_min_y, env._spawn_max_y, env._oob_region], g["spawn"], atol=1e-12)
+    assert [verts.shape[0], tris.shape[0]] == g["mesh_counts"].tolist()
+    assert {m for m, _ in pickle_globals(path) if not m.startswith(("numpy", "torch", "collections", "_codecs"))} == {"util.terrain_util"}
+    env2 = mgdm_env.MotionGenDeepMimicEnv(cfg, 8, "cpu", False, km, generator=Gen())
+    env2.load_terrain(path)
+    assert torch.equal(env2._terrain.hf, env._terrain.hf) and env2._spawn_max_x == env._spawn_max_x and env2._oob_region == env._oob_region
+    assert env.get_target_dim() == 2
+    # pose containers
+    a = motion_util.MotionFrames()
+    a.init_blank_frames(km, 2, batch_size=3)
+    assert a.joint_rot.shape == (3, 2, 14, 4) and float(a.root_rot[..., 3].min()) == 1.0
+    b = motion_util.MotionFrames(root_pos=torch.ones(3, 1, 3), root_rot=a.root_rot[:, :1], joint_rot=a.joint_rot[:, :1], contacts=torch.zeros(3, 1, 15))
+    a.body_pos = a.body_rot = None
+    c = motion_util.cat_motion_frames([a, b])
+    assert c.root_pos.shape == (3, 3, 3) and c.body_pos is None and float(c.root_pos[:, -1].min()) == 1.0
+    assert c.get_slice(slice(1, 3)).contacts.shape == (3, 2, 15) and c.get_idx(torch.tensor([2])).root_pos.shape == (1, 3, 3)
+    a.set_vals(c.get_slice(slice(1, 3)), torch.tensor([1]))
+    assert float(a.root_pos[1, -1].min()) == 1.0 and float(a.root_pos[0].abs().max()) == 0.0
+    parc_amd.install_reference_aliases()
+    import util.motion_util as ref_named            # the name the reference's scripts import
+    assert ref_named.MotionFrames is motion_util.MotionFrames

@@ -1,0 +1,254 @@
+"""The motion-generator sub-env on the GPU.
+
+1. Against fixture G21: the REFERENCE's envs/ig_parkour/mgdm_env.py MotionGenDeepMimicEnv driven on CPU for 27 steps (tests/golden/
+   gen_golden.py stage mgdm) with a recorded stand-in generator.  Here the generator replays the recorded plans and ASSERTS that it is
+   handed the recorded inputs; uniform draws are replayed in call order; the "physics" states are the recorded ones.  Compared after
+   every call: reference pose buffers (the fused launch on the sub-env's rows with its own clip library and terrain), target poses,
+   ray-fan heights, the generator's height grid, termination codes per branch, replan flags / counters / plan clock, targets, the state
+   histories, the re-spawned character states.
+2. IGParkourEnv with fraction_dm_envs < 1: both sub-envs in one env, the agent-style loop step -> reset(done ids)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from test_hip_parity import DEV, T, close, km  # noqa: F401  (km is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+class ReplayRand:
+    def __init__(self, g):
+        self.g, self.k = g, 0
+
+    def __call__(self, n):
+        r = self.g["rand_%d" % self.k]
+        assert r.shape == (n,), ("draw %d" % self.k, r.shape, n)
+        self.k += 1
+        return T(r)
+
+
+class ReplayGenerator:
+    """returns the recorded plans; checks that the env hands over the recorded inputs"""
+    _num_prev_states, _sequence_fps = 2, 30
+    _dx = _dy = 0.4
+    _num_x_neg, _num_x_pos, _num_y_neg, _num_y_pos = 2, 5, 3, 3
+
+    def __init__(self, g):
+        self.g, self.k = g, 0
+
+    def __call__(self, target_xy, prev_frames, terrain, char_model, settings):
+        from parc_amd.util.motion_util import MotionFrames
+        g, p = self.g, "gen%d_" % self.k
+        close(target_xy, g[p + "target"], atol=2e-5, rtol=0)
+        close(prev_frames.root_pos, g[p + "prev_root_pos"], atol=2e-5, rtol=0)
+        close(prev_frames.root_rot, g[p + "prev_root_rot"], atol=2e-5, rtol=0)
+        close(prev_frames.joint_rot, g[p + "prev_joint_rot"], atol=2e-5, rtol=0)
+        close(prev_frames.contacts, g[p + "prev_contacts"], atol=0, rtol=0)
+        assert np.array_equal(settings.use_prev_state.cpu().numpy(), g[p + "use_prev_state"])
+        assert np.array_equal(settings.prev_state_ind_key.cpu().numpy(), g[p + "prev_state_ind_key"])
+        assert terrain.hf.shape == g["terrain_hf"].shape
+        self.k += 1
+        return MotionFrames(root_pos=T(g[p + "out_root_pos"]), root_rot=T(g[p + "out_root_rot"]), joint_rot=T(g[p + "out_joint_rot"]),
+                            contacts=T(g[p + "out_contacts"]))
+
+
+def _g21_env_config(g):
+    from parc_amd.envs.ig_parkour.default_config import default_env_config
+    cfg = default_env_config()
+    e = cfg["env"]
+    e.update(json.loads(bytes(g["config_json"]).decode())["env"])
+    e.update(tar_obs_steps=[int(v) for v in g["tar_obs_steps"]], termination_height=0.15, episode_length=0.8, pose_termination=True,
+             pose_termination_dist=[float(v) for v in g["pose_termination_dist"]], enable_early_termination=True, track_root=True,
+             root_pos_termination_dist=0.6, root_rot_termination_angle=1.309, contact_bodies=["right_foot", "left_foot"],
+             key_bodies=["right_hand", "left_hand", "right_foot", "left_foot"], fraction_dm_envs=0.0)
+    return cfg
+
+
+def _make_sub_env(g, km):
+    from parc_amd.envs.ig_parkour import mgdm_env
+    from parc_amd.tracker_core import TrackerConfig, TrackerCore
+    from parc_amd.util import terrain_util
+    cfg = _g21_env_config(g)
+    N = int(g["env_offsets"].shape[0])
+    rays = T(g["ray_xy_points"])
+    tcfg = TrackerConfig(cfg["env"], km, int(rays.shape[0]))
+    assert tcfg.key_body_ids == g["key_body_ids"].tolist()
+    core = TrackerCore(N, DEV, km, None, tcfg, rays)
+    core.env_offsets[:] = T(g["env_offsets"])
+    gen, rnd = ReplayGenerator(g), ReplayRand(g)
+    mg = mgdm_env.MotionGenDeepMimicEnv(cfg, N, DEV, False, km, generator=gen, rand_fn=rnd)
+    close(mg._mgdm_local_xy_points, g["local_grid"], atol=1e-6, rtol=0)
+    mg._terrain = terrain_util.SubTerrain.from_arrays(g["terrain_hf"], g["terrain_min_point"], g["terrain_dxdy"], device=DEV)
+    mg._spawn_min_x, mg._spawn_max_x, mg._spawn_min_y, mg._spawn_max_y, mg._oob_region = [float(v) for v in g["spawn"]]
+    mg.attach(core, 0)
+    return cfg, core, mg, gen, rnd
+
+
+def _check_snapshot(g, tag, core, mg, gen, rnd, need_refresh):
+    for name in ("ref_root_pos", "ref_root_rot", "ref_root_vel", "ref_root_ang_vel", "ref_body_pos", "ref_joint_rot", "ref_dof_pos", "ref_dof_vel",
+                 "ref_contacts"):
+        tol = 3e-4 if name in ("ref_root_vel", "ref_root_ang_vel", "ref_dof_vel", "ref_joint_rot", "ref_dof_pos", "ref_body_pos") else 3e-5
+        close(getattr(core, name), g[tag + "_" + name], atol=tol, rtol=1e-4)
+    close(mg._char_root_pos, g[tag + "_char_root_pos"], atol=3e-5, rtol=0)
+    close(mg._char_root_rot, g[tag + "_char_root_rot"], atol=3e-5, rtol=0)
+    close(mg._char_root_vel, g[tag + "_char_root_vel"], atol=3e-4, rtol=1e-4)
+    close(mg._char_dof_pos, g[tag + "_char_dof_pos"], atol=3e-5, rtol=0)
+    close(mg._char_dof_vel, g[tag + "_char_dof_vel"], atol=3e-4, rtol=1e-4)
+    assert np.array_equal(core.done.cpu().numpy(), g[tag + "_done"]), tag
+    assert np.array_equal(core.timestep_buf.cpu().numpy(), g[tag + "_timestep"]), tag
+    close(core.time_buf, g[tag + "_time"], atol=1e-6, rtol=0)
+    close(core.target_xy, g[tag + "_target_xy"], atol=3e-5, rtol=0)
+    close(core.next_target_xy_time, g[tag + "_next_target_time"], atol=1e-5, rtol=0)
+    assert np.array_equal(mg._replan_buf.cpu().numpy(), g[tag + "_replan_buf"]), tag
+    assert np.array_equal(mg._replan_counter.cpu().numpy(), g[tag + "_replan_counter"]), tag
+    close(mg._mgdm_time_buf, g[tag + "_plan_time"], atol=0, rtol=0)
+    assert float(mg._plan_time_host) == float(g[tag + "_plan_time"][0])            # the host image of the plan clock is the same fp32 number
+    assert int(mg._replan_flag) == int(g[tag + "_replan_flag"][0])
+    assert np.array_equal(need_refresh.cpu().numpy(), g[tag + "_need_reset"][:, 0]), tag
+    assert rnd.k == int(g[tag + "_num_rand"][0]) and gen.k == int(g[tag + "_num_gen"][0]), (tag, rnd.k, gen.k)
+    close(mg._agent_state_hist.root_pos, g[tag + "_agent_hist_root_pos"], atol=3e-5, rtol=0)
+    close(mg._agent_state_hist.joint_rot, g[tag + "_agent_hist_joint_rot"], atol=3e-5, rtol=0)
+    close(mg._ref_state_hist.root_pos, g[tag + "_ref_hist_root_pos"], atol=3e-5, rtol=0)
+
+
+def test_g21_sub_env_follows_the_reference_step_by_step(km):
+    from parc_amd import _hip
+    from parc_amd.envs import base_env
+    from parc_amd.util import torch_util
+    g = golden("g21_mgdm")
+    cfg, core, mg, gen, rnd = _make_sub_env(g, km)
+    N, B, D = core.N, km.get_num_joints(), km.get_dof_size()
+    dt = 1.0 / 30.0
+    tar_steps = torch.tensor(g["tar_obs_steps"], device=DEV)
+    rb = core.rigid_body_state.view(N, B, 13)
+
+    def take_need():
+        need = mg._need_refresh.clone()
+        mg._need_refresh[:] = False
+        return need
+    mg.replan()                                           # IGParkourEnv construction (ig_parkour_env.py:796-798)
+    _check_snapshot(g, "init", core, mg, gen, rnd, take_need())
+    mg.reset(torch.arange(N, device=DEV))                 # the agent's first reset: a soft reset of every env
+    _check_snapshot(g, "reset0", core, mg, gen, rnd, take_need())
+    seen = set()
+    for k in range(int(g["num_steps"][0])):
+        tag = "s%d" % k
+        mg.pre_physics_step()
+        # the recorded "physics"
+        mg._char_root_pos[:] = T(g[tag + "_in_char_root_pos"])
+        mg._char_root_rot[:] = T(g[tag + "_in_char_root_rot"])
+        mg._char_root_vel[:] = T(g[tag + "_in_char_root_vel"])
+        mg._char_root_ang_vel[:] = T(g[tag + "_in_char_root_ang_vel"])
+        mg._char_dof_pos[:] = T(g[tag + "_in_char_dof_pos"])
+        mg._char_dof_vel[:] = T(g[tag + "_in_char_dof_vel"])
+        bp, br = km.forward_kinematics(mg._char_root_pos.contiguous(), mg._char_root_rot.contiguous(), km.dof_to_rot(mg._char_dof_pos.contiguous()))
+        close(bp, g[tag + "_in_char_rigid_body_pos"], atol=3e-5, rtol=0)
+        rb[..., 0:3] = T(g[tag + "_in_char_rigid_body_pos"])
+        rb[..., 3:7] = br
+        mg._char_contact_forces[:] = T(g[tag + "_in_char_contact_forces"])
+        core.timestep_buf += 1
+        torch.mul(core.timestep_buf, dt, out=core.time_buf)
+        mg.update_time(dt)
+        mg.update_misc()
+        mg._update_ref_motion()
+        tar = mg.compute_tar_obs(tar_steps)
+        for got, name in zip(tar, ("tar_root_pos", "tar_root_rot", "tar_joint_rot", "tar_key_pos", "tar_contacts")):
+            # (joint rotations: slerp between nearly equal frames switches formula at sin(half angle) < 1e-3, a few 1e-4 either side)
+            close(got, g[tag + "_" + name], atol=3e-4 if name in ("tar_joint_rot", "tar_key_pos") else 5e-5, rtol=0)
+        mg.refresh_obs_hfs(mg._char_root_pos + mg._env_offsets, torch_util.calc_heading(mg._char_root_rot))
+        close(mg._mgdm_hfs, g[tag + "_mgdm_hfs"], atol=3e-5, rtol=0)
+        close(mg._mgdm_floor_heights, g[tag + "_floor"], atol=0, rtol=0)
+        mg._post(_hip.POST_OBS | _hip.POST_HF)                                 # the ray fan is part of the fused launch
+        # heights are piecewise constant in the query point: a ray point within rounding of a cell border may read the neighbour
+        ray_err = (core.ray_hfs.cpu().numpy() - g[tag + "_ray_hfs"])
+        assert (np.abs(ray_err) > 3e-5).mean() < 0.02, (tag, (np.abs(ray_err) > 3e-5).mean())
+        mg.update_done()
+        want = g[tag + "_done_after_update"]
+        assert np.array_equal(core.done.cpu().numpy(), want), (tag, core.done.tolist(), want.tolist())
+        assert np.array_equal(mg._replan_buf.cpu().numpy(), g[tag + "_replan_buf_after_update"]), tag
+        assert int(mg._replan_flag) == int(g[tag + "_replan_flag_after_update"][0]), tag
+        seen |= {(int(d), int(f)) for d, f in zip(want, [int(g[tag + "_replan_flag_after_update"][0])] * N)}
+        ids = (core.done != base_env.DoneFlags.NULL.value).nonzero().flatten()
+        mg.reset(ids)
+        _check_snapshot(g, tag, core, mg, gen, rnd, take_need())
+    # the fixture reaches failure, walking off the terrain (TIME without a replan pending), and the replan-time TIME
+    assert {(1, 0), (3, 0), (3, 1), (0, 1)} <= seen, seen
+    assert rnd.k == int(g["num_rand"][0]) and gen.k == int(g["num_gen"][0]) == 4
+
+
+class WalkGenerator:
+    """A deterministic stand-in planner for end-to-end runs: from the last previous frame, walk towards the target at 1 m/s keeping the
+    pose, root height = floor + 0.9."""
+    _num_prev_states, _sequence_fps = 2, 30
+    _dx = _dy = 0.4
+    _num_x_neg, _num_x_pos, _num_y_neg, _num_y_pos = 2, 5, 3, 3
+    F = 45
+    calls = 0
+
+    def __call__(self, target_xy, prev_frames, terrain, char_model, settings):
+        from parc_amd.util import terrain_util
+        from parc_amd.util.motion_util import MotionFrames
+        WalkGenerator.calls += 1
+        F = self.F
+        p, q, j = prev_frames.root_pos[:, -1], prev_frames.root_rot[:, -1], prev_frames.joint_rot[:, -1]
+        n = p.shape[0]
+        d = target_xy[:, 0:2] - p[:, 0:2]
+        d = d / torch.linalg.vector_norm(d, dim=-1, keepdim=True).clamp(min=1e-3)
+        tt = torch.arange(F, dtype=torch.float32, device=p.device).reshape(1, F, 1) / 30.0
+        rp = p.unsqueeze(1).repeat(1, F, 1)
+        rp[..., 0:2] += tt * d.unsqueeze(1)
+        return MotionFrames(root_pos=rp, root_rot=q.unsqueeze(1).repeat(1, F, 1), joint_rot=j.unsqueeze(1).repeat(1, F, 1, 1),
+                            contacts=torch.zeros((n, F, char_model.get_num_joints()), device=p.device))
+
+
+@pytest.mark.parametrize("fraction", [0.5, 0.0])
+def test_env_with_both_sub_envs(fraction):
+    """IGParkourEnv with fraction_dm_envs < 1 through the agent-style loop: dataset rows keep their clips and tile offsets, generator rows
+    follow their plans (clip id = row, clip time = plan clock), replans happen on schedule, counters and episode bookkeeping move."""
+    from parc_amd import workloads
+    from parc_amd.envs import base_env
+    N = 64
+    WalkGenerator.calls = 0
+    mg_cfg = {"plan_length": 0.5, "ddim_stride": 50, "max_replans": 3, "cfg_scale": 0.7, "target_dist_max": 4.0, "target_dist_min": 1.0,
+              "target_dur_max": 2.0, "target_dur_min": 1.0, "target_heading_scale": 0.5, "generator": WalkGenerator(),
+              "heightmap": {"horizontal_scale": 0.4, "sq_m_per_env": 0.5, "safety_region": 3.0, "num_segments": 6, "platform_heights": [0.0]}}
+    env, _, _ = workloads.build_env("boxes_64clips", N, DEV, seed=3, env_overrides={"fraction_dm_envs": fraction, "mgdm": mg_cfg, "enable_replan_timer_obs": False})
+    n_dm = env._num_dm_envs
+    assert n_dm == int(fraction * N) and env.has_mgdm_envs() and env.has_dm_envs() == (n_dm > 0)
+    assert not env.supports_device_reset() and not env.supports_graph_step()
+    mg = env.get_mgdm_env()
+    assert WalkGenerator.calls == 1                                    # plans exist before the first observation
+    obs, info = env.reset()
+    assert obs.shape == (N, env._cfg.obs_dim) and torch.isfinite(obs).all()
+    low, high = env._action_bound_low, env._action_bound_high
+    torch.manual_seed(0)
+    replans, total_done = 0, 0
+    for it in range(40):
+        plan_before = float(mg._plan_time_host)
+        a = env._ref_dof_pos.clone()                                   # PD target = the reference pose: a sensible controller
+        obs, r, done, info = env.step(torch.minimum(torch.maximum(a, low), high))
+        assert torch.isfinite(obs).all() and torch.isfinite(r).all()
+        # generator rows: reference pose = their plan at the plan clock
+        rp = mg._motion_lib.calc_motion_frame(mg._motion_ids, mg._mgdm_time_buf.expand(N - n_dm))[0]
+        assert (env._ref_root_pos[n_dm:] - rp).abs().max() < 1e-4
+        assert abs(float(mg._plan_time_host) - (plan_before + 1.0 / 30.0)) < 1e-5
+        ids = (done != base_env.DoneFlags.NULL.value).nonzero().flatten()
+        total_done += int(ids.numel())
+        calls = WalkGenerator.calls
+        env.reset(ids)
+        if WalkGenerator.calls > calls:
+            replans += 1
+            assert float(mg._plan_time_host) == np.float32(1.0 / 30.0) and not mg._replan_flag
+            assert (mg._replan_counter >= 1).all() and (mg._replan_counter <= mg_cfg["max_replans"]).all()
+        assert (env._done_buf[ids] == 0).all() if len(ids) else True
+    assert replans == 2, replans                                        # plan_length 0.5 s at 30 Hz: after steps 15 and 30
+    assert env.get_replan_counter().shape == (N,) and (env.get_replan_counter()[:n_dm] == 0).all()
+    assert float(env.get_replan_time_buf()[0]) == float(mg._plan_time_host)
+    if n_dm > 0:
+        dm = env.get_dm_env()
+        assert (env._core.motion_ids[:n_dm] < dm._motion_lib.num_motions()).all()
+        assert (env._core.motion_ids[n_dm:] == torch.arange(N - n_dm, device=DEV)).all()
+        assert dm._motion_id_fail_rates.shape[0] == dm._motion_lib.num_motions() and torch.isfinite(dm._motion_id_fail_rates).all()
