@@ -252,3 +252,31 @@ def test_env_with_both_sub_envs(fraction):
         assert (env._core.motion_ids[:n_dm] < dm._motion_lib.num_motions()).all()
         assert (env._core.motion_ids[n_dm:] == torch.arange(N - n_dm, device=DEV)).all()
         assert dm._motion_id_fail_rates.shape[0] == dm._motion_lib.num_motions() and torch.isfinite(dm._motion_id_fail_rates).all()
+
+
+def test_agent_trains_on_an_env_with_generator_rows():
+    """The PPO agent on a split env: it steps such an env eagerly (no rollout graph: the sub-env takes host decisions), records the replan
+    timer / counter columns the reference's agent records for this env (dm_ppo_agent.py:278), and a training iteration goes through."""
+    from parc_amd import workloads
+    N = 32
+    WalkGenerator.calls = 0
+    mg_cfg = {"plan_length": 0.2, "ddim_stride": 50, "max_replans": 3, "cfg_scale": 0.7, "target_dist_max": 4.0, "target_dist_min": 1.0,
+              "target_dur_max": 2.0, "target_dur_min": 1.0, "target_heading_scale": 0.5, "generator": WalkGenerator(),
+              "heightmap": {"horizontal_scale": 0.4, "sq_m_per_env": 0.5, "safety_region": 3.0, "num_segments": 6, "platform_heights": [0.0, 0.4]}}
+    env, _, _ = workloads.build_env("boxes_64clips", N, DEV, seed=5, env_overrides={"fraction_dm_envs": 0.5, "mgdm": mg_cfg,
+                                                                                   "enable_replan_timer_obs": False})
+    agent = workloads.build_agent(env, DEV, steps_per_iter=16, update_epochs=1, batch_size=2)
+    assert not agent._graph_ok() or agent._mode.name != "TRAIN"
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    assert not agent._graph_ok()
+    w0 = agent._model._actor_layers[0].weight.clone()
+    info = agent._train_iter()
+    assert np.isfinite(info["critic_loss"].item()) and np.isfinite(info["actor_loss"].item())
+    assert not torch.equal(w0, agent._model._actor_layers[0].weight)
+    assert WalkGenerator.calls >= 3                                     # construction + a replan every 0.2 s = 6 steps
+    eb = agent._exp_buffer
+    rc = eb.get_data("replan_counter")
+    assert rc.shape[-1] == N and (rc[:, :16] == 0).all() and (rc[:, 16:] >= 1).all()
+    rt = eb.get_data("replan_timer")
+    assert float(rt.max()) <= 0.2 + 2.0 / 30.0 + 1e-6 and float(rt.min()) >= 1.0 / 30.0 - 1e-6
