@@ -107,3 +107,26 @@ def test_bench_two_ranks_from_a_plain_invocation():
         bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--envs", "64", "--steps", "1"],
                              capture_output=True, text=True, env=env, timeout=300)
         assert bad.returncode != 0 and bad.stdout.strip() == ""
+
+
+def test_collectives_on_the_real_backend_with_one_rank():
+    """RCCL itself (torch.distributed "nccl"), world size 1, the package's multi-process switch forced on inside the probe: every
+    collective of the data-parallel path (bucketed asynchronous all-reduce of gradient views started from gradient callbacks, the
+    per-epoch averaging of flat parameters / momentum, broadcasts, MIN reductions) runs on the backend the 8-GPU job will use, and the
+    result equals the single-process run exactly (a mean over one rank is the identity).  tools/rccl_probe.py"""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PARC_DIST_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29731", os.path.join(REPO, "tools", "rccl_probe.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    for cadence in ("minibatch", "epoch"):
+        r = res[cadence]
+        assert r["finite"] and r["synced"] and r["max_abs_diff"] == 0.0 and r["loss"] == r["loss_single"], (cadence, r)
+    assert res["minibatch"]["overlap"] and res["minibatch"]["buckets"] >= 2
+    assert res["helpers"] == {"broadcast": True, "sum": True, "min": 3.5, "mean": True}
