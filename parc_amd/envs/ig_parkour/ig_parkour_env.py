@@ -52,8 +52,8 @@ class IGParkourEnv(base_env.BaseEnv):
         self._fraction_dm_envs = env_config["fraction_dm_envs"]
         self._num_dm_envs = min(int(self._fraction_dm_envs * num_envs), num_envs)
         self._num_mgdm_envs = num_envs - self._num_dm_envs
-        if env_config.get("enable_replan_timer_obs", False) and self._num_mgdm_envs > 0:
-            raise NotImplementedError("enable_replan_timer_obs adds a column to the observation row the fused kernel does not write")
+        # the plan clock as one more observation column, for every row, when generator rows exist (ig_parkour_env.py:77,1227-1233)
+        self._enable_replan_timer_obs = bool(env_config.get("enable_replan_timer_obs", False)) and self._num_mgdm_envs > 0
         self._output_motion_dir = env_config.get("output_motion_dir", "output/_motions/recorded_motions/")
         self._never_done = env_config.get("never_done", False)
         self._report_tracking_error = env_config.get("report_tracking_error", False)
@@ -184,7 +184,10 @@ class IGParkourEnv(base_env.BaseEnv):
         self._reward_buf, self._done_buf = c.reward, c.done
         self._timestep_buf, self._time_buf = c.timestep_buf, c.time_buf
         self._ep_num_buf = torch.zeros(N, device=self._device, dtype=torch.int64)
-        self._obs_buf = c.obs
+        # the kernels write rows of cfg.obs_dim; with the replan-timer column the env hands out a buffer one column wider that is
+        # refreshed from them (a strided copy per step: such an env is stepped eagerly anyway)
+        self._obs_buf = c.obs if not self._enable_replan_timer_obs else torch.zeros((N, self._cfg.obs_dim + 1), dtype=torch.float32,
+                                                                                    device=self._device)
         self._ray_hfs = c.ray_hfs
         self._target_xy, self._next_target_xy_time = c.target_xy, c.next_target_xy_time
         self._info = dict()
@@ -201,7 +204,20 @@ class IGParkourEnv(base_env.BaseEnv):
         return (0.0, 1.0)
 
     def get_obs_space(self):
-        return Box(low=-np.inf, high=np.inf, shape=[self._cfg.obs_dim], dtype=np.float32)
+        return Box(low=-np.inf, high=np.inf, shape=[int(self._obs_buf.shape[1])], dtype=np.float32)
+
+    def _publish_obs(self, env_ids=None):
+        """rows the kernels just wrote -> the handed-out buffer, plan clock in the last column (only with the replan-timer column)"""
+        if not self._enable_replan_timer_obs:
+            return
+        D = self._cfg.obs_dim
+        t = self._mgdm_env.get_mgdm_time_buf()
+        if env_ids is None:
+            self._obs_buf[:, :D] = self._core.obs
+            self._obs_buf[:, D] = t
+        elif len(env_ids) > 0:
+            self._obs_buf[env_ids, :D] = self._core.obs[env_ids]
+            self._obs_buf[env_ids, D] = t
 
     def has_dm_envs(self):
         return self._num_dm_envs > 0
@@ -319,6 +335,7 @@ class IGParkourEnv(base_env.BaseEnv):
             ids = changed + self._num_dm_envs
             self._refresh_bodies(ids)
             mg._post(_hip.POST_OBS | _hip.POST_HF, changed)
+            self._publish_obs(ids)
             self._ep_num_buf[ids] += 1
 
     def _reset_dm(self, env_ids):
@@ -355,6 +372,7 @@ class IGParkourEnv(base_env.BaseEnv):
             self._refresh_bodies(env_ids)
             c.target_rand.uniform_()
             c.post_step(_hip.POST_OBS | _hip.POST_HF | _hip.POST_TARGETS, env_ids)      # + xy target resample for these envs
+            self._publish_obs(env_ids)
             self._ep_num_buf[env_ids] += 1
 
     # ------------------------------------------------------------------ device-side reset of finished envs
@@ -486,6 +504,7 @@ class IGParkourEnv(base_env.BaseEnv):
                        "parc_update_fail_rates")
         mg._post(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF)
         mg.update_done_extra()
+        self._publish_obs()
         if self._never_done:
             self._done_buf[:] = base_env.DoneFlags.NULL.value
         self._update_info(step=True)
@@ -558,6 +577,8 @@ class IGParkourEnv(base_env.BaseEnv):
             shapes["tar_contacts"] = {"use_normalizer": False, "shape": torch.Size([S, B])}
             shapes["char_contacts"] = {"use_normalizer": False, "shape": torch.Size([B])}
             shapes["hf"] = {"use_normalizer": False, "shape": torch.Size([self._ray_xy_points.shape[0]])}
+            if self._enable_replan_timer_obs:
+                shapes["replan_t"] = {"use_normalizer": False, "shape": torch.Size([1])}
             return shapes
         if self.has_mgdm_envs():
             ids = self._all_env_ids if env_ids is None else env_ids.to(torch.long)
@@ -565,6 +586,7 @@ class IGParkourEnv(base_env.BaseEnv):
             if n_dm > 0:
                 self._core.post_step(_hip.POST_OBS | _hip.POST_HF, ids[ids < n_dm])
             self._mgdm_env._post(_hip.POST_OBS | _hip.POST_HF, ids[ids >= n_dm] - n_dm)
+            self._publish_obs(env_ids)
         else:
             self._core.post_step(_hip.POST_OBS | _hip.POST_HF, env_ids)
         return self._obs_buf if env_ids is None else self._obs_buf[env_ids]

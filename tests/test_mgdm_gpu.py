@@ -204,8 +204,8 @@ class WalkGenerator:
                             contacts=torch.zeros((n, F, char_model.get_num_joints()), device=p.device))
 
 
-@pytest.mark.parametrize("fraction", [0.5, 0.0])
-def test_env_with_both_sub_envs(fraction):
+@pytest.mark.parametrize("fraction,timer", [(0.5, False), (0.0, False), (0.5, True)])
+def test_env_with_both_sub_envs(fraction, timer):
     """IGParkourEnv with fraction_dm_envs < 1 through the agent-style loop: dataset rows keep their clips and tile offsets, generator rows
     follow their plans (clip id = row, clip time = plan clock), replans happen on schedule, counters and episode bookkeeping move."""
     from parc_amd import workloads
@@ -215,14 +215,15 @@ def test_env_with_both_sub_envs(fraction):
     mg_cfg = {"plan_length": 0.5, "ddim_stride": 50, "max_replans": 3, "cfg_scale": 0.7, "target_dist_max": 4.0, "target_dist_min": 1.0,
               "target_dur_max": 2.0, "target_dur_min": 1.0, "target_heading_scale": 0.5, "generator": WalkGenerator(),
               "heightmap": {"horizontal_scale": 0.4, "sq_m_per_env": 0.5, "safety_region": 3.0, "num_segments": 6, "platform_heights": [0.0]}}
-    env, _, _ = workloads.build_env("boxes_64clips", N, DEV, seed=3, env_overrides={"fraction_dm_envs": fraction, "mgdm": mg_cfg, "enable_replan_timer_obs": False})
+    env, _, _ = workloads.build_env("boxes_64clips", N, DEV, seed=3, env_overrides={"fraction_dm_envs": fraction, "mgdm": mg_cfg, "enable_replan_timer_obs": timer})
     n_dm = env._num_dm_envs
     assert n_dm == int(fraction * N) and env.has_mgdm_envs() and env.has_dm_envs() == (n_dm > 0)
     assert not env.supports_device_reset() and not env.supports_graph_step()
     mg = env.get_mgdm_env()
     assert WalkGenerator.calls == 1                                    # plans exist before the first observation
     obs, info = env.reset()
-    assert obs.shape == (N, env._cfg.obs_dim) and torch.isfinite(obs).all()
+    assert obs.shape == (N, env._cfg.obs_dim + int(timer)) == (N, env.get_obs_space().shape[0]) and torch.isfinite(obs).all()
+    assert ("replan_t" in env._compute_obs(ret_obs_shapes=True)) == timer
     low, high = env._action_bound_low, env._action_bound_high
     torch.manual_seed(0)
     replans, total_done = 0, 0
@@ -235,6 +236,8 @@ def test_env_with_both_sub_envs(fraction):
         rp = mg._motion_lib.calc_motion_frame(mg._motion_ids, mg._mgdm_time_buf.expand(N - n_dm))[0]
         assert (env._ref_root_pos[n_dm:] - rp).abs().max() < 1e-4
         assert abs(float(mg._plan_time_host) - (plan_before + 1.0 / 30.0)) < 1e-5
+        if timer:                                                       # the plan clock is the last observation column of EVERY row
+            assert (obs[:, -1] == mg._mgdm_time_buf[0]).all() and torch.equal(obs[:, :-1], env._core.obs)
         ids = (done != base_env.DoneFlags.NULL.value).nonzero().flatten()
         total_done += int(ids.numel())
         calls = WalkGenerator.calls
@@ -263,8 +266,8 @@ def test_agent_trains_on_an_env_with_generator_rows():
     mg_cfg = {"plan_length": 0.2, "ddim_stride": 50, "max_replans": 3, "cfg_scale": 0.7, "target_dist_max": 4.0, "target_dist_min": 1.0,
               "target_dur_max": 2.0, "target_dur_min": 1.0, "target_heading_scale": 0.5, "generator": WalkGenerator(),
               "heightmap": {"horizontal_scale": 0.4, "sq_m_per_env": 0.5, "safety_region": 3.0, "num_segments": 6, "platform_heights": [0.0, 0.4]}}
-    env, _, _ = workloads.build_env("boxes_64clips", N, DEV, seed=5, env_overrides={"fraction_dm_envs": 0.5, "mgdm": mg_cfg,
-                                                                                   "enable_replan_timer_obs": False})
+    env, _, _ = workloads.build_env("boxes_64clips", N, DEV, seed=5, env_overrides={"fraction_dm_envs": 0.5, "mgdm": mg_cfg})
+    assert env._enable_replan_timer_obs and env.get_obs_space().shape[0] == env._cfg.obs_dim + 1       # the tracker config's default
     agent = workloads.build_agent(env, DEV, steps_per_iter=16, update_epochs=1, batch_size=2)
     assert not agent._graph_ok() or agent._mode.name != "TRAIN"
     agent._curr_obs, agent._curr_info = env.reset()
