@@ -615,6 +615,10 @@ class IGParkourEnv(base_env.BaseEnv):
     # Python lists on every step (a loop over all envs with device reads); here the states are scattered into device buffers
     # [steps, env, ...] with a per-env write row, and the host only touches the envs that finish (one small transfer per step).
     def build_agent_states_dict(self, name_suffix="", record_obs=False):
+        if self.has_mgdm_envs():
+            # the recorder ends a clip at its dataset motion's end (parc_4_phys_record runs all rows on dataset clips); the reference
+            # reaches this with generator rows from its viewer only (ig_parkour_env.py:329-332)
+            raise NotImplementedError("motion recording covers envs whose rows all follow dataset clips (fraction_dm_envs: 1.0)")
         obs_shapes = self._compute_obs(ret_obs_shapes=True) if record_obs else None
         self._dm_agent_motion = []
         for _ in range(self._num_envs):
