@@ -30,6 +30,7 @@ _ALIASES = {
     "learning.tracking_error_tracker": "learning.tracking_error_tracker",
     "PARC.util.create_dataset": "util.create_dataset",
     "tools.motion_opt.motion_optimization": "tools.motion_opt.motion_optimization",
+    "zmotion_editing_tools": "zmotion_editing_tools", "zmotion_editing_tools.motion_edit_lib": "zmotion_editing_tools.motion_edit_lib",
 }
 # pure namespace packages of the reference that hold nothing this path needs besides the sub-module above
 _NAMESPACES = ("PARC", "PARC.util", "tools", "tools.motion_opt")

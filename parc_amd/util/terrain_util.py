@@ -83,6 +83,15 @@ class SubTerrain:
     def get_max_point(self):
         return self.min_point + self.get_real_size() - self.dxdy
 
+    def flip_by_XZ_axis(self):
+        """mirror the field in the plane y = 0 (reference util/terrain_util.py:169-178): cells reversed along y, the new first
+        column centre is minus the old last one"""
+        max_point = self.get_max_point()
+        self.hf = torch.flip(self.hf, dims=[1])
+        self.hf_mask = torch.flip(self.hf_mask, dims=[1])
+        self.hf_maxmin = torch.flip(self.hf_maxmin, dims=[1])
+        self.min_point[1] = -1.0 * max_point[1]
+
     def get_inbounds_grid_index(self, grid_ind):
         return torch.clamp(grid_ind, torch.zeros_like(self.dims), self.dims - 1)
 

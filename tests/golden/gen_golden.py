@@ -1031,7 +1031,7 @@ def gen_recorded_files():
 
 
 STAGES = ["core", "voxel-mesh", "dataset-yaml", "procgen", "terrain-geometry", "done-branches", "ppo-loss", "normalizer", "trackers",
-          "action-head", "recorded-files", "motion-opt", "mgdm"]
+          "action-head", "recorded-files", "motion-opt", "mgdm", "motion-edit"]
 
 
 def _icosa_points(radius):
@@ -1308,6 +1308,48 @@ def gen_mgdm():
     save("g21_mgdm", **out)
 
 
+def gen_motion_edit():
+    """G22: the motion-file helpers between stage 2 and the tracker (zmotion_editing_tools/motion_edit_lib.py): flip_motion_about_XZ_plane
+    (:514-610) with SubTerrain.flip_by_XZ_axis (util/terrain_util.py:169-178) - the mirrored copy parc_2_kin_gen.py:493-511 adds for
+    every optimised clip - and remove_hesitation_frames (:1242-1319), on 60 frames of the civilization clip with two stretches of
+    near-repeated poses spliced in; MotionData / save_motion_data / load_motion_file round trip of the written file."""
+    import zmotion_editing_tools.motion_edit_lib as medit
+    rng = np.random.default_rng(22)
+    km = load_char()
+    civ = load_motion_file_safe(os.path.join(REF, "data/terrains/civilization.pkl"))
+    frames = np.asarray(civ["frames"], np.float32)[40:100].copy()
+    contacts = np.asarray(civ["contacts"], np.float32)[40:100].copy()
+    out = dict(frames=frames, contacts=contacts)
+    flipped, fcon = medit.flip_motion_about_XZ_plane(t(frames), km, contact_frames=t(contacts))
+    out.update(flip_frames=flipped, flip_contacts=fcon)
+    ter = ref_terrain_from_dict(civ["terrain"])
+    sl, _ = terrain_util.slice_terrain_around_motion(t(frames), ter, padding=0.8)
+    out.update(ter_hf=sl.hf.clone(), ter_min_point=sl.min_point.clone(), ter_dxdy=sl.dxdy.clone(), ter_mask=sl.hf_mask.clone(),
+               ter_maxmin=sl.hf_maxmin.clone())
+    sl.flip_by_XZ_axis()
+    out.update(ter_flip_hf=sl.hf, ter_flip_min_point=sl.min_point, ter_flip_mask=sl.hf_mask, ter_flip_maxmin=sl.hf_maxmin)
+    # hesitation: frames 20..27 hover around frame 19 and 45..47 around frame 44 (a run shorter than the minimum length: kept)
+    hes = frames.copy()
+    hcon = contacts.copy()
+    for k in range(20, 28):
+        hes[k] = hes[19] + rng.normal(0, 0.004, size=hes.shape[1]).astype(np.float32)
+    for k in range(45, 48):
+        hes[k] = hes[44] + rng.normal(0, 0.004, size=hes.shape[1]).astype(np.float32)
+    nf, nc = medit.remove_hesitation_frames(t(hes), t(hcon), km)
+    out.update(hes_frames=hes, hes_contacts=hcon, hes_out_frames=nf, hes_out_contacts=nc)
+    nf2, _ = medit.remove_hesitation_frames(t(hes), t(hcon), km, hesitation_val=0.3, hesitation_min_seq_len=2)
+    out["hes_out2_count"] = np.array([nf2.shape[0]])
+    # file round trip
+    tmp = tempfile.mkdtemp(prefix="parc_golden_medit_")
+    path = os.path.join(tmp, "clip.pkl")
+    ter2 = ref_terrain_from_dict(civ["terrain"])
+    medit.save_motion_data(path, t(frames), t(contacts), ter2, 30, "CLAMP", loss=1.5, min_point_offset=t([0.25, -0.5]))
+    md = medit.load_motion_file(path)
+    out.update(rt_fps=np.array([md.get_fps()]), rt_frames=md.get_frames(), rt_contacts=md.get_contacts(), rt_hf=md.get_terrain().hf,
+               rt_keys=np.array(sorted(md._data.keys())))
+    save("g22_motion_edit", **out)
+
+
 def gen_core():
     rng = np.random.default_rng(0)
     torch.manual_seed(0)
@@ -1329,7 +1371,7 @@ def main():
     run = {"core": gen_core, "voxel-mesh": lambda: gen_voxel_mesh(np.random.default_rng(10)), "dataset-yaml": gen_dataset_yaml,
            "procgen": gen_procgen, "terrain-geometry": gen_terrain_geometry, "done-branches": gen_done_branches, "ppo-loss": gen_ppo_loss,
            "normalizer": gen_normalizer, "trackers": gen_trackers, "action-head": gen_action_head, "recorded-files": gen_recorded_files,
-           "motion-opt": gen_motion_opt, "mgdm": gen_mgdm}
+           "motion-opt": gen_motion_opt, "mgdm": gen_mgdm, "motion-edit": gen_motion_edit}
     picked = [s_ for s_ in STAGES if "--only-" + s_ in sys.argv]
     if "--check" in sys.argv:
         # regenerate everything into a scratch directory and compare with the committed fixtures array by array

@@ -654,3 +654,38 @@ def test_mgdm_terrain_build_and_pose_containers_against_g21(tmp_path):
     parc_amd.install_reference_aliases()
     import util.motion_util as ref_named            # the name the reference's scripts import
     assert ref_named.MotionFrames is motion_util.MotionFrames
+
+
+def test_motion_file_helpers_against_g22(tmp_path):
+    """zmotion_editing_tools.motion_edit_lib on the host, against the reference's outputs (fixture G22): the mirrored terrain, and a
+    motion file written by save_motion_data / MotionData.save_to_file - class paths, round trip through the non-executing reader."""
+    import parc_amd
+    from parc_amd.util import terrain_util
+    from parc_amd.zmotion_editing_tools import motion_edit_lib as medit
+    g = golden("g22_motion_edit")
+    ter = terrain_util.SubTerrain.from_arrays(g["ter_hf"], g["ter_min_point"], g["ter_dxdy"], g["ter_mask"], g["ter_maxmin"], device="cpu")
+    ter.flip_by_XZ_axis()
+    np.testing.assert_array_equal(ter.hf.numpy(), g["ter_flip_hf"])
+    np.testing.assert_array_equal(ter.hf_mask.numpy(), g["ter_flip_mask"])
+    np.testing.assert_array_equal(ter.hf_maxmin.numpy(), g["ter_flip_maxmin"])
+    np.testing.assert_allclose(ter.min_point.numpy(), g["ter_flip_min_point"], atol=1e-6)
+    path = str(tmp_path / "clip.pkl")
+    ter2 = terrain_util.SubTerrain.from_arrays(g["rt_hf"], np.zeros(2, np.float32), np.array([0.4, 0.4], np.float32), device="cpu")
+    medit.save_motion_data(path, torch.tensor(g["frames"]), torch.tensor(g["contacts"]), ter2, 30, "CLAMP", loss=1.5,
+                           min_point_offset=torch.tensor([0.25, -0.5]))
+    mods = {m for m, _ in pickle_globals(path)}
+    assert ("util.terrain_util", "SubTerrain") in pickle_globals(path) and not any(m.startswith("parc_amd") for m in mods), mods
+    md = medit.load_motion_file(path)
+    assert sorted(md._data.keys()) == [str(k) for k in g["rt_keys"]]
+    assert md.get_fps() == int(g["rt_fps"][0]) and md.get_loop_mode() == "CLAMP" and md.has_terrain() and md.has_contacts()
+    np.testing.assert_array_equal(md.get_frames().numpy(), g["rt_frames"])
+    np.testing.assert_array_equal(md.get_contacts().numpy(), g["rt_contacts"])
+    np.testing.assert_array_equal(md.get_terrain().hf.numpy(), g["rt_hf"])
+    md.set_fps(29.97)
+    path2 = str(tmp_path / "clip2.pkl")
+    md.save_to_file(path2, verbose=False)
+    back = medit.load_motion_file(path2)
+    assert back.get_fps() == 29 and torch.equal(back.get_frames(), torch.tensor(g["rt_frames"]))      # int() of the value, like the reference
+    parc_amd.install_reference_aliases()
+    import zmotion_editing_tools.motion_edit_lib as by_reference_name
+    assert by_reference_name.MotionData is medit.MotionData
