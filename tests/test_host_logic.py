@@ -640,6 +640,13 @@ def test_mgdm_terrain_build_and_pose_containers_against_g21(tmp_path):
     env2.load_terrain(path)
     assert torch.equal(env2._terrain.hf, env._terrain.hf) and env2._spawn_max_x == env._spawn_max_x and env2._oob_region == env._oob_region
     assert env.get_target_dim() == 2
+    # a pickled model object is only loaded on request (the reference's load_mdm executes the file, mgdm_env.py:32-35)
+    cfg_model = json.loads(bytes(g["config_json"]).decode())
+    with pytest.raises(RuntimeError, match="unsafe_pickle"):
+        mgdm_env.MotionGenDeepMimicEnv(cfg_model, 8, "cpu", False, km)
+    cfg_model["env"]["mgdm"]["unsafe_pickle"] = True
+    with pytest.raises(ModuleNotFoundError, match="diffusion"):       # ... and then needs the reference's own diffusion package
+        mgdm_env.MotionGenDeepMimicEnv(cfg_model, 8, "cpu", False, km)
     # pose containers
     a = motion_util.MotionFrames()
     a.init_blank_frames(km, 2, batch_size=3)
