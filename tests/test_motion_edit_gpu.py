@@ -1,6 +1,5 @@
 """The two clip edits between stage 2's optimiser and the tracker's dataset (zmotion_editing_tools/motion_edit_lib.py of the reference:
 flip_motion_about_XZ_plane :514-610, remove_hesitation_frames :1242-1319) against fixture G22 (reference outputs on CPU)."""
-import numpy as np
 import pytest
 import torch
 

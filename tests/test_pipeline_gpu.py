@@ -2,12 +2,9 @@
 (parc_2_kin_gen.py:427-511 -> PARC/util/create_dataset.py -> parc_3_tracker's env): optimise a generated clip on its terrain, drop
 hesitation frames, compute the per-frame heightfield masks, save it and its mirrored copy, build the class-balanced dataset YAML with
 preprocessing, construct the tracking env from that YAML, step it."""
-import os
-
 import numpy as np
 import pytest
 import torch
-import yaml
 
 from test_hip_parity import DEV, km  # noqa: F401  (km is a fixture)
 
