@@ -111,13 +111,11 @@ def compute_approx_body_constraints(root_pos, root_rot, joint_rot, contacts, cha
             off = _f32(char_model.get_geoms(b)[0]._offset, body_pos.device)
             pos[n] = pos[n] + torch_util.quat_rotate(body_rot[:, b], off.unsqueeze(0).expand(body_pos.shape[0], 3))
     out = [[] for _ in range(char_model.get_num_joints())]
-    for n, b in ids.items():
-        runs = _consecutive_true_runs(contacts[:, b] > 0.9)
-        if not runs:
-            continue
-        pts = torch.stack([pos[n][r].mean(dim=0) for r in runs])
-        pts = _project_points_to_surface(pts, terrain)
-        for k, r in enumerate(runs):
+    # every run of every body becomes one point; all of them descend together (independent terms of one objective)
+    todo = [(b, r, pos[n][r].mean(dim=0)) for n, b in ids.items() for r in _consecutive_true_runs(contacts[:, b] > 0.9)]
+    if todo:
+        pts = _project_points_to_surface(torch.stack([p for _, _, p in todo]), terrain)
+        for k, (b, r, _) in enumerate(todo):
             c = BodyConstraint()
             c.start_frame_idx = r[0].item()
             c.end_frame_idx = r[-1].item()
