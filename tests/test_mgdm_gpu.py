@@ -204,7 +204,7 @@ class WalkGenerator:
                             contacts=torch.zeros((n, F, char_model.get_num_joints()), device=p.device))
 
 
-@pytest.mark.parametrize("fraction,timer", [(0.5, False), (0.0, False), (0.5, True)])
+@pytest.mark.parametrize("fraction,timer", [(0.5, False), (0.0, False), (0.5, True), (0.3, False)])   # 0.3: 19 + 45 rows, nothing aligned
 def test_env_with_both_sub_envs(fraction, timer):
     """IGParkourEnv with fraction_dm_envs < 1 through the agent-style loop: dataset rows keep their clips and tile offsets, generator rows
     follow their plans (clip id = row, clip time = plan clock), replans happen on schedule, counters and episode bookkeeping move."""
