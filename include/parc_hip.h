@@ -162,6 +162,17 @@ int parc_rot_to_dof(void *stream, parc_char_model_t model, int n, const float *j
 int parc_forward_kinematics(void *stream, parc_char_model_t model, int n, const float *root_pos, const float *root_rot,
                             const float *joint_rot, float *body_pos, float *body_rot);
 
+/* The pose chain of a batch of frames and its adjoint (what stage 2's motion optimiser differentiates: util/torch_util.py:414-419
+ * exp_map_to_quat, anim/kin_char_model.py:478-541 dof_to_rot + forward_kinematics, tools/motion_opt/motion_optimization.py:203-213).
+ * forward: root_pos [n,3], root_exp [n,3] (exponential map), dof [n,D] -> root_quat [n,4], joint_rot [n,J,4], body_pos [n,B,3],
+ * body_rot [n,B,4].  backward: the cotangents of those four outputs -> g_root_pos [n,3], g_root_exp [n,3], g_dof [n,D] (overwritten).
+ * Bodies must be stored parents-first (MJCF depth-first order). */
+int parc_pose_chain_forward(void *stream, parc_char_model_t model, int n, const float *root_pos, const float *root_exp, const float *dof,
+                            float *root_quat, float *joint_rot, float *body_pos, float *body_rot);
+int parc_pose_chain_backward(void *stream, parc_char_model_t model, int n, const float *root_exp, const float *dof,
+                             const float *g_root_quat, const float *g_joint_rot, const float *g_body_pos, const float *g_body_rot,
+                             float *g_root_pos, float *g_root_exp, float *g_dof);
+
 /* ---- K3: MotionLib.calc_motion_frame  anim/motion_lib.py:80-112 (contact_info=True)
  * outputs AoS: root_pos[Q,3] root_rot[Q,4] root_vel[Q,3] root_ang_vel[Q,3] joint_rot[Q,J,4] dof_vel[Q,D] contacts[Q,B] */
 int parc_calc_motion_frame(void *stream, parc_motion_lib_t mlib, int n_queries, const int64_t *motion_ids,

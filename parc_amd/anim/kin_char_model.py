@@ -401,8 +401,46 @@ class KinCharModel:
             rot = rot.index_copy(-2, bodies, torch_util.quat_mul_compact(prot, local[..., bodies - 1, :]))
         return pos, rot
 
+    def pose_chain(self, root_pos, root_exp, dof):
+        """(root position [T, 3], root exponential map [T, 3], joint dofs [T, D]) -> (root quaternion [T, 4], joint rotations [T, J, 4],
+        body positions [T, B, 3], body rotations [T, B, 4]), differentiable: forward and vector-Jacobian product are one HIP launch each
+        (parc_pose_chain_forward / _backward) instead of the ~190 autograd nodes of exp_map_to_quat + dof_to_rot_torch +
+        forward_kinematics_torch, whose values and gradients they reproduce."""
+        return _PoseChain.apply(self, root_pos, root_exp, dof)
+
     def apply_joint_dof_limits(self, joint_dofs):
         return torch.minimum(torch.maximum(joint_dofs, self._lower_dof_limits), self._upper_dof_limits)
+
+
+class _PoseChain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, km, root_pos, root_exp, dof):
+        B, D = km.get_num_joints(), km.get_dof_size()
+        n = int(root_pos.shape[0])
+        assert root_pos.shape == (n, 3) and root_exp.shape == (n, 3) and dof.shape == (n, D)
+        rp, re, dd = (t.detach().to(torch.float32).contiguous() for t in (root_pos, root_exp, dof))
+        dev = rp.device
+        rq = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        jr = torch.empty((n, B - 1, 4), dtype=torch.float32, device=dev)
+        bp = torch.empty((n, B, 3), dtype=torch.float32, device=dev)
+        br = torch.empty((n, B, 4), dtype=torch.float32, device=dev)
+        _hip.check(_hip.lib().parc_pose_chain_forward(_hip.stream(), km.c_struct(), n, _hip.ptr(rp), _hip.ptr(re), _hip.ptr(dd), _hip.ptr(rq),
+                                                      _hip.ptr(jr), _hip.ptr(bp), _hip.ptr(br)), "parc_pose_chain_forward")
+        ctx.km = km
+        ctx.save_for_backward(re, dd)
+        return rq, jr, bp, br
+
+    @staticmethod
+    def backward(ctx, g_rq, g_jr, g_bp, g_br):
+        km = ctx.km
+        re, dd = ctx.saved_tensors
+        n = int(re.shape[0])
+        g = [x.to(torch.float32).contiguous() for x in (g_rq, g_jr, g_bp, g_br)]
+        g_rp, g_re, g_dd = torch.empty_like(re), torch.empty_like(re), torch.empty_like(dd)
+        _hip.check(_hip.lib().parc_pose_chain_backward(_hip.stream(), km.c_struct(), n, _hip.ptr(re), _hip.ptr(dd), _hip.ptr(g[0]), _hip.ptr(g[1]),
+                                                       _hip.ptr(g[2]), _hip.ptr(g[3]), _hip.ptr(g_rp), _hip.ptr(g_re), _hip.ptr(g_dd)),
+                   "parc_pose_chain_backward")
+        return None, g_rp, g_re, g_dd
 
 
 def default_char_file():

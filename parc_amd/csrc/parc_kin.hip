@@ -599,6 +599,161 @@ extern "C" int parc_forward_kinematics(void *stream, parc_char_model_t model, in
 }
 
 // =============================================================================================
+// Pose chain with its adjoint, one thread per frame: (root position, root exponential map, joint dofs) -> root quaternion, joint
+// rotations, body positions / rotations, and the vector-Jacobian product back.  This is what stage 2's motion optimiser
+// differentiates thousands of times per clip (tools/motion_opt/motion_optimization.py:203-213: exp_map_to_quat, KinCharModel.dof_to_rot,
+// forward_kinematics and their autograd); as torch ops it is ~190 autograd nodes per evaluation, here two launches.
+// Forward uses the library-precision maps (the values torch computes); the adjoint is exact for those formulas:
+//   q = a (x) b  bilinear          =>  g_a = g (x) conj(b),  g_b = conj(a) (x) g
+//   r = v + w t + u x t, t = 2 u x v  =>  g_w = g.t,  g_t = w g + g x u,  g_u = t x g + 2 v x g_t
+//   q = unit(n(axis) sin h, cos h), h = angle / 2   (torch_util.axis_angle_to_quat: both normalisations are projections at unit length)
+// =============================================================================================
+struct aa_grad { v3 g_axis; float g_angle; };
+
+PARC_DEV aa_grad axis_angle_to_quat_bwd(v3 axis, float angle, q4 q, q4 g) {
+    // through quat_unit: q = raw / |raw| with |raw| = 1 up to rounding -> g_raw = g - (g.q) q
+    const float gq = g.x * q.x + g.y * q.y + g.z * q.z + g.w * q.w;
+    const q4 gr = q4{g.x - gq * q.x, g.y - gq * q.y, g.z - gq * q.z, g.w - gq * q.w};
+    const float h = 0.5f * angle;
+    const float sh = sinf(h), ch = cosf(h);
+    const float na = fmaxf(sqrtf(dot3(axis, axis)), 1e-9f);
+    const v3 a = mk3(axis.x / na, axis.y / na, axis.z / na);
+    const v3 grv = mk3(gr.x, gr.y, gr.z);
+    aa_grad o;
+    o.g_angle = 0.5f * (ch * dot3(a, grv) - sh * gr.w);
+    // through normalize(axis): g_axis = (I - a a^T) (sin h g_v) / |axis|
+    const v3 ga = mk3(sh * grv.x, sh * grv.y, sh * grv.z);
+    const float gaa = dot3(ga, a);
+    o.g_axis = mk3((ga.x - gaa * a.x) / na, (ga.y - gaa * a.y) / na, (ga.z - gaa * a.z) / na);
+    return o;
+}
+
+// torch_util.exp_map_to_quat = axis_angle_to_quat(e / |e|, wrap(|e|)), z axis / angle 0 below 1e-5 (that branch is constant)
+PARC_DEV v3 exp_map_to_quat_bwd(v3 em, q4 q, q4 g) {
+    const float raw = sqrtf((em.x * em.x + em.y * em.y) + em.z * em.z);
+    const float ang = atan2f(sinf(raw), cosf(raw));
+    if (!(fabsf(ang) > 1e-5f)) return mk3(0.f, 0.f, 0.f);
+    const v3 a = mk3(em.x / raw, em.y / raw, em.z / raw);
+    const aa_grad ag = axis_angle_to_quat_bwd(a, ang, q, g);
+    // axis = e / raw: J^T g = (g - (g.a) a) / raw;  angle = wrap(raw): d/de = a
+    const float ga = dot3(ag.g_axis, a);
+    return mk3((ag.g_axis.x - ga * a.x) / raw + ag.g_angle * a.x, (ag.g_axis.y - ga * a.y) / raw + ag.g_angle * a.y,
+               (ag.g_axis.z - ga * a.z) / raw + ag.g_angle * a.z);
+}
+
+PARC_DEV q4 qadd(q4 a, q4 b) { return q4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+
+__global__ __launch_bounds__(64) void pose_chain_fwd_kernel(parc_char_model_t m, int n, const float *__restrict__ root_pos,
+                                                            const float *__restrict__ root_exp, const float *__restrict__ dof,
+                                                            float *root_quat, float *joint_rot, float *body_pos, float *body_rot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int B = m.num_bodies;
+    q4 rot[PARC_MAX_BODIES];
+    v3 pos[PARC_MAX_BODIES];
+    rot[0] = exp_map_to_quat_lib(ld3(root_exp + 3 * (size_t)i));
+    pos[0] = ld3(root_pos + 3 * (size_t)i);
+    st4(root_quat + 4 * (size_t)i, rot[0]);
+    const float *d = dof + (size_t)i * m.dof_size;
+    for (int b = 1; b < B; ++b) {
+        const int p = m.parent[b];
+        const q4 jq = joint_dof_to_rot<true>(m, b, d, 1);
+        st4(joint_rot + ((size_t)i * (B - 1) + (b - 1)) * 4, jq);
+        const q4 loc = quat_mul(mk4(m.local_rotation[b][0], m.local_rotation[b][1], m.local_rotation[b][2], m.local_rotation[b][3]), jq);
+        rot[b] = quat_mul(rot[p], loc);
+        pos[b] = pos[p] + quat_rotate(rot[p], mk3(m.local_translation[b][0], m.local_translation[b][1], m.local_translation[b][2]));
+    }
+    for (int b = 0; b < B; ++b) {
+        st3(body_pos + ((size_t)i * B + b) * 3, pos[b]);
+        st4(body_rot + ((size_t)i * B + b) * 4, rot[b]);
+    }
+}
+
+__global__ __launch_bounds__(64) void pose_chain_bwd_kernel(parc_char_model_t m, int n, const float *__restrict__ root_exp,
+                                                            const float *__restrict__ dof, const float *__restrict__ g_root_quat,
+                                                            const float *__restrict__ g_joint_rot, const float *__restrict__ g_body_pos,
+                                                            const float *__restrict__ g_body_rot, float *g_root_pos, float *g_root_exp,
+                                                            float *g_dof) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int B = m.num_bodies;
+    q4 rot[PARC_MAX_BODIES], jq[PARC_MAX_BODIES], loc[PARC_MAX_BODIES], grot[PARC_MAX_BODIES];
+    v3 gpos[PARC_MAX_BODIES];
+    const v3 em = ld3(root_exp + 3 * (size_t)i);
+    const float *d = dof + (size_t)i * m.dof_size;
+    float *gd = g_dof + (size_t)i * m.dof_size;
+    for (int k = 0; k < m.dof_size; ++k) gd[k] = 0.f;
+    rot[0] = exp_map_to_quat_lib(em);
+    for (int b = 1; b < B; ++b) {
+        jq[b] = joint_dof_to_rot<true>(m, b, d, 1);
+        loc[b] = quat_mul(mk4(m.local_rotation[b][0], m.local_rotation[b][1], m.local_rotation[b][2], m.local_rotation[b][3]), jq[b]);
+        rot[b] = quat_mul(rot[m.parent[b]], loc[b]);
+    }
+    for (int b = 0; b < B; ++b) {
+        gpos[b] = ld3(g_body_pos + ((size_t)i * B + b) * 3);
+        grot[b] = ld4(g_body_rot + ((size_t)i * B + b) * 4);
+    }
+    for (int b = B - 1; b >= 1; --b) {          // children before parents: a body's index exceeds its parent's
+        const int p = m.parent[b];
+        // pos[b] = pos[p] + rotate(rot[p], t_b)
+        gpos[p] = gpos[p] + gpos[b];
+        {
+            const v3 v = mk3(m.local_translation[b][0], m.local_translation[b][1], m.local_translation[b][2]);
+            const q4 q = rot[p];
+            const v3 u = mk3(q.x, q.y, q.z), g = gpos[b];
+            const v3 t = 2.f * cross3(u, v);
+            const v3 gxu = cross3(g, u);
+            const v3 gt = mk3(q.w * g.x + gxu.x, q.w * g.y + gxu.y, q.w * g.z + gxu.z);
+            const v3 gu = cross3(t, g) + 2.f * cross3(v, gt);
+            grot[p] = qadd(grot[p], q4{gu.x, gu.y, gu.z, dot3(g, t)});
+        }
+        // rot[b] = rot[p] (x) loc[b]
+        grot[p] = qadd(grot[p], quat_mul(grot[b], quat_conj(loc[b])));
+        const q4 gloc = quat_mul(quat_conj(rot[p]), grot[b]);
+        // loc[b] = lrot (x) jq[b], + the cotangent handed in for the joint rotation itself
+        const q4 lr = mk4(m.local_rotation[b][0], m.local_rotation[b][1], m.local_rotation[b][2], m.local_rotation[b][3]);
+        const q4 gj = qadd(quat_mul(quat_conj(lr), gloc), ld4(g_joint_rot + ((size_t)i * (B - 1) + (b - 1)) * 4));
+        const int jt = m.joint_type[b], d0 = m.dof_idx[b];
+        if (jt == PARC_JOINT_HINGE) {
+            const v3 ax = mk3(m.joint_axis[b][0], m.joint_axis[b][1], m.joint_axis[b][2]);
+            gd[d0] = axis_angle_to_quat_bwd(ax, d[d0], jq[b], gj).g_angle;
+        } else if (jt == PARC_JOINT_SPHERICAL) {
+            const v3 ge = exp_map_to_quat_bwd(mk3(d[d0], d[d0 + 1], d[d0 + 2]), jq[b], gj);
+            gd[d0] = ge.x;
+            gd[d0 + 1] = ge.y;
+            gd[d0 + 2] = ge.z;
+        }
+    }
+    st3(g_root_pos + 3 * (size_t)i, gpos[0]);
+    st3(g_root_exp + 3 * (size_t)i, exp_map_to_quat_bwd(em, rot[0], qadd(grot[0], ld4(g_root_quat + 4 * (size_t)i))));
+}
+
+extern "C" int parc_pose_chain_forward(void *stream, parc_char_model_t model, int n, const float *root_pos, const float *root_exp,
+                                       const float *dof, float *root_quat, float *joint_rot, float *body_pos, float *body_rot) {
+    if (n < 0 || !model_ok(model)) return PARC_EINVAL;
+    for (int b = 1; b < model.num_bodies; ++b)
+        if (model.parent[b] < 0 || model.parent[b] >= b) return PARC_EUNSUPPORTED;      // the sweeps rely on parents-first order
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(pose_chain_fwd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, model, n, root_pos, root_exp, dof, root_quat,
+                       joint_rot, body_pos, body_rot);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+extern "C" int parc_pose_chain_backward(void *stream, parc_char_model_t model, int n, const float *root_exp, const float *dof,
+                                        const float *g_root_quat, const float *g_joint_rot, const float *g_body_pos, const float *g_body_rot,
+                                        float *g_root_pos, float *g_root_exp, float *g_dof) {
+    if (n < 0 || !model_ok(model)) return PARC_EINVAL;
+    for (int b = 1; b < model.num_bodies; ++b)
+        if (model.parent[b] < 0 || model.parent[b] >= b) return PARC_EUNSUPPORTED;
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(pose_chain_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, model, n, root_exp, dof, g_root_quat,
+                       g_joint_rot, g_body_pos, g_body_rot, g_root_pos, g_root_exp, g_dof);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+// =============================================================================================
 // Fused post-physics pass.  A pose (simulated character, reference at t, 6 targets at t+dt_s) is handled by a
 // 16-lane group, lane b = body b; the observation rows are assembled in LDS and written with float4 stores.
 // =============================================================================================

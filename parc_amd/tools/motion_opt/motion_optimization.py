@@ -8,8 +8,8 @@ call it unchanged.  What differs is the mechanics:
 * all 15 bodies' sample points go through the terrain query together: two launches of ``parc_points_hf_sdf`` per evaluation (inside /
   outside distance) over ``[frames x points]`` instead of 30 calls that each materialise ``[points, cells, 3]`` temporaries; the
   kernel reports the arg-min column, and autograd sees the distance to that one column only (terrain_util.points_hf_sdf);
-* the pose maps are the level-batched torch versions of the tracker's kinematics (KinCharModel.dof_to_rot_torch /
-  forward_kinematics_torch), one composition per tree level instead of one per body;
+* the pose chain (exponential maps -> quaternions -> forward kinematics) and its adjoint are one HIP launch each
+  (KinCharModel.pose_chain: parc_pose_chain_forward / _backward) instead of ~190 autograd nodes per evaluation;
 * nothing in an iteration reads the device back (the reference takes nine ``.item()`` per iteration for its loss dict); the terms
   are read at the logging stride only, so a whole iteration (forward, backward, Adam) is captured ONCE in a hipGraph and replayed.
 
@@ -200,11 +200,10 @@ class _Problem:
         s_rp, s_rq, s_jr, s_bv, s_brv = self.src
         zero = tgt_root_pos.new_zeros(())
         root_pos_loss = torch.sum(torch.square(tgt_root_pos - s_rp))
-        tgt_rq = torch_util.exp_map_to_quat(tgt_root_rot)
+        # root quaternion, joint rotations and every body's pose in one launch, with a one-launch adjoint (KinCharModel.pose_chain)
+        tgt_rq, tgt_jr, body_pos, body_rot = km.pose_chain(tgt_root_pos, tgt_root_rot, tgt_joint_dof)
         root_rot_loss = torch.sum(torch.square(_diff_angle(tgt_rq, s_rq)))
-        tgt_jr = km.dof_to_rot_torch(tgt_joint_dof)
         joint_rot_loss = torch.sum(torch.square(_diff_angle(tgt_jr, s_jr)))
-        body_pos, body_rot = km.forward_kinematics_torch(tgt_root_pos, tgt_rq, tgt_jr)
         body_vels = body_pos[1:] - body_pos[:-1]
         vel_err_sq = torch.square(body_vels - s_bv)
         rot_vel_err_sq = torch.square(_diff_angle(body_rot[1:], body_rot[:-1]) - s_brv)

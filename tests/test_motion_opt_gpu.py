@@ -118,3 +118,36 @@ def test_g20_descent_follows_the_reference(km):
         traces[use_graph] = got
     # the replayed graph is the same computation as the eager launches
     assert np.abs(traces[True] - traces[False]).max() <= 2e-3 * ref[0], np.abs(traces[True] - traces[False]).max()
+
+
+def test_pose_chain_kernels_equal_the_torch_chain(km):
+    """parc_pose_chain_forward / _backward against exp_map_to_quat + dof_to_rot_torch + forward_kinematics_torch and their autograd:
+    values, and the vector-Jacobian product for random cotangents on all four outputs (incl. wrapped angles > pi and a near-zero map)."""
+    from parc_amd.util import torch_util
+    torch.manual_seed(4)
+    n, D = 96, km.get_dof_size()
+    rp = torch.randn((n, 3), device=DEV)
+    re = 0.8 * torch.randn((n, 3), device=DEV)
+    dof = 0.7 * torch.randn((n, D), device=DEV)
+    re[0] = torch.tensor([0.0, 0.0, 4.0])            # angle beyond pi: wrapped
+    re[1] = torch.tensor([2e-6, 0.0, 1e-6])          # below the small-angle threshold: identity, zero gradient
+    dof[2, 0:3] = torch.tensor([3.5, 0.2, -0.1])
+    ins = [x.clone().requires_grad_(True) for x in (rp, re, dof)]
+    ref_in = [x.clone().requires_grad_(True) for x in (rp, re, dof)]
+    out = km.pose_chain(*ins)
+    rq = torch_util.exp_map_to_quat(ref_in[1])
+    jr = km.dof_to_rot_torch(ref_in[2])
+    bp, br = km.forward_kinematics_torch(ref_in[0], rq, jr)
+    ref = (rq, jr, bp, br)
+    for a, b, name in zip(out, ref, ("root_quat", "joint_rot", "body_pos", "body_rot")):
+        assert a.shape == b.shape
+        close(a, b.detach().cpu().numpy(), atol=3e-6, rtol=0)
+    cot = [torch.randn_like(o) for o in out]
+    torch.autograd.backward(out, cot)
+    torch.autograd.backward(ref, cot)
+    for a, b, name in zip(ins, ref_in, ("root_pos", "root_exp", "dof")):
+        ga, gb = a.grad, b.grad
+        scale = float(gb.abs().max())
+        err = float((ga - gb).abs().max())
+        assert err <= 2e-5 * scale, (name, err, scale)
+    assert float(ins[1].grad[1].abs().max()) == 0.0
