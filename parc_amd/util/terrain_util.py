@@ -360,12 +360,14 @@ def points_hf_sdf(points, hf, hf_min_box_center, hf_dxdy, base_z=-10.0, inverted
 def _body_points_world(motion_frames, char_model, char_point_samples):
     """frames [..., 34] -> (world positions [..., P, 3] of every sample point, owning body [P]); bodies in order, a body's
     points in the order of its sample tensor."""
-    root_rot = torch_util.exp_map_to_quat(motion_frames[..., 3:6])
     if torch.is_grad_enabled() and motion_frames.requires_grad:
-        # pose through torch ops so that autograd reaches the frames (KinCharModel.*_torch); values agree with the kernels to fp32 rounding
-        joint_rot = char_model.dof_to_rot_torch(motion_frames[..., 6:])
-        body_pos, body_rot = char_model.forward_kinematics_torch(motion_frames[..., 0:3], root_rot, joint_rot)
+        # the pose chain with its one-launch adjoint, so that autograd reaches the frames (KinCharModel.pose_chain)
+        lead = motion_frames.shape[:-1]
+        flat = motion_frames.reshape(-1, motion_frames.shape[-1])
+        _, _, body_pos, body_rot = char_model.pose_chain(flat[:, 0:3], flat[:, 3:6], flat[:, 6:])
+        body_pos, body_rot = body_pos.reshape(lead + body_pos.shape[1:]), body_rot.reshape(lead + body_rot.shape[1:])
     else:
+        root_rot = torch_util.exp_map_to_quat(motion_frames[..., 3:6])
         joint_rot = char_model.dof_to_rot(motion_frames[..., 6:])
         body_pos, body_rot = char_model.forward_kinematics(motion_frames[..., 0:3], root_rot, joint_rot)
     dev = motion_frames.device
