@@ -83,3 +83,40 @@ def _len(path):
     from parc_amd.util import safe_pickle
     d = safe_pickle.load_motion_file_safe(path)
     return np.asarray(d["frames"]).shape[0] / float(d["fps"])              # the dataset builder counts frames, not intervals
+
+
+def test_optimize_motions_driver_from_a_config_file(km, tmp_path):
+    """tools/motion_opt/optimize_motions.py as a program: the reference's config keys, a dataset YAML in, <name>_opt.pkl files in the
+    reference's motion format out (frame_stride 2 halves the clip and its fps, constraints are re-indexed)."""
+    import yaml
+    from parc_amd import synthetic
+    from parc_amd.assets import humanoid_spec
+    from parc_amd.tools.motion_opt import optimize_motions
+    from parc_amd.util import safe_pickle, terrain_util
+    from test_host_logic import pickle_globals
+    src = tmp_path / "src"
+    src.mkdir()
+    entries = []
+    for k, clip in enumerate(synthetic.make_dataset(num_clips=2, seed=21, frames_range=(60, 70), tile_cells=16)):
+        ter = terrain_util.SubTerrain.from_arrays(clip["hf"], clip["min_point"], clip["dxdy"], device="cpu").numpy_copy()
+        path = str(src / ("clip_%d.pkl" % k))
+        terrain_util.dump_reference_pickle({"fps": 30, "loop_mode": "CLAMP", "frames": clip["frames"], "contacts": clip["contacts"], "terrain": ter}, path)
+        entries.append({"file": path, "weight": 1.0})
+    (tmp_path / "motions.yaml").write_text(yaml.safe_dump({"motions": entries}))
+    cfg = {"motions_yaml_path": str(tmp_path / "motions.yaml"), "device": DEV, "char_model": humanoid_spec.write_mjcf(),
+           "output_folder_path": str(tmp_path / "opt") + "/", "num_iters": 30, "step_size": 0.001, "w_root_pos": 1.0, "w_root_rot": 10.0,
+           "w_joint_rot": 1.0, "w_smoothness": 10.0, "w_penetration": 1000.0, "w_contact": 1000.0, "w_sliding": 10.0, "w_body_constraints": 1000.0,
+           "w_jerk": 1000.0, "max_jerk": 1000.0, "use_wandb": False, "auto_compute_body_constraints": True, "frame_stride": 2,
+           "char_point_samples": {"sphere_num_subdivisions": 0, "box_num_slices": 2, "box_dim_x": 3, "box_dim_y": 6, "capsule_num_circle_points": 4,
+                                  "capsule_num_sphere_subdivisions": 0, "capsule_num_cylinder_slices": 4}}
+    (tmp_path / "motion_opt.yaml").write_text(yaml.safe_dump(cfg))
+    optimize_motions.main(["optimize_motions.py", "--config", str(tmp_path / "motion_opt.yaml")])
+    for k in range(2):
+        out = tmp_path / "opt" / ("clip_%d_opt.pkl" % k)
+        assert out.exists() and (tmp_path / "opt" / "log" / ("log_clip_%d_opt.txt" % k)).exists()
+        d = safe_pickle.load_motion_file_safe(str(out))
+        n_src = safe_pickle.load_motion_file_safe(entries[k]["file"])["frames"].shape[0]
+        assert d["fps"] == 15 and d["frames"].shape == ((n_src + 1) // 2, 34) and d["contacts"].shape[0] == d["frames"].shape[0]
+        assert np.isfinite(np.asarray(d["frames"])).all()
+        mods = {m for m, _ in pickle_globals(str(out))}
+        assert not any(m.startswith("parc_amd") for m in mods), mods
