@@ -69,6 +69,7 @@ __global__ __launch_bounds__(SDF_THREADS) void points_hf_sdf_kernel(int n_points
             }
         }
     }
+    if (!(px == px && py == py && pz == pz)) best = __builtin_nanf("");   // a NaN coordinate: torch's abs / clamp / min propagate it, fmaxf / fminf above do not
     if (radius > 0.f) best -= radius;           // sdRoundBox: x - r is monotone, so it commutes with the min
     if (inverted) best = -best;
     out[(size_t)bi * n_points + p] = best;

@@ -151,3 +151,40 @@ def test_pose_chain_kernels_equal_the_torch_chain(km):
         err = float((ga - gb).abs().max())
         assert err <= 2e-5 * scale, (name, err, scale)
     assert float(ins[1].grad[1].abs().max()) == 0.0
+
+
+def test_pose_chain_and_sdf_edge_cases(km, oracle):
+    """Ragged and degenerate inputs of the two kernels the optimiser leans on: empty / single / non-multiple-of-64 batches of the pose
+    chain, and the windowed terrain query for points far outside the field, on its border, at a NaN coordinate and on a one-cell field."""
+    from parc_amd.util import terrain_util
+    D = km.get_dof_size()
+    for n in (0, 1, 65):
+        rp = torch.randn((n, 3), device=DEV, requires_grad=True)
+        re = (0.5 * torch.randn((n, 3), device=DEV)).requires_grad_(True)
+        dof = (0.5 * torch.randn((n, D), device=DEV)).requires_grad_(True)
+        rq, jr, bp, br = km.pose_chain(rp, re, dof)
+        assert rq.shape == (n, 4) and jr.shape == (n, 14, 4) and bp.shape == (n, 15, 3) and br.shape == (n, 15, 4)
+        (bp.sum() + br.sum() + rq.sum() + jr.sum()).backward()
+        assert rp.grad.shape == (n, 3) and torch.isfinite(dof.grad).all()
+        if n:
+            close(bp[:, 0], rp.detach().cpu().numpy(), atol=0, rtol=0)
+            assert float((rp.grad - 15.0).abs().max()) < 1e-4            # every body position carries the root translation once
+    rng = np.random.default_rng(9)
+    X, Y = 23, 17
+    hf = rng.uniform(-1, 1, size=(1, X, Y)).astype(np.float32)
+    mbc = np.array([[0.3, -0.2]], np.float32)
+    dxdy = np.array([0.4, 0.25], np.float32)
+    far = rng.uniform(-400, 400, size=(1, 300, 3)).astype(np.float32)         # hundreds of cells away: the window covers the whole field
+    near = np.concatenate([rng.uniform(-1, 10, size=(1, 300, 1)), rng.uniform(-1, 5, size=(1, 300, 1)), rng.uniform(-3, 3, size=(1, 300, 1))], axis=-1)
+    edge = np.array([[[0.3, -0.2, 0.0], [0.3 + 0.4 * (X - 1), -0.2 + 0.25 * (Y - 1), 5.0], [0.3 - 0.2, -0.2 - 0.125, -20.0], [0.5, 0.05, 1e6]]], np.float32)
+    for pts in (far, near.astype(np.float32), edge):
+        for kw in ({}, dict(inverted=False), dict(inverted=False, radius=0.1)):
+            got = terrain_util.points_hf_sdf(T(pts), T(hf), T(mbc), T(dxdy), **kw)
+            want = oracle.points_hf_sdf(pts, hf, mbc, dxdy, **kw)
+            close(got, want, atol=1e-6, rtol=2e-7)
+    bad = near.astype(np.float32).copy()
+    bad[0, 0, 0] = np.nan
+    out = terrain_util.points_hf_sdf(T(bad), T(hf), T(mbc), T(dxdy))
+    assert torch.isnan(out[0, 0]) and torch.isfinite(out[0, 1:]).all()
+    one = terrain_util.points_hf_sdf(T(near.astype(np.float32)), T(hf[:, :1, :1]), T(mbc), T(dxdy))
+    close(one, oracle.points_hf_sdf(near.astype(np.float32), hf[:, :1, :1], mbc, dxdy), atol=1e-6, rtol=2e-7)
