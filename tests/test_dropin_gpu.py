@@ -121,8 +121,12 @@ def test_collectives_on_the_real_backend_with_one_rank():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PARC_DIST_BACKEND"):
         env.pop(k, None)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                          "--master-port", "29731", os.path.join(REPO, "tools", "rccl_probe.py")], capture_output=True, text=True, env=env, timeout=900)
+                          "--master-port", str(port), os.path.join(REPO, "tools", "rccl_probe.py")], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
     for cadence in ("minibatch", "epoch"):
