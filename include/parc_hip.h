@@ -335,6 +335,12 @@ int parc_points_hf_sdf(void *stream, int batch, int n_points, int dim_x, int dim
                        const float *min_box_center, const float *x_points, const float *y_points, float half_x, float half_y,
                        float base_z, int inverted, float radius, float *out, int32_t *out_cell);
 
+/* The adjoint of parc_points_hf_sdf with respect to the points: g_points [B,N,3] = g_out [B,N] * d(out)/d(point) for the column the
+ * forward call reported in out_cell (what the reference obtains from autograd through util/terrain_util.py:1835-1893). */
+int parc_points_hf_sdf_grad(void *stream, int batch, int n_points, int dim_x, int dim_y, const float *points, const float *hf,
+                            const float *min_box_center, const float *x_points, const float *y_points, float half_x, float half_y,
+                            float base_z, int inverted, const int32_t *cell, const float *g_out, float *g_points);
+
 /* Backward of a Linear + ReLU layer between its two GEMMs (the derivative of learning/nets/fc_3layers_2048units.py:4-22): in one pass
  * gy[r, c] <- gy[r, c] * (y[r, c] > 0) (in place) and db[c] <- sum_r of the result (overwritten, fixed summation order).
  * gy, y: [rows, dim] row-major, dim % 4 == 0, 16-byte aligned; workspace: parc_relu_bwd_workspace_floats(rows, dim) floats. */

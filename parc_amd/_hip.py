@@ -166,6 +166,8 @@ def _declare(L):
     L.parc_action_head.restype = c_int
     L.parc_points_hf_sdf.argtypes = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 5 + [c_f, c_f, c_f, c_int, c_f, c_vp, c_vp]
     L.parc_points_hf_sdf.restype = c_int
+    L.parc_points_hf_sdf_grad.argtypes = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 5 + [c_f, c_f, c_f, c_int, c_vp, c_vp, c_vp]
+    L.parc_points_hf_sdf_grad.restype = c_int
     L.parc_scale_by_clipped_norm.argtypes = [c_vp, c_i64, c_vp, c_vp, c_f]
     L.parc_scale_by_clipped_norm.restype = c_int
     L.parc_moments_workspace_floats.argtypes = [c_i64, c_int]
@@ -206,7 +208,7 @@ EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hf
             "parc_update_fail_rates", "parc_td_lambda_return", "parc_adv_normalize", "parc_reset_apply", "parc_ppo_loss", "parc_ppo_workspace_floats", "parc_record_step", "parc_return_tracker_update", "parc_normalize_clamp",
             "parc_action_head", "parc_points_hf_sdf", "parc_moments_workspace_floats", "parc_moments_accumulate", "parc_reset_sample_apply", "parc_return_tracker_workspace_floats", "parc_scale_by_clipped_norm", "parc_relu_bwd_workspace_floats",
             "parc_relu_bwd_bias_grad", "parc_ppo_loss_packed", "parc_weighted_colsum", "parc_sgd_workspace_floats", "parc_sgd_momentum_step",
-            "parc_pose_chain_forward", "parc_pose_chain_backward"]
+            "parc_pose_chain_forward", "parc_pose_chain_backward", "parc_points_hf_sdf_grad"]
 
 
 def check(rc, what):

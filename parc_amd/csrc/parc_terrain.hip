@@ -76,6 +76,61 @@ __global__ __launch_bounds__(SDF_THREADS) void points_hf_sdf_kernel(int n_points
     if (out_cell) out_cell[(size_t)bi * n_points + p] = best_cell;
 }
 
+// Adjoint of the query above with respect to the points: g_points = g_out * d(sd)/dp for the column the forward pass selected
+// (out_cell).  The same piecewise expression torch's autograd differentiates in the reference (abs -> sign, clamp(min=0) + norm ->
+// unit vector of the positive part, max -> its first arg-max, clamp(max=0) -> passes at <= 0), evaluated once per point.
+__global__ __launch_bounds__(SDF_THREADS) void points_hf_sdf_grad_kernel(int n_points, int dim_x, int dim_y, const float *__restrict__ points,
+                                                                         const float *__restrict__ hf, const float *__restrict__ min_box_center,
+                                                                         const float *__restrict__ x_points, const float *__restrict__ y_points,
+                                                                         float half_x, float half_y, float base_z, int inverted,
+                                                                         const int32_t *__restrict__ cell, const float *__restrict__ g_out,
+                                                                         float *__restrict__ g_points) {
+    const int bi = blockIdx.y;
+    const int p = blockIdx.x * SDF_THREADS + threadIdx.x;
+    if (p >= n_points) return;
+    const size_t ip = (size_t)bi * n_points + p;
+    const float *pt = points + ip * 3;
+    const int ci = cell[ip], i = ci / dim_y, j = ci - i * dim_y;
+    const float h = hf[(size_t)bi * dim_x * dim_y + ci];
+    const float top_z = -base_z;
+    const float cx = x_points[i] + min_box_center[2 * bi], cy = y_points[j] + min_box_center[2 * bi + 1];
+    const float cz = inverted ? (h + top_z) / 2.0f : (h + base_z) / 2.0f;
+    const float hz = inverted ? (top_z - h) / 2.0f : (h - base_z) / 2.0f;
+    const float d[3] = {pt[0] - cx, pt[1] - cy, pt[2] - cz};
+    const float q[3] = {fabsf(d[0]) - half_x, fabsf(d[1]) - half_y, fabsf(d[2]) - hz};
+    const float a[3] = {fmaxf(q[0], 0.f), fmaxf(q[1], 0.f), fmaxf(q[2], 0.f)};
+    const float n = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    float g[3] = {0.f, 0.f, 0.f};
+    if (n > 0.f) {
+        g[0] = a[0] / n;
+        g[1] = a[1] / n;
+        g[2] = a[2] / n;
+    }
+    int km = 0;
+    if (q[1] > q[km]) km = 1;
+    if (q[2] > q[km]) km = 2;
+    if (q[km] <= 0.f) g[km] += 1.0f;
+    const float s = (inverted ? -1.0f : 1.0f) * g_out[ip];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float sg = d[k] > 0.f ? 1.0f : (d[k] < 0.f ? -1.0f : 0.0f);
+        g_points[ip * 3 + k] = s * g[k] * sg;
+    }
+}
+
+extern "C" int parc_points_hf_sdf_grad(void *stream, int batch, int n_points, int dim_x, int dim_y, const float *points, const float *hf,
+                                       const float *min_box_center, const float *x_points, const float *y_points, float half_x, float half_y,
+                                       float base_z, int inverted, const int32_t *cell, const float *g_out, float *g_points) {
+    if (batch < 0 || n_points < 0 || dim_x <= 0 || dim_y <= 0) return PARC_EINVAL;
+    if (batch == 0 || n_points == 0) return PARC_OK;
+    if (batch > 65535) return PARC_EUNSUPPORTED;
+    if (!points || !hf || !min_box_center || !x_points || !y_points || !cell || !g_out || !g_points) return PARC_EINVAL;
+    hipLaunchKernelGGL(points_hf_sdf_grad_kernel, dim3((n_points + SDF_THREADS - 1) / SDF_THREADS, batch), dim3(SDF_THREADS), 0, (hipStream_t)stream,
+                       n_points, dim_x, dim_y, points, hf, min_box_center, x_points, y_points, half_x, half_y, base_z, inverted, cell, g_out, g_points);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}
+
 extern "C" int parc_points_hf_sdf(void *stream, int batch, int n_points, int dim_x, int dim_y, const float *points, const float *hf,
                                   const float *min_box_center, const float *x_points, const float *y_points, float half_x, float half_y,
                                   float base_z, int inverted, float radius, float *out, int32_t *out_cell) {

@@ -311,10 +311,10 @@ def points_hf_sdf(points, hf, hf_min_box_center, hf_dxdy, base_z=-10.0, inverted
     hf_min_box_center [B, 2]; inverted (default) = negative depth below the surface for points in the ground.
     Reference: util/terrain_util.py:1835-1893.  One launch, no [B, N, X*Y, 3] temporaries.
 
-    Differentiable in ``points``: the kernel also reports WHICH column attains the minimum; when ``points`` requires grad the distance
-    to that one column is re-evaluated with torch ops (N box distances instead of N * X * Y), so autograd sees exactly the branch
-    torch.min would have routed the gradient through.  With ``grid=HfGrid(...)`` the call reads nothing back from the device."""
-    from .. import _hip
+    Differentiable in ``points``: the kernel also reports WHICH column attains the minimum, and the adjoint is the derivative of the
+    distance to that one column - the branch torch.min would have routed the gradient through - in one launch (parc_points_hf_sdf_grad).
+    When the heightfield itself requires grad, that column's distance is re-evaluated with torch ops instead.  With ``grid=HfGrid(...)``
+    the call reads nothing back from the device."""
     assert points.dim() == 3 and hf.dim() == 3 and hf_min_box_center.dim() == 2
     B, N = int(points.shape[0]), int(points.shape[1])
     assert hf.shape[0] == B and hf_min_box_center.shape[0] == B
@@ -328,17 +328,14 @@ def points_hf_sdf(points, hf, hf_min_box_center, hf_dxdy, base_z=-10.0, inverted
     if radius is not None:
         assert isinstance(radius, float) and radius > 0.0
     want_grad = torch.is_grad_enabled() and (points.requires_grad or hf.requires_grad)
-    out = torch.empty((B, N), dtype=torch.float32, device=dev)
-    cell = torch.empty((B, N), dtype=torch.int32, device=dev) if want_grad else None
-    pts = points.detach().to(torch.float32).contiguous()
-    hfc = hf.detach().to(torch.float32).contiguous()
-    mbc = hf_min_box_center.detach().to(torch.float32).contiguous()
-    _hip.check(_hip.lib().parc_points_hf_sdf(_hip.stream(), B, N, X, Y, _hip.ptr(pts), _hip.ptr(hfc), _hip.ptr(mbc), _hip.ptr(xs), _hip.ptr(ys),
-                                             float(half[0]), float(half[1]), float(base_z), 1 if inverted else 0,
-                                             float(radius) if radius is not None else 0.0, _hip.ptr(out), _hip.ptr(cell)), "parc_points_hf_sdf")
+    if want_grad and not (hf.requires_grad or hf_min_box_center.requires_grad):
+        # the common case (poses are optimised, the terrain is fixed): the adjoint is one launch too
+        return _PointsHfSdf.apply(points, hf, hf_min_box_center, grid, float(base_z), bool(inverted), radius)
+    out, cell = _points_hf_sdf_launch(points, hf, hf_min_box_center, grid, base_z, inverted, radius, want_grad)
     if not want_grad:
         return out
-    # the selected column per point, through autograd (same expressions as the kernel / the reference)
+    # gradients with respect to the heightfield asked for: the selected column per point, through autograd (same expressions as the
+    # kernel / the reference)
     ci = cell.long()
     i, j = torch.div(ci, Y, rounding_mode="floor"), ci % Y
     h = torch.gather(hf.reshape(B, -1), 1, ci)
@@ -355,6 +352,50 @@ def points_hf_sdf(points, hf, hf_min_box_center, hf_dxdy, base_z=-10.0, inverted
     if radius is not None:
         sd = sd - radius
     return -sd if inverted else sd
+
+
+def _points_hf_sdf_launch(points, hf, hf_min_box_center, grid, base_z, inverted, radius, want_cell):
+    from .. import _hip
+    B, N = int(points.shape[0]), int(points.shape[1])
+    X, Y = grid.shape
+    dev = points.device
+    out = torch.empty((B, N), dtype=torch.float32, device=dev)
+    cell = torch.empty((B, N), dtype=torch.int32, device=dev) if want_cell else None
+    pts = points.detach().to(torch.float32).contiguous()
+    hfc = hf.detach().to(torch.float32).contiguous()
+    mbc = hf_min_box_center.detach().to(torch.float32).contiguous()
+    _hip.check(_hip.lib().parc_points_hf_sdf(_hip.stream(), B, N, X, Y, _hip.ptr(pts), _hip.ptr(hfc), _hip.ptr(mbc), _hip.ptr(grid.xs), _hip.ptr(grid.ys),
+                                             float(grid.half[0]), float(grid.half[1]), float(base_z), 1 if inverted else 0,
+                                             float(radius) if radius is not None else 0.0, _hip.ptr(out), _hip.ptr(cell)), "parc_points_hf_sdf")
+    return out, cell
+
+
+class _PointsHfSdf(torch.autograd.Function):
+    """points_hf_sdf for a fixed terrain: forward = the query (which also reports the arg-min column), backward = parc_points_hf_sdf_grad
+    (g_points = g_out * d(distance to that column)/d(point)), one launch each."""
+
+    @staticmethod
+    def forward(ctx, points, hf, hf_min_box_center, grid, base_z, inverted, radius):
+        out, cell = _points_hf_sdf_launch(points, hf, hf_min_box_center, grid, base_z, inverted, radius, True)
+        ctx.save_for_backward(points.detach().to(torch.float32).contiguous(), hf.detach().to(torch.float32).contiguous(),
+                              hf_min_box_center.detach().to(torch.float32).contiguous(), cell)
+        ctx.grid, ctx.base_z, ctx.inverted = grid, base_z, inverted
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        from .. import _hip
+        pts, hfc, mbc, cell = ctx.saved_tensors
+        grid = ctx.grid
+        B, N = int(pts.shape[0]), int(pts.shape[1])
+        X, Y = grid.shape
+        g = g_out.to(torch.float32).contiguous()
+        g_pts = torch.empty_like(pts)
+        _hip.check(_hip.lib().parc_points_hf_sdf_grad(_hip.stream(), B, N, X, Y, _hip.ptr(pts), _hip.ptr(hfc), _hip.ptr(mbc), _hip.ptr(grid.xs),
+                                                      _hip.ptr(grid.ys), float(grid.half[0]), float(grid.half[1]), float(ctx.base_z),
+                                                      1 if ctx.inverted else 0, _hip.ptr(cell), _hip.ptr(g), _hip.ptr(g_pts)),
+                   "parc_points_hf_sdf_grad")
+        return g_pts, None, None, None, None, None, None
 
 
 def _body_points_world(motion_frames, char_model, char_point_samples):

@@ -650,6 +650,14 @@ def test_g13_penetration_loss_gradients(km):
     sd = terrain_util.points_hf_sdf(p, T(g["sdf_hf"]), T(g["sdf_mbc"]), T(g["sdf_dxdy"]))
     close(sd.detach(), g["sdf_inverted"], atol=5e-7, rtol=0)
     sd.sum().backward()
+    # the one-launch adjoint (terrain fixed) and the torch re-evaluation of the selected column (terrain differentiable) are the same map
+    for kw in ({}, dict(inverted=False, base_z=-5.0), dict(inverted=False, radius=0.07)):
+        pa, pb = T(g["sdf_points"]).requires_grad_(True), T(g["sdf_points"]).requires_grad_(True)
+        hfb = T(g["sdf_hf"]).requires_grad_(True)
+        wts = torch.randn(g["sdf_points"].shape[:2], device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+        (terrain_util.points_hf_sdf(pa, T(g["sdf_hf"]), T(g["sdf_mbc"]), T(g["sdf_dxdy"]), **kw) * wts).sum().backward()
+        (terrain_util.points_hf_sdf(pb, hfb, T(g["sdf_mbc"]), T(g["sdf_dxdy"]), **kw) * wts).sum().backward()
+        assert float((pa.grad - pb.grad).abs().max()) < 1e-5 and float(hfb.grad.abs().sum()) > 0
     ref = g["sdf_inverted_grad"]
     got = p.grad.cpu().numpy()
     # the gradient is a unit vector per point; points equidistant from two columns (a tie inside fp32 rounding) may legitimately
