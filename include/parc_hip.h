@@ -173,6 +173,14 @@ int parc_pose_chain_backward(void *stream, parc_char_model_t model, int n, const
                              const float *g_root_quat, const float *g_joint_rot, const float *g_body_pos, const float *g_body_rot,
                              float *g_root_pos, float *g_root_exp, float *g_dof);
 
+/* Sample points of the bodies in the world frame, world [T,P,3] = body_pos[t, owner[p]] + rotate(body_rot[t, owner[p]], local[p])
+ * (what the terrain losses feed to parc_points_hf_sdf: util/terrain_util.py:1895-1951, tools/motion_opt/motion_optimization.py:241-247),
+ * and its adjoint g_world -> g_body_pos [T,B,3], g_body_rot [T,B,4]; a body's points are contiguous, start [B+1] are their offsets. */
+int parc_body_points_world(void *stream, int n_frames, int num_bodies, int num_points, const float *body_pos, const float *body_rot,
+                           const float *local, const int32_t *owner, float *world);
+int parc_body_points_world_grad(void *stream, int n_frames, int num_bodies, int num_points, const float *body_rot, const float *local,
+                                const int32_t *start, const float *g_world, float *g_body_pos, float *g_body_rot);
+
 /* ---- K3: MotionLib.calc_motion_frame  anim/motion_lib.py:80-112 (contact_info=True)
  * outputs AoS: root_pos[Q,3] root_rot[Q,4] root_vel[Q,3] root_ang_vel[Q,3] joint_rot[Q,J,4] dof_vel[Q,D] contacts[Q,B] */
 int parc_calc_motion_frame(void *stream, parc_motion_lib_t mlib, int n_queries, const int64_t *motion_ids,

@@ -643,6 +643,16 @@ PARC_DEV v3 exp_map_to_quat_bwd(v3 em, q4 q, q4 g) {
 
 PARC_DEV q4 qadd(q4 a, q4 b) { return q4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 
+// cotangent of q for r = quat_rotate(q, v) = v + w t + u x t, t = 2 u x v (u = q.xyz), given the cotangent g of r
+PARC_DEV q4 quat_rotate_bwd_q(q4 q, v3 v, v3 g) {
+    const v3 u = mk3(q.x, q.y, q.z);
+    const v3 t = 2.f * cross3(u, v);
+    const v3 gxu = cross3(g, u);
+    const v3 gt = mk3(q.w * g.x + gxu.x, q.w * g.y + gxu.y, q.w * g.z + gxu.z);
+    const v3 gu = cross3(t, g) + 2.f * cross3(v, gt);
+    return q4{gu.x, gu.y, gu.z, dot3(g, t)};
+}
+
 __global__ __launch_bounds__(64) void pose_chain_fwd_kernel(parc_char_model_t m, int n, const float *__restrict__ root_pos,
                                                             const float *__restrict__ root_exp, const float *__restrict__ dof,
                                                             float *root_quat, float *joint_rot, float *body_pos, float *body_rot) {
@@ -697,16 +707,7 @@ __global__ __launch_bounds__(64) void pose_chain_bwd_kernel(parc_char_model_t m,
         const int p = m.parent[b];
         // pos[b] = pos[p] + rotate(rot[p], t_b)
         gpos[p] = gpos[p] + gpos[b];
-        {
-            const v3 v = mk3(m.local_translation[b][0], m.local_translation[b][1], m.local_translation[b][2]);
-            const q4 q = rot[p];
-            const v3 u = mk3(q.x, q.y, q.z), g = gpos[b];
-            const v3 t = 2.f * cross3(u, v);
-            const v3 gxu = cross3(g, u);
-            const v3 gt = mk3(q.w * g.x + gxu.x, q.w * g.y + gxu.y, q.w * g.z + gxu.z);
-            const v3 gu = cross3(t, g) + 2.f * cross3(v, gt);
-            grot[p] = qadd(grot[p], q4{gu.x, gu.y, gu.z, dot3(g, t)});
-        }
+        grot[p] = qadd(grot[p], quat_rotate_bwd_q(rot[p], mk3(m.local_translation[b][0], m.local_translation[b][1], m.local_translation[b][2]), gpos[b]));
         // rot[b] = rot[p] (x) loc[b]
         grot[p] = qadd(grot[p], quat_mul(grot[b], quat_conj(loc[b])));
         const q4 gloc = quat_mul(quat_conj(rot[p]), grot[b]);
@@ -726,6 +727,58 @@ __global__ __launch_bounds__(64) void pose_chain_bwd_kernel(parc_char_model_t m,
     }
     st3(g_root_pos + 3 * (size_t)i, gpos[0]);
     st3(g_root_exp + 3 * (size_t)i, exp_map_to_quat_bwd(em, rot[0], qadd(grot[0], ld4(g_root_quat + 4 * (size_t)i))));
+}
+
+// Sample points of the bodies in the world frame, x[t, p] = pos[t, owner(p)] + rotate(rot[t, owner(p)], local[p]), and the adjoint
+// (the points of a body are contiguous: body b owns [start[b], start[b + 1])), one thread per point / per (frame, body).
+__global__ __launch_bounds__(256) void body_points_world_kernel(int n_frames, int B, int P, const float *__restrict__ body_pos,
+                                                                const float *__restrict__ body_rot, const float *__restrict__ local,
+                                                                const int32_t *__restrict__ owner, float *world) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_frames * P) return;
+    const int t = (int)(i / P), p = (int)(i - (size_t)t * P), b = owner[p];
+    const v3 x = ld3(body_pos + ((size_t)t * B + b) * 3) + quat_rotate(ld4(body_rot + ((size_t)t * B + b) * 4), ld3(local + 3 * (size_t)p));
+    st3(world + i * 3, x);
+}
+
+__global__ __launch_bounds__(256) void body_points_world_grad_kernel(int n_frames, int B, int P, const float *__restrict__ body_rot,
+                                                                     const float *__restrict__ local, const int32_t *__restrict__ start,
+                                                                     const float *__restrict__ g_world, float *g_body_pos, float *g_body_rot) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n_frames * B) return;
+    const int t = (int)(i / B), b = (int)(i - (size_t)t * B);
+    const q4 q = ld4(body_rot + i * 4);
+    v3 gp = mk3(0.f, 0.f, 0.f);
+    q4 gq = mk4(0.f, 0.f, 0.f, 0.f);
+    for (int p = start[b]; p < start[b + 1]; ++p) {
+        const v3 g = ld3(g_world + ((size_t)t * P + p) * 3);
+        gp = gp + g;
+        gq = qadd(gq, quat_rotate_bwd_q(q, ld3(local + 3 * (size_t)p), g));
+    }
+    st3(g_body_pos + i * 3, gp);
+    st4(g_body_rot + i * 4, gq);
+}
+
+extern "C" int parc_body_points_world(void *stream, int n_frames, int num_bodies, int num_points, const float *body_pos, const float *body_rot,
+                                      const float *local, const int32_t *owner, float *world) {
+    if (n_frames < 0 || num_bodies <= 0 || num_points < 0) return PARC_EINVAL;
+    const size_t n = (size_t)n_frames * num_points;
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(body_points_world_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_frames, num_bodies, num_points,
+                       body_pos, body_rot, local, owner, world);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+extern "C" int parc_body_points_world_grad(void *stream, int n_frames, int num_bodies, int num_points, const float *body_rot, const float *local,
+                                           const int32_t *start, const float *g_world, float *g_body_pos, float *g_body_rot) {
+    if (n_frames < 0 || num_bodies <= 0 || num_points < 0) return PARC_EINVAL;
+    const size_t n = (size_t)n_frames * num_bodies;
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(body_points_world_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_frames, num_bodies,
+                       num_points, body_rot, local, start, g_world, g_body_pos, g_body_rot);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
 }
 
 extern "C" int parc_pose_chain_forward(void *stream, parc_char_model_t model, int n, const float *root_pos, const float *root_exp,

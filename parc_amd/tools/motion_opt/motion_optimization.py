@@ -140,10 +140,10 @@ class _Problem:
         self.contacts = contacts
         B = char_model.get_num_joints()
         assert len(body_points) == B
-        counts = [int(p.shape[0]) for p in body_points]
-        self.local = torch.cat([p.to(dev, torch.float32).reshape(-1, 3) for p in body_points], dim=0)
-        self.owner = torch.cat([torch.full((n,), b, dtype=torch.int64, device=dev) for b, n in enumerate(counts)])
-        self.start = [sum(counts[:b]) for b in range(B)]
+        self.points = terrain_util.BodyPoints(body_points, dev)
+        counts = self.points.counts
+        self.local, self.owner = self.points.local, self.points.owner
+        self.start = self.points.start[:B]
         self.counts = counts
         self.hf = terrain.hf.to(dev, torch.float32).unsqueeze(0)
         self.min_point = terrain.min_point.to(dev, torch.float32).unsqueeze(0)
@@ -210,7 +210,7 @@ class _Problem:
         smoothness_loss = torch.sum(vel_err_sq) + torch.sum(rot_vel_err_sq)
 
         T, P = int(tgt_root_pos.shape[0]), int(self.local.shape[0])
-        world = torch_util.quat_rotate(body_rot[:, self.owner], self.local.unsqueeze(0).expand(T, P, 3)) + body_pos[:, self.owner]
+        world = self.points.world(body_pos, body_rot)                      # [T, P, 3], one launch (and one for its adjoint)
         flat = world.reshape(1, T * P, 3)
         inside = terrain_util.points_hf_sdf(flat, self.hf, self.min_point, self.dxdy, base_z=-10.0, inverted=True, grid=self.grid)
         penetration_loss = torch.sum(-torch.clamp(inside, max=0.0))

@@ -398,9 +398,61 @@ class _PointsHfSdf(torch.autograd.Function):
         return g_pts, None, None, None, None, None, None
 
 
+class BodyPoints:
+    """The sample points of all bodies as one table: local coordinates [P, 3], owning body [P] and the offsets of each body's
+    (contiguous) range - prepared once per character / point set."""
+
+    def __init__(self, char_point_samples, device):
+        counts = [int(p.shape[0]) for p in char_point_samples]
+        self.num_bodies = len(counts)
+        self.counts = counts
+        self.start = [sum(counts[:b]) for b in range(len(counts) + 1)]
+        self.local = torch.cat([p.to(device=device, dtype=torch.float32).reshape(-1, 3) for p in char_point_samples], dim=0).contiguous()
+        self.owner = torch.cat([torch.full((n,), b, dtype=torch.int64, device=device) for b, n in enumerate(counts)])
+        self.owner32 = self.owner.to(torch.int32).contiguous()
+        self.start32 = torch.tensor(self.start, dtype=torch.int32, device=device)
+        self.num_points = int(self.local.shape[0])
+
+    def world(self, body_pos, body_rot):
+        """body_pos [..., B, 3], body_rot [..., B, 4] -> world positions [..., P, 3] of every sample point (differentiable: forward and
+        adjoint are one launch each, parc_body_points_world / _grad)"""
+        lead = body_pos.shape[:-2]
+        w = _BodyPointsWorld.apply(body_pos.reshape(-1, self.num_bodies, 3), body_rot.reshape(-1, self.num_bodies, 4), self)
+        return w.reshape(lead + (self.num_points, 3))
+
+
+class _BodyPointsWorld(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, body_pos, body_rot, bp):
+        from .. import _hip
+        T_ = int(body_pos.shape[0])
+        pos, rot = body_pos.detach().to(torch.float32).contiguous(), body_rot.detach().to(torch.float32).contiguous()
+        world = torch.empty((T_, bp.num_points, 3), dtype=torch.float32, device=pos.device)
+        _hip.check(_hip.lib().parc_body_points_world(_hip.stream(), T_, bp.num_bodies, bp.num_points, _hip.ptr(pos), _hip.ptr(rot), _hip.ptr(bp.local),
+                                                     _hip.ptr(bp.owner32), _hip.ptr(world)), "parc_body_points_world")
+        ctx.save_for_backward(rot)
+        ctx.bp = bp
+        return world
+
+    @staticmethod
+    def backward(ctx, g_world):
+        from .. import _hip
+        rot, = ctx.saved_tensors
+        bp = ctx.bp
+        T_ = int(rot.shape[0])
+        g = g_world.to(torch.float32).contiguous()
+        g_pos = torch.empty((T_, bp.num_bodies, 3), dtype=torch.float32, device=rot.device)
+        g_rot = torch.empty((T_, bp.num_bodies, 4), dtype=torch.float32, device=rot.device)
+        _hip.check(_hip.lib().parc_body_points_world_grad(_hip.stream(), T_, bp.num_bodies, bp.num_points, _hip.ptr(rot), _hip.ptr(bp.local),
+                                                          _hip.ptr(bp.start32), _hip.ptr(g), _hip.ptr(g_pos), _hip.ptr(g_rot)),
+                   "parc_body_points_world_grad")
+        return g_pos, g_rot, None
+
+
 def _body_points_world(motion_frames, char_model, char_point_samples):
     """frames [..., 34] -> (world positions [..., P, 3] of every sample point, owning body [P]); bodies in order, a body's
     points in the order of its sample tensor."""
+    bp = BodyPoints(char_point_samples, motion_frames.device)
     if torch.is_grad_enabled() and motion_frames.requires_grad:
         # the pose chain with its one-launch adjoint, so that autograd reaches the frames (KinCharModel.pose_chain)
         lead = motion_frames.shape[:-1]
@@ -411,10 +463,7 @@ def _body_points_world(motion_frames, char_model, char_point_samples):
         root_rot = torch_util.exp_map_to_quat(motion_frames[..., 3:6])
         joint_rot = char_model.dof_to_rot(motion_frames[..., 6:])
         body_pos, body_rot = char_model.forward_kinematics(motion_frames[..., 0:3], root_rot, joint_rot)
-    dev = motion_frames.device
-    owner = torch.cat([torch.full((p.shape[0],), b, dtype=torch.int64, device=dev) for b, p in enumerate(char_point_samples)])
-    local = torch.cat([p.to(dev) for p in char_point_samples], dim=0)
-    return torch_util.quat_rotate(body_rot[..., owner, :], local.expand(body_rot.shape[:-2] + local.shape)) + body_pos[..., owner, :], owner
+    return bp.world(body_pos, body_rot), bp.owner
 
 
 def motion_frames_hf_sdf_loss(motion_frames, char_point_samples, hf, hf_min_box_center, hf_dxdy, char_model, ret_vis_info=False,

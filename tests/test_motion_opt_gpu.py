@@ -188,3 +188,30 @@ def test_pose_chain_and_sdf_edge_cases(km, oracle):
     assert torch.isnan(out[0, 0]) and torch.isfinite(out[0, 1:]).all()
     one = terrain_util.points_hf_sdf(T(near.astype(np.float32)), T(hf[:, :1, :1]), T(mbc), T(dxdy))
     close(one, oracle.points_hf_sdf(near.astype(np.float32), hf[:, :1, :1], mbc, dxdy), atol=1e-6, rtol=2e-7)
+
+
+def test_body_points_world_kernels_equal_the_torch_formula(km):
+    """parc_body_points_world / _grad against pos[owner] + quat_rotate(rot[owner], local) and its autograd, incl. a body without points
+    and a leading batch dimension."""
+    from parc_amd.util import geom_util, terrain_util, torch_util
+    torch.manual_seed(7)
+    pts = geom_util.get_char_point_samples(km)
+    pts[2] = pts[2][:0]                                       # a body that owns no point
+    bp = terrain_util.BodyPoints(pts, DEV)
+    assert bp.num_points == sum(int(p.shape[0]) for p in pts) and bp.start[3] == bp.start[2]
+    B = km.get_num_joints()
+    pos = torch.randn((2, 37, B, 3), device=DEV)
+    rot = torch.randn((2, 37, B, 4), device=DEV)
+    rot = rot / rot.norm(dim=-1, keepdim=True) * (1.0 + 0.01 * torch.randn((2, 37, B, 1), device=DEV))       # not exactly unit, like slerped frames
+    a = [pos.clone().requires_grad_(True), rot.clone().requires_grad_(True)]
+    b = [pos.clone().requires_grad_(True), rot.clone().requires_grad_(True)]
+    w = bp.world(a[0], a[1])
+    ref = torch_util.quat_rotate(b[1][..., bp.owner, :], bp.local.expand(2, 37, bp.num_points, 3)) + b[0][..., bp.owner, :]
+    assert w.shape == ref.shape == (2, 37, bp.num_points, 3)
+    close(w, ref.detach().cpu().numpy(), atol=2e-6, rtol=0)
+    cot = torch.randn_like(ref)
+    w.backward(cot)
+    ref.backward(cot)
+    for x, y in zip(a, b):
+        assert float((x.grad - y.grad).abs().max()) <= 2e-5 * float(y.grad.abs().max())
+    assert float(a[0].grad[..., 2, :].abs().max()) == 0.0 and float(a[1].grad[..., 2, :].abs().max()) == 0.0
