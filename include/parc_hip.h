@@ -181,6 +181,11 @@ int parc_body_points_world(void *stream, int n_frames, int num_bodies, int num_p
 int parc_body_points_world_grad(void *stream, int n_frames, int num_bodies, int num_points, const float *body_rot, const float *local,
                                 const int32_t *start, const float *g_world, float *g_body_pos, float *g_body_rot);
 
+/* torch_util.quat_diff_angle (util/torch_util.py:427-431) for n quaternion pairs and its adjoint (g_q0, g_q1 [n,4] overwritten):
+ * the rotation-error terms of stage 2's optimiser (motion_optimization.py:203-221). */
+int parc_quat_diff_angle(void *stream, int64_t n, const float *q0, const float *q1, float *angle);
+int parc_quat_diff_angle_grad(void *stream, int64_t n, const float *q0, const float *q1, const float *g_angle, float *g_q0, float *g_q1);
+
 /* ---- K3: MotionLib.calc_motion_frame  anim/motion_lib.py:80-112 (contact_info=True)
  * outputs AoS: root_pos[Q,3] root_rot[Q,4] root_vel[Q,3] root_ang_vel[Q,3] joint_rot[Q,J,4] dof_vel[Q,D] contacts[Q,B] */
 int parc_calc_motion_frame(void *stream, parc_motion_lib_t mlib, int n_queries, const int64_t *motion_ids,

@@ -729,6 +729,55 @@ __global__ __launch_bounds__(64) void pose_chain_bwd_kernel(parc_char_model_t m,
     st3(g_root_exp + 3 * (size_t)i, exp_map_to_quat_bwd(em, rot[0], qadd(grot[0], ld4(g_root_quat + 4 * (size_t)i))));
 }
 
+// Angle between two rotations, torch_util.quat_diff_angle(q0, q1) = angle of q1 (x) conj(q0) (util/torch_util.py:421-431,68-88: the
+// w >= 0 representative, 2 atan2(|v|, w), 0 below |v| = 1e-5), and its adjoint; one thread per pair.  The optimiser evaluates it for
+// the root, every joint and every body-to-next-frame pair of every frame.
+__global__ __launch_bounds__(256) void quat_diff_angle_kernel(size_t n, const float *__restrict__ q0, const float *__restrict__ q1, float *angle) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const q4 d = quat_mul(ld4(q1 + 4 * i), quat_conj(ld4(q0 + 4 * i)));
+    const float s = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+    angle[i] = s > 1e-5f ? 2.0f * atan2f(s, fabsf(d.w)) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void quat_diff_angle_grad_kernel(size_t n, const float *__restrict__ q0, const float *__restrict__ q1,
+                                                                   const float *__restrict__ g_angle, float *g_q0, float *g_q1) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const q4 a = ld4(q0 + 4 * i), b = ld4(q1 + 4 * i);
+    const q4 d = quat_mul(b, quat_conj(a));
+    const float s = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+    q4 ga = mk4(0.f, 0.f, 0.f, 0.f), gb = ga;
+    if (s > 1e-5f) {
+        const float sg = d.w < 0.f ? -1.0f : 1.0f;           // quat_pos: the representative with w >= 0
+        const float w = sg * d.w, den = s * s + w * w, g = g_angle[i];
+        const float gs = 2.0f * w / den * g / s;               // d angle / d|v| * (v / |v|), on the flipped vector part ...
+        const q4 gd = q4{sg * gs * (sg * d.x), sg * gs * (sg * d.y), sg * gs * (sg * d.z), sg * (-2.0f * s / den * g)};     // ... and flipped back
+        gb = quat_mul(gd, a);                                   // d = b (x) conj(a):  g_b = g_d (x) a
+        const q4 gc = quat_mul(quat_conj(b), gd);               //                     g_conj(a) = conj(b) (x) g_d
+        ga = q4{-gc.x, -gc.y, -gc.z, gc.w};
+    }
+    st4(g_q0 + 4 * i, ga);
+    st4(g_q1 + 4 * i, gb);
+}
+
+extern "C" int parc_quat_diff_angle(void *stream, int64_t n, const float *q0, const float *q1, float *angle) {
+    if (n < 0) return PARC_EINVAL;
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(quat_diff_angle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (size_t)n, q0, q1, angle);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+extern "C" int parc_quat_diff_angle_grad(void *stream, int64_t n, const float *q0, const float *q1, const float *g_angle, float *g_q0, float *g_q1) {
+    if (n < 0) return PARC_EINVAL;
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(quat_diff_angle_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (size_t)n, q0, q1, g_angle,
+                       g_q0, g_q1);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
 // Sample points of the bodies in the world frame, x[t, p] = pos[t, owner(p)] + rotate(rot[t, owner(p)], local[p]), and the adjoint
 // (the points of a body are contiguous: body b owns [start[b], start[b + 1])), one thread per point / per (frame, body).
 __global__ __launch_bounds__(256) void body_points_world_kernel(int n_frames, int B, int P, const float *__restrict__ body_pos,

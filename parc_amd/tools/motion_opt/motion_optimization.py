@@ -250,7 +250,9 @@ class _Problem:
 
 
 def _diff_angle(q0, q1):
-    """torch_util.quat_diff_angle with the compact quaternion product"""
+    """torch_util.quat_diff_angle: one launch (and one for its adjoint) on the GPU, torch ops elsewhere"""
+    if q0.is_cuda:
+        return torch_util.quat_diff_angle_fused(q0, q1)
     return torch_util.quat_to_axis_angle(torch_util.quat_mul_compact(q1, torch_util.quat_conjugate(q0)))[1]
 
 

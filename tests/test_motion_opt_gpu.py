@@ -215,3 +215,28 @@ def test_body_points_world_kernels_equal_the_torch_formula(km):
     for x, y in zip(a, b):
         assert float((x.grad - y.grad).abs().max()) <= 2e-5 * float(y.grad.abs().max())
     assert float(a[0].grad[..., 2, :].abs().max()) == 0.0 and float(a[1].grad[..., 2, :].abs().max()) == 0.0
+
+
+def test_quat_diff_angle_kernels_equal_torch():
+    """parc_quat_diff_angle / _grad against torch_util.quat_diff_angle and its autograd: random pairs, identical pairs (the zero branch),
+    antipodal representatives (w < 0) and a broadcast operand."""
+    from parc_amd.util import torch_util
+    torch.manual_seed(11)
+    a = torch.randn((7, 33, 4), device=DEV)
+    b = torch.randn((7, 33, 4), device=DEV)
+    a, b = a / a.norm(dim=-1, keepdim=True), b / b.norm(dim=-1, keepdim=True)
+    b[0, :5] = a[0, :5]
+    b[1, :5] = -a[1, :5] * 1.0
+    b[2] = torch_util.quat_mul(torch_util.exp_map_to_quat(1e-3 * torch.randn((33, 3), device=DEV)), a[2])       # small angles
+    for q0, q1 in ((a, b), (a[:, :1], b)):
+        x = [q0.clone().requires_grad_(True), q1.clone().requires_grad_(True)]
+        y = [q0.clone().requires_grad_(True), q1.clone().requires_grad_(True)]
+        got, ref = torch_util.quat_diff_angle_fused(*x), torch_util.quat_diff_angle(*y)
+        assert got.shape == ref.shape
+        close(got, ref.detach().cpu().numpy(), atol=3e-6, rtol=1e-5)
+        cot = torch.randn_like(ref)
+        got.backward(cot)
+        ref.backward(cot)
+        for u, v in zip(x, y):
+            assert u.grad.shape == v.grad.shape
+            assert float((u.grad - v.grad).abs().max()) <= 3e-4 * max(float(v.grad.abs().max()), 1.0), float((u.grad - v.grad).abs().max())
