@@ -310,7 +310,8 @@ def motion_contact_optimization(src_frames, contacts, body_points, terrain, char
               src_frames[:, 6:34].clone().requires_grad_(True)]
     on_gpu = src_frames.is_cuda
     use_graph = on_gpu if use_graph is None else use_graph
-    optimizer = torch.optim.Adam(params, lr=step_size, capturable=bool(use_graph))
+    # one multi-tensor launch per step on the GPU (same update rule)
+    optimizer = torch.optim.Adam(params, lr=step_size, capturable=bool(use_graph), **({"fused": True} if on_gpu else {}))
     log_iter_stride = 25
     logger = build_logger(log_file=log_file, exp_name=exp_name, use_wandb=use_wandb)
     # the iteration's outputs live in fixed buffers: [total, nine terms]
