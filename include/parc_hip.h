@@ -186,6 +186,17 @@ int parc_body_points_world_grad(void *stream, int n_frames, int num_bodies, int 
 int parc_quat_diff_angle(void *stream, int64_t n, const float *q0, const float *q1, float *angle);
 int parc_quat_diff_angle_grad(void *stream, int64_t n, const float *q0, const float *q1, const float *g_angle, float *g_q0, float *g_q1);
 
+/* Frame-to-frame terms of stage 2's motion loss per (frame, body) and their adjoint (motion_optimization.py:215-224,346-362):
+ * partial [3, T, B] = smoothness |v - v_src|^2 + r, sliding pseudo-Huber terms (masked by `keep`, weighted by `pair_contact`), jerk
+ * max(|third difference of body_pos| - jerk_limit, 0); v = body_pos[t+1] - body_pos[t]; rot_err_sq / src_vel / keep / pair_contact are
+ * [T-1, B(,3)] (row T-1 of the [T, B] index space is not read).  The caller sums the partials; the adjoint takes the cotangents of the
+ * three sums (device, 3 floats) and overwrites g_body_pos [T,B,3] and g_rot_err_sq [T-1,B]. */
+int parc_temporal_terms(void *stream, int n_frames, int num_bodies, const float *body_pos, const float *rot_err_sq, const float *src_vel,
+                        const float *keep, const float *pair_contact, float c, float c2, float jerk_limit, float *partial);
+int parc_temporal_terms_grad(void *stream, int n_frames, int num_bodies, const float *body_pos, const float *rot_err_sq, const float *src_vel,
+                             const float *keep, const float *pair_contact, float c, float c2, float jerk_limit, const float *cotangents,
+                             float *g_body_pos, float *g_rot_err_sq);
+
 /* ---- K3: MotionLib.calc_motion_frame  anim/motion_lib.py:80-112 (contact_info=True)
  * outputs AoS: root_pos[Q,3] root_rot[Q,4] root_vel[Q,3] root_ang_vel[Q,3] joint_rot[Q,J,4] dof_vel[Q,D] contacts[Q,B] */
 int parc_calc_motion_frame(void *stream, parc_motion_lib_t mlib, int n_queries, const int64_t *motion_ids,

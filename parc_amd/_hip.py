@@ -152,6 +152,8 @@ def _declare(L):
     L.parc_body_points_world_grad.argtypes = [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]
     L.parc_quat_diff_angle.argtypes = [c_vp, ctypes.c_int64, c_vp, c_vp, c_vp]
     L.parc_quat_diff_angle_grad.argtypes = [c_vp, ctypes.c_int64, c_vp, c_vp, c_vp, c_vp, c_vp]
+    L.parc_temporal_terms.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_f, c_f, c_vp]
+    L.parc_temporal_terms_grad.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_f, c_f, c_vp, c_vp, c_vp]
     L.parc_calc_motion_frame.argtypes = [c_vp, MotionLibS, c_int, c_vp, c_vp] + [c_vp] * 7
     L.parc_motion_lib_build.argtypes = [c_vp, CharModelS, MotionLibS, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
     L.parc_track_post_step.argtypes = [c_vp, CharModelS, MotionLibS, TerrainS, TrackCfgS, EnvBuffersS, c_vp, c_int, c_int, c_vp]
@@ -213,7 +215,7 @@ EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hf
             "parc_action_head", "parc_points_hf_sdf", "parc_moments_workspace_floats", "parc_moments_accumulate", "parc_reset_sample_apply", "parc_return_tracker_workspace_floats", "parc_scale_by_clipped_norm", "parc_relu_bwd_workspace_floats",
             "parc_relu_bwd_bias_grad", "parc_ppo_loss_packed", "parc_weighted_colsum", "parc_sgd_workspace_floats", "parc_sgd_momentum_step",
             "parc_pose_chain_forward", "parc_pose_chain_backward", "parc_points_hf_sdf_grad", "parc_body_points_world", "parc_body_points_world_grad",
-            "parc_quat_diff_angle", "parc_quat_diff_angle_grad"]
+            "parc_quat_diff_angle", "parc_quat_diff_angle_grad", "parc_temporal_terms", "parc_temporal_terms_grad"]
 
 
 def check(rc, what):

@@ -778,6 +778,101 @@ extern "C" int parc_quat_diff_angle_grad(void *stream, int64_t n, const float *q
     return PARC_OK;
 }
 
+// The frame-to-frame terms of stage 2's motion loss (tools/motion_opt/motion_optimization.py:215-224,346-362) per (frame, body), and
+// their adjoint: smoothness |v - v_src|^2 + r, sliding (pseudo-Huber of the same errors where the constraint mask keeps them, times the
+// contact of the frame pair), jerk max(|third difference| - limit, 0); v = p[t+1] - p[t], r = squared rotation-speed error (an input).
+// Forward writes the three partial terms per (t, b) (summed by one reduction afterwards); backward gathers, per (t, b), the
+// contributions of the (at most) two velocity errors and four third differences that contain p[t, b] - no atomics.
+struct tt_args { float c, c2, jerk_limit; };
+
+PARC_DEV v3 tt_vel_err(const float *__restrict__ pos, const float *__restrict__ src_vel, int B, int t, int b) {
+    return (ld3(pos + ((size_t)(t + 1) * B + b) * 3) - ld3(pos + ((size_t)t * B + b) * 3)) - ld3(src_vel + ((size_t)t * B + b) * 3);
+}
+PARC_DEV v3 tt_third_diff(const float *__restrict__ pos, int B, int t, int b) {
+    const v3 p0 = ld3(pos + ((size_t)t * B + b) * 3), p1 = ld3(pos + ((size_t)(t + 1) * B + b) * 3), p2 = ld3(pos + ((size_t)(t + 2) * B + b) * 3),
+             p3 = ld3(pos + ((size_t)(t + 3) * B + b) * 3);
+    return ((p3 - p2) - (p2 - p1)) - ((p2 - p1) - (p1 - p0));      // (a[t+1] - a[t]) of the velocities' differences, like the torch expression
+}
+
+__global__ __launch_bounds__(256) void temporal_terms_kernel(int T, int B, const float *__restrict__ pos, const float *__restrict__ rot_err_sq,
+                                                             const float *__restrict__ src_vel, const float *__restrict__ keep,
+                                                             const float *__restrict__ pair_contact, tt_args a, float *partial) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * B) return;
+    const int t = i / B, b = i - t * B;
+    float sm = 0.f, sl = 0.f, jl = 0.f;
+    if (t < T - 1) {
+        const v3 e = tt_vel_err(pos, src_vel, B, t, b);
+        const float e2 = (e.x * e.x + e.y * e.y) + e.z * e.z, r = rot_err_sq[i], k = keep[i], pc = pair_contact[i];
+        sm = e2 + r;
+        sl = (sqrtf(k * e2 + a.c2) - a.c) * pc + (sqrtf(k * r + a.c2) - a.c) * pc;
+    }
+    if (t < T - 3) {
+        const v3 j = tt_third_diff(pos, B, t, b);
+        jl = fmaxf(sqrtf(dot3(j, j)) - a.jerk_limit, 0.f);
+    }
+    const size_t n = (size_t)T * B;
+    partial[i] = sm;
+    partial[n + i] = sl;
+    partial[2 * n + i] = jl;
+}
+
+__global__ __launch_bounds__(256) void temporal_terms_grad_kernel(int T, int B, const float *__restrict__ pos, const float *__restrict__ rot_err_sq,
+                                                                  const float *__restrict__ src_vel, const float *__restrict__ keep,
+                                                                  const float *__restrict__ pair_contact, tt_args a,
+                                                                  const float *__restrict__ w /* cotangents of the 3 sums */, float *g_pos,
+                                                                  float *g_rot_err_sq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * B) return;
+    const int t = i / B, b = i - t * B;
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    v3 g = mk3(0.f, 0.f, 0.f);
+    // velocity errors of the pairs (t-1, t) [+] and (t, t+1) [-]
+    for (int k = 0; k < 2; ++k) {
+        const int tp = t - 1 + k;
+        if (tp < 0 || tp >= T - 1) continue;
+        const v3 e = tt_vel_err(pos, src_vel, B, tp, b);
+        const float e2 = (e.x * e.x + e.y * e.y) + e.z * e.z;
+        const size_t ip = (size_t)tp * B + b;
+        const float f = (k == 0 ? 1.f : -1.f) * (2.f * w0 + w1 * pair_contact[ip] * keep[ip] / sqrtf(keep[ip] * e2 + a.c2));
+        g = g + f * e;
+    }
+    // third differences j[t-3] (+1), j[t-2] (-3), j[t-1] (+3), j[t] (-1)
+    const float coef[4] = {1.f, -3.f, 3.f, -1.f};
+    for (int k = 0; k < 4; ++k) {
+        const int tj = t - 3 + k;
+        if (tj < 0 || tj >= T - 3) continue;
+        const v3 j = tt_third_diff(pos, B, tj, b);
+        const float jn = sqrtf(dot3(j, j));
+        if (jn - a.jerk_limit >= 0.f && jn > 0.f) g = g + (w2 * coef[k] / jn) * j;
+    }
+    st3(g_pos + (size_t)i * 3, g);
+    if (t < T - 1) g_rot_err_sq[i] = w0 + w1 * pair_contact[i] * keep[i] / (2.f * sqrtf(keep[i] * rot_err_sq[i] + a.c2));
+}
+
+extern "C" int parc_temporal_terms(void *stream, int n_frames, int num_bodies, const float *body_pos, const float *rot_err_sq, const float *src_vel,
+                                   const float *keep, const float *pair_contact, float c, float c2, float jerk_limit, float *partial) {
+    if (n_frames < 0 || num_bodies <= 0) return PARC_EINVAL;
+    const int n = n_frames * num_bodies;
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(temporal_terms_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_frames, num_bodies, body_pos, rot_err_sq,
+                       src_vel, keep, pair_contact, tt_args{c, c2, jerk_limit}, partial);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
+extern "C" int parc_temporal_terms_grad(void *stream, int n_frames, int num_bodies, const float *body_pos, const float *rot_err_sq,
+                                        const float *src_vel, const float *keep, const float *pair_contact, float c, float c2, float jerk_limit,
+                                        const float *cotangents, float *g_body_pos, float *g_rot_err_sq) {
+    if (n_frames < 0 || num_bodies <= 0) return PARC_EINVAL;
+    const int n = n_frames * num_bodies;
+    if (n == 0) return PARC_OK;
+    hipLaunchKernelGGL(temporal_terms_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_frames, num_bodies, body_pos,
+                       rot_err_sq, src_vel, keep, pair_contact, tt_args{c, c2, jerk_limit}, cotangents, g_body_pos, g_rot_err_sq);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
+}
+
 // Sample points of the bodies in the world frame, x[t, p] = pos[t, owner(p)] + rotate(rot[t, owner(p)], local[p]), and the adjoint
 // (the points of a body are contiguous: body b owns [start[b], start[b + 1])), one thread per point / per (frame, body).
 __global__ __launch_bounds__(256) void body_points_world_kernel(int n_frames, int B, int P, const float *__restrict__ body_pos,

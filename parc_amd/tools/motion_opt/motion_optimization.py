@@ -204,10 +204,17 @@ class _Problem:
         tgt_rq, tgt_jr, body_pos, body_rot = km.pose_chain(tgt_root_pos, tgt_root_rot, tgt_joint_dof)
         root_rot_loss = torch.sum(torch.square(_diff_angle(tgt_rq, s_rq)))
         joint_rot_loss = torch.sum(torch.square(_diff_angle(tgt_jr, s_jr)))
-        body_vels = body_pos[1:] - body_pos[:-1]
-        vel_err_sq = torch.square(body_vels - s_bv)
         rot_vel_err_sq = torch.square(_diff_angle(body_rot[1:], body_rot[:-1]) - s_brv)
-        smoothness_loss = torch.sum(vel_err_sq) + torch.sum(rot_vel_err_sq)
+        dt = 1.0 / 30.0                 # the reference hard-codes the frame time (:360)
+        fused_terms = body_pos.is_cuda and int(body_pos.shape[0]) >= 4
+        if fused_terms:
+            # smoothness, sliding and jerk sums of the frame-to-frame errors: one launch + one reduction (and one launch back)
+            tt = _TemporalTerms.apply(body_pos, rot_vel_err_sq, s_bv.contiguous(), self.pair_keep, self.pair_contact, max_jerk * dt ** 3)
+            smoothness_loss = tt[0]
+        else:
+            body_vels = body_pos[1:] - body_pos[:-1]
+            vel_err_sq = torch.square(body_vels - s_bv)
+            smoothness_loss = torch.sum(vel_err_sq) + torch.sum(rot_vel_err_sq)
 
         T, P = int(tgt_root_pos.shape[0]), int(self.local.shape[0])
         world = self.points.world(body_pos, body_rot)                      # [T, P, 3], one launch (and one for its adjoint)
@@ -229,17 +236,20 @@ class _Problem:
         if self.box is not None:        # box bodies (feet): every sole point within 1.25 box diagonals of the point (:306-322)
             f, p, pt, r = self.box
             body_constraint_loss = body_constraint_loss + torch.sum(torch.clamp(geom_util.sdSphere(pt, world[f, p], r), min=0.0))
-        if w["w_sliding"] != 0.0:
-            c, c2 = 0.03, 0.0009        # pseudo-Huber
-            k = self.pair_keep
-            sliding_loss = torch.sum((torch.sqrt(torch.sum(vel_err_sq * k.unsqueeze(-1), dim=-1) + c2) - c) * self.pair_contact) \
-                + torch.sum((torch.sqrt(rot_vel_err_sq * k + c2) - c) * self.pair_contact)
+        if fused_terms:
+            sliding_loss = tt[1] if w["w_sliding"] != 0.0 else zero
+            jerk_loss = tt[2]
         else:
-            sliding_loss = zero
-        acc = body_vels[1:] - body_vels[:-1]
-        jerk = torch.linalg.vector_norm(acc[1:] - acc[:-1], dim=-1)
-        dt = 1.0 / 30.0                 # the reference hard-codes the frame time (:360)
-        jerk_loss = torch.sum(torch.clamp(jerk - max_jerk * dt ** 3, min=0.0))
+            if w["w_sliding"] != 0.0:
+                c, c2 = 0.03, 0.0009        # pseudo-Huber
+                k = self.pair_keep
+                sliding_loss = torch.sum((torch.sqrt(torch.sum(vel_err_sq * k.unsqueeze(-1), dim=-1) + c2) - c) * self.pair_contact) \
+                    + torch.sum((torch.sqrt(rot_vel_err_sq * k + c2) - c) * self.pair_contact)
+            else:
+                sliding_loss = zero
+            acc = body_vels[1:] - body_vels[:-1]
+            jerk = torch.linalg.vector_norm(acc[1:] - acc[:-1], dim=-1)
+            jerk_loss = torch.sum(torch.clamp(jerk - max_jerk * dt ** 3, min=0.0))
 
         terms = torch.stack([root_pos_loss, root_rot_loss, joint_rot_loss, smoothness_loss, penetration_loss, contact_loss, sliding_loss, jerk_loss,
                              body_constraint_loss])
@@ -247,6 +257,36 @@ class _Problem:
             + w["w_smoothness"] * smoothness_loss + w["w_penetration"] * penetration_loss + w["w_contact"] * contact_loss \
             + w["w_sliding"] * sliding_loss + w["w_body_constraints"] * body_constraint_loss + w["w_jerk"] * jerk_loss
         return loss, terms
+
+
+class _TemporalTerms(torch.autograd.Function):
+    """(smoothness, sliding, jerk) sums of the frame-to-frame errors: per-(frame, body) partials in one launch + one reduction, the adjoint
+    in one launch (parc_temporal_terms / _grad).  rot_err_sq carries its own gradient (it comes from the rotation-angle kernel)."""
+
+    @staticmethod
+    def forward(ctx, body_pos, rot_err_sq, src_vel, keep, pair_contact, jerk_limit):
+        from ... import _hip
+        T, B = int(body_pos.shape[0]), int(body_pos.shape[1])
+        pos = body_pos.detach().to(torch.float32).contiguous()
+        r = rot_err_sq.detach().to(torch.float32).contiguous()
+        partial = torch.empty((3, T, B), dtype=torch.float32, device=pos.device)
+        ctx.args = (T, B, 0.03, 0.0009, float(jerk_limit))          # pseudo-Huber constants of the reference (:349-350)
+        _hip.check(_hip.lib().parc_temporal_terms(_hip.stream(), T, B, _hip.ptr(pos), _hip.ptr(r), _hip.ptr(src_vel), _hip.ptr(keep),
+                                                  _hip.ptr(pair_contact), ctx.args[2], ctx.args[3], ctx.args[4], _hip.ptr(partial)), "parc_temporal_terms")
+        ctx.save_for_backward(pos, r, src_vel, keep, pair_contact)
+        return partial.sum(dim=(1, 2))
+
+    @staticmethod
+    def backward(ctx, g):
+        from ... import _hip
+        pos, r, src_vel, keep, pair_contact = ctx.saved_tensors
+        T, B, c, c2, lim = ctx.args
+        g_pos, g_r = torch.empty_like(pos), torch.empty_like(r)
+        gg = g.to(torch.float32).contiguous()
+        _hip.check(_hip.lib().parc_temporal_terms_grad(_hip.stream(), T, B, _hip.ptr(pos), _hip.ptr(r), _hip.ptr(src_vel), _hip.ptr(keep),
+                                                       _hip.ptr(pair_contact), c, c2, lim, _hip.ptr(gg), _hip.ptr(g_pos), _hip.ptr(g_r)),
+                   "parc_temporal_terms_grad")
+        return g_pos, g_r, None, None, None, None
 
 
 def _diff_angle(q0, q1):

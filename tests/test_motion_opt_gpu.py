@@ -240,3 +240,35 @@ def test_quat_diff_angle_kernels_equal_torch():
         for u, v in zip(x, y):
             assert u.grad.shape == v.grad.shape
             assert float((u.grad - v.grad).abs().max()) <= 3e-4 * max(float(v.grad.abs().max()), 1.0), float((u.grad - v.grad).abs().max())
+
+
+def test_temporal_terms_kernels_equal_torch():
+    """parc_temporal_terms / _grad against the torch expressions of the smoothness, sliding and jerk terms and their autograd (values
+    and the vector-Jacobian product for random cotangents), incl. masked pairs and a jerk limit that clips part of the frames."""
+    from parc_amd.tools.motion_opt import motion_optimization as mo
+    torch.manual_seed(5)
+    for T_, B in ((37, 15), (4, 3), (5, 1)):
+        pos = torch.randn((T_, B, 3), device=DEV)
+        r = torch.rand((T_ - 1, B), device=DEV)
+        s_bv = 0.3 * torch.randn((T_ - 1, B, 3), device=DEV)
+        keep = (torch.rand((T_ - 1, B), device=DEV) > 0.3).float()
+        pc = torch.rand((T_ - 1, B), device=DEV)
+        lim = 1.5
+        a = [pos.clone().requires_grad_(True), r.clone().requires_grad_(True)]
+        b = [pos.clone().requires_grad_(True), r.clone().requires_grad_(True)]
+        got = mo._TemporalTerms.apply(a[0], a[1], s_bv, keep, pc, lim)
+        v = b[0][1:] - b[0][:-1]
+        e2 = torch.square(v - s_bv)
+        c, c2 = 0.03, 0.0009
+        smooth = e2.sum() + b[1].sum()
+        slide = ((torch.sqrt((e2 * keep.unsqueeze(-1)).sum(-1) + c2) - c) * pc).sum() + ((torch.sqrt(b[1] * keep + c2) - c) * pc).sum()
+        acc = v[1:] - v[:-1]
+        jl = torch.clamp(torch.linalg.vector_norm(acc[1:] - acc[:-1], dim=-1) - lim, min=0.0).sum()
+        ref = torch.stack([smooth, slide, jl])
+        close(got, ref.detach().cpu().numpy(), atol=1e-4, rtol=2e-5)
+        assert float(jl.detach()) > 0 or T_ < 37
+        cot = torch.tensor([1.3, -0.7, 2.1], device=DEV)
+        got.backward(cot)
+        ref.backward(cot)
+        for x, y in zip(a, b):
+            assert float((x.grad - y.grad).abs().max()) <= 3e-5 * max(float(y.grad.abs().max()), 1.0), float((x.grad - y.grad).abs().max())
