@@ -12,7 +12,6 @@ Motion files are read with the non-executing reader (parc_amd.util.safe_pickle) 
 """
 import enum
 import os
-import pickle
 
 import numpy as np
 import torch
@@ -94,8 +93,7 @@ class MotionLib:
 
     def _load_one(self, path):
         if self._unsafe_pickle:
-            with open(path, "rb") as f:
-                data = pickle.load(f)
+            data = safe_pickle.load_executing(path)
             ter = data.get("terrain")
             return data, ter
         data = safe_pickle.load_motion_file_safe(path)

@@ -7,7 +7,6 @@ kernels; this class owns the bookkeeping tensors and the sampling logic that the
 RNG calls (multinomial / rand) at reset time.
 """
 import os
-import pickle
 
 import numpy as np
 import torch
@@ -127,7 +126,7 @@ class DeepMimicEnv:
         from ...util import safe_pickle
         with open(env_config["dm"]["motion_file"], "r") as f:
             my = yaml.safe_load(f)
-        loader = (lambda p: pickle.load(open(p, "rb"))) if env_config["dm"].get("unsafe_pickle", False) else safe_pickle.load_motion_file_safe
+        loader = safe_pickle.load_executing if env_config["dm"].get("unsafe_pickle", False) else safe_pickle.load_motion_file_safe
         t = loader(my["terrain"])["terrain"]
         if isinstance(t, dict):
             t = terrain_util.SubTerrain.from_arrays(t["hf"], t["min_point"], t["dxdy"], t.get("hf_mask"), t.get("hf_maxmin"), device=self._device)

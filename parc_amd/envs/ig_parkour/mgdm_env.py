@@ -17,8 +17,9 @@ How it sits on the MI355X path:
   replan decision costs no read-back.
 
 The generator is a callable ``generator(target_xy, prev_frames, terrain, char_model, settings) -> MotionFrames`` with the attributes
-the reference reads from its model object (``_num_prev_states``, ``_sequence_fps``, ``_dx/_dy/_num_x_neg/...``).  The reference's own
-trained diffusion model (stage 1's ``diffusion.mdm.MDM``, outside this package's scope) plugs in through ``ReferenceMDMGenerator``.
+the reference reads from its model object (``_num_prev_states``, ``_sequence_fps``, ``_dx/_dy/_num_x_neg/...``).  It is the ONLY entry:
+this package imports nothing of the reference's ``diffusion`` package and opens no model file; the adapter that wraps stage 1's trained
+``diffusion.mdm.MDM`` is user-side code, and ``mgdm.model_path`` without a generator is an error.
 Checked against fixture G21 (the reference's class driven on CPU with a recorded stand-in generator).
 """
 import enum
@@ -56,30 +57,6 @@ class MDMGenSettings:
     ddim_stride = 10
 
 
-class ReferenceMDMGenerator:
-    """Adapter for the reference's trained model: ``pickle.load`` of stage 1's ``mdm.MDM`` object and generation through the
-    reference's ``diffusion.gen_util.gen_mdm_motion`` - both need the reference's ``diffusion`` package importable (pure torch, runs
-    on ROCm as it is).  Loading executes the pickle like the reference's load_mdm (:32-35): opt in with ``mgdm.unsafe_pickle: true``."""
-
-    def __init__(self, model_path, allow_pickle):
-        if not allow_pickle:
-            raise RuntimeError("mgdm.model_path is a pickled model object; loading it executes the file - set mgdm.unsafe_pickle: true to "
-                               "allow that, or pass a generator object as mgdm.generator")
-        import pickle
-        import diffusion.gen_util as gen_util            # the reference's package (not part of this one)
-        with open(model_path, "rb") as f:
-            self._model = pickle.load(f)
-        self._gen_util = gen_util
-        for name in ("_num_prev_states", "_sequence_fps", "_dx", "_dy", "_num_x_neg", "_num_x_pos", "_num_y_neg", "_num_y_pos", "_target_type"):
-            setattr(self, name, getattr(self._model, name))
-
-    def __call__(self, target_xy, prev_frames, terrain, char_model, settings):
-        s = self._gen_util.MDMGenSettings()
-        for k in ("ddim_stride", "use_cfg", "use_prev_state", "prev_state_ind_key"):
-            setattr(s, k, getattr(settings, k))
-        return self._gen_util.gen_mdm_motion(target_xy, prev_frames, terrain, self._model, char_model, s, verbose=False)
-
-
 class MotionGenDeepMimicEnv:
     def __init__(self, config, num_envs, device, visualize, char_model, generator=None, rand_fn=None):
         env_config = config["env"]
@@ -108,7 +85,12 @@ class MotionGenDeepMimicEnv:
 
         gen = generator if generator is not None else mg.get("generator")
         if gen is None:
-            gen = ReferenceMDMGenerator(mg["model_path"], bool(mg.get("unsafe_pickle", False)))
+            # reference :32-35 load_mdm unpickles a model object of its diffusion package here; this package does neither
+            raise RuntimeError("rows under the motion-generator sub-env (fraction_dm_envs < 1) need a planner: pass a callable "
+                               "generator(target_xy, prev_frames, terrain, char_model, settings) -> MotionFrames as mgdm.generator"
+                               + (" -- mgdm.model_path ({!r}) is not opened by this package; wrap the reference's trained model with the "
+                                  "user-side adapter of INTEGRATION.md section 3 and hand it over as mgdm.generator".format(mg["model_path"])
+                                  if mg.get("model_path") else ""))
         self._mgen = gen
         self._num_prev_states = gen._num_prev_states
         assert self._num_prev_states > 1, "the env keeps the one-frame state histories the generator continues from"

@@ -266,3 +266,12 @@ def load_motion_file_safe(path):
     with open(path, "rb") as f:
         data = f.read()
     return materialize(load_inert(data))
+
+
+def load_executing(path):
+    """The ONE place in this package that hands a file to ``pickle.load`` (as the reference does everywhere, e.g. anim/motion_lib.py:240):
+    reached only through the explicit ``unsafe_pickle`` opt-ins of MotionLib / DeepMimicEnv / motion_edit_lib.load_motion_file, for files
+    the user wrote themselves.  Never used on the files that ship with the reference."""
+    import pickle
+    with open(path, "rb") as f:
+        return pickle.load(f)

@@ -121,9 +121,7 @@ class MotionData:
 
 def load_motion_file(motion_filepath, device="cpu", unsafe_pickle=False):
     if unsafe_pickle:
-        import pickle
-        with open(motion_filepath, "rb") as f:
-            data = pickle.load(f)
+        data = safe_pickle.load_executing(motion_filepath)
     else:
         data = dict(safe_pickle.load_motion_file_safe(motion_filepath))
     return MotionData(data, device=device)

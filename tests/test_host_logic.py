@@ -640,13 +640,19 @@ def test_mgdm_terrain_build_and_pose_containers_against_g21(tmp_path):
     env2.load_terrain(path)
     assert torch.equal(env2._terrain.hf, env._terrain.hf) and env2._spawn_max_x == env._spawn_max_x and env2._oob_region == env._oob_region
     assert env.get_target_dim() == 2
-    # a pickled model object is only loaded on request (the reference's load_mdm executes the file, mgdm_env.py:32-35)
+    # the package opens no model file and imports nothing of the reference's diffusion package (its load_mdm, mgdm_env.py:32-35, unpickles
+    # a model object): without a generator callable the sub-env refuses, and mgdm.model_path points the user at INTEGRATION.md
     cfg_model = json.loads(bytes(g["config_json"]).decode())
-    with pytest.raises(RuntimeError, match="unsafe_pickle"):
+    assert cfg_model["env"]["mgdm"]["model_path"]
+    with pytest.raises(RuntimeError, match="mgdm.generator.*INTEGRATION.md"):
         mgdm_env.MotionGenDeepMimicEnv(cfg_model, 8, "cpu", False, km)
-    cfg_model["env"]["mgdm"]["unsafe_pickle"] = True
-    with pytest.raises(ModuleNotFoundError, match="diffusion"):       # ... and then needs the reference's own diffusion package
+    cfg_model["env"]["mgdm"]["unsafe_pickle"] = True                 # the round-2 opt-in switch no longer exists
+    with pytest.raises(RuntimeError, match="mgdm.generator"):
         mgdm_env.MotionGenDeepMimicEnv(cfg_model, 8, "cpu", False, km)
+    del cfg_model["env"]["mgdm"]["model_path"]
+    with pytest.raises(RuntimeError, match="need a planner"):
+        mgdm_env.MotionGenDeepMimicEnv(cfg_model, 8, "cpu", False, km)
+    assert not hasattr(mgdm_env, "ReferenceMDMGenerator")
     # pose containers
     a = motion_util.MotionFrames()
     a.init_blank_frames(km, 2, batch_size=3)
