@@ -131,6 +131,16 @@ class MotionLib:
         return out
 
 
+    def slerp_cosines(self, ids, times):
+        """-> (|cos half angle| [Q, 1 + J] as slerp evaluates it for the frame pair of each query, blend [Q]); column 0 = root rotation"""
+        ids = _l(ids); times = _f(times)
+        Q = ids.shape[0]
+        cos = np.zeros((Q, self.J + 1), np.float32)
+        blend = np.zeros(Q, np.float32)
+        lib().orc_slerp_cosines(*self.args(), c_int(Q), _p(ids), _p(times), _p(cos), _p(blend))
+        return cos, blend
+
+
 def _batch(name, n, ins, out_shape):
     out = np.zeros(out_shape, np.float32)
     getattr(lib(), name)(c_int(n), *[_p(x) for x in ins], _p(out))

@@ -423,6 +423,38 @@ void orc_calc_motion_frame(MLIB_ARGS, int Q, const int64_t *ids, const float *ti
                            dof_vel + (size_t)q * D, contacts + (size_t)q * B);
 }
 
+/* Diagnostic for the parity tests (not a reference function): |cos(half angle)| between the two frames a query blends, as slerp
+ * (util/torch_util.py:447-451) evaluates it in fp32, for the root rotation (column 0) and every joint (columns 1..J), plus the blend.
+ * slerp has two value discontinuities in that cosine: `cos >= 1 -> q0` (:466) and `sin < 0.001 -> plain average` (:465); a query whose
+ * cosine sits within an ulp or two of either is where a 1-ulp difference in a stored frame legitimately flips the branch. */
+void orc_slerp_cosines(MLIB_ARGS, int Q, const int64_t *ids, const float *times, float *out_cos, float *out_blend) {
+    MLIB_MAKE;
+#pragma omp parallel for schedule(static)
+    for (int q = 0; q < Q; ++q) {
+        const orc_mlib_t *m = &ml;
+        int64_t id = ids[q];
+        float len = m->length[id];
+        int wrap = (m->loop_mode[id] == 1);
+        float phase = times[q] / len;
+        if (wrap) phase = phase - floorf(phase);
+        if (phase < 0.f) phase = 0.f;
+        if (phase > 1.f) phase = 1.f;
+        int64_t nf = m->num_frames[id];
+        float fp = phase * (float)(nf - 1);
+        int64_t i0 = (int64_t)fp;
+        int64_t i1 = i0 + 1 < nf - 1 ? i0 + 1 : nf - 1;
+        out_blend[q] = fp - (float)i0;
+        i0 += m->start_idx[id];
+        i1 += m->start_idx[id];
+        for (int j = 0; j <= m->J; ++j) {
+            const float *a = j == 0 ? m->root_rot + 4 * i0 : m->joint_rot + ((size_t)i0 * m->J + (j - 1)) * 4;
+            const float *b = j == 0 ? m->root_rot + 4 * i1 : m->joint_rot + ((size_t)i1 * m->J + (j - 1)) * 4;
+            float c = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+            out_cos[(size_t)q * (m->J + 1) + j] = fabsf(c);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ heightfield (a8) */
 
 /* util/geom_util.py:249-270 + torch_util.rotate_2d_vec :619-631 ; out [num_rays*(num_neg+num_pos+1), 2] */

@@ -1031,7 +1031,7 @@ def gen_recorded_files():
 
 
 STAGES = ["core", "voxel-mesh", "dataset-yaml", "procgen", "terrain-geometry", "done-branches", "ppo-loss", "normalizer", "trackers",
-          "action-head", "recorded-files", "motion-opt", "mgdm", "motion-edit"]
+          "action-head", "recorded-files", "motion-opt", "mgdm", "motion-edit", "sim-config"]
 
 
 def _icosa_points(radius):
@@ -1350,6 +1350,149 @@ def gen_motion_edit():
     save("g22_motion_edit", **out)
 
 
+class _Rec:
+    """Recording stand-in for an Isaac Gym parameter object (gymapi.SimParams / AssetOptions / TriangleMeshParams ...): attribute
+    writes are kept, attribute reads create nested recorders - so running the reference's own set-up code on it yields exactly the
+    values the reference hands to Isaac Gym."""
+
+    def __init__(self):
+        object.__setattr__(self, "_d", {})
+
+    def __getattr__(self, k):
+        d = object.__getattribute__(self, "_d")
+        if k not in d:
+            d[k] = _Rec()
+        return d[k]
+
+    def __setattr__(self, k, v):
+        object.__getattribute__(self, "_d")[k] = v
+
+    def tree(self):
+        out = {}
+        for k, v in object.__getattribute__(self, "_d").items():
+            out[k] = v.tree() if isinstance(v, _Rec) else (v if isinstance(v, (int, float, str, bool)) or v is None else repr(v))
+        return out
+
+
+def gen_sim_config():
+    """G23: the simulator's CONFIGURATION - the only part of row a1 that can be pinned (Isaac Gym's arithmetic is an absent binary).
+    (1) data/assets/humanoid.xml parsed with ElementTree: every body / joint / geom / motor attribute, class defaults resolved;
+    (2) what the reference's own set-up code hands to Isaac Gym, recorded by running it on recording stand-ins for the gymapi objects:
+        IGEnv._parse_sim_params (envs/ig_env.py:131-164) on PARC/tracker_config/dm_env_default.yaml, IGCharEnv._build_char_asset_options
+        and _build_character (envs/ig_char_env.py:105-146), util/ig_util.add_trimesh_to_gym (:6-22);
+        gymutil.parse_sim_config is Isaac Gym's helper (absent): its stand-in copies the YAML's `sim:` keys onto the parameter object,
+        which is its documented behaviour (scalars onto SimParams, the `physx:` block onto SimParams.physx);
+    (3) the two default YAML trees (env + agent) as JSON."""
+    import json
+    import xml.etree.ElementTree as ET
+    import yaml
+    import envs.ig_env as ig_env
+    import util.ig_util as ig_util
+    root = ET.parse(os.path.join(REF, CHAR_FILE)).getroot()
+    dflt = {"motor": dict(root.find("default").find("motor").attrib)}
+    for d in root.find("default").findall("default"):
+        dflt[d.attrib["class"]] = {c.tag: dict(c.attrib) for c in d}
+    nums = lambda s_: [float(x) for x in s_.split()]
+    bodies = []
+
+    def walk(el, parent, cls):
+        cls = el.attrib.get("childclass", cls)
+        b = {"name": el.attrib["name"], "parent": parent, "pos": nums(el.attrib["pos"]), "class": cls, "freejoint": el.find("freejoint") is not None,
+             "joints": [], "geoms": []}
+        for j in el.findall("joint"):
+            a = dict(dflt[cls]["joint"])
+            a.update(j.attrib)
+            b["joints"].append({"name": a["name"], "type": a["type"], "axis": nums(a["axis"]), "range_deg": nums(a["range"]),
+                                "stiffness": float(a["stiffness"]), "damping": float(a["damping"]), "armature": float(a["armature"]),
+                                "limited": a["limited"]})
+        for g in el.findall("geom"):
+            a = dict(dflt[cls]["geom"])
+            a.update(g.attrib)
+            e = {"name": a["name"], "type": a["type"], "size": nums(a["size"]), "density": float(a["density"]), "friction": nums(a["friction"]),
+                 "condim": int(a["condim"])}
+            if "fromto" in a:
+                e["fromto"] = nums(a["fromto"])
+            if "pos" in a:
+                e["pos"] = nums(a["pos"])
+            b["geoms"].append(e)
+        bodies.append(b)
+        for c in el.findall("body"):
+            walk(c, b["name"], cls)
+    for top in root.find("worldbody").findall("body"):
+        walk(top, None, None)
+    motors = [{"name": m.attrib["name"], "joint": m.attrib["joint"], "gear": float(m.attrib["gear"])} for m in root.find("actuator").findall("motor")]
+    with open(os.path.join(REF, "PARC/tracker_config/dm_env_default.yaml")) as f:
+        env_yaml = yaml.safe_load(f)
+    with open(os.path.join(REF, "PARC/tracker_config/dm_agent_default.yaml")) as f:
+        agent_yaml = yaml.safe_load(f)
+    # ---- what the reference's set-up code hands to Isaac Gym
+    gymapi, gymutil = sys.modules["isaacgym.gymapi"], sys.modules["isaacgym.gymutil"]
+    saved = {k: getattr(gymapi, k, None) for k in ("SimParams", "AssetOptions", "TriangleMeshParams", "Transform", "Vec3", "Quat", "UP_AXIS_Z",
+                                                    "DOF_MODE_POS", "DOF_MODE_VEL", "DOF_MODE_EFFORT", "DOF_MODE_NONE")}
+    gymapi.SimParams = gymapi.AssetOptions = gymapi.TriangleMeshParams = gymapi.Transform = _Rec
+    gymapi.Vec3 = lambda *a: list(a)
+    gymapi.Quat = lambda *a: list(a)
+    gymapi.UP_AXIS_Z = "UP_AXIS_Z"
+    for m_ in ("DOF_MODE_POS", "DOF_MODE_VEL", "DOF_MODE_EFFORT", "DOF_MODE_NONE"):
+        setattr(gymapi, m_, m_)
+
+    def parse_sim_config(sim, params):
+        for k, v in sim.items():
+            if k == "physx":
+                for kk, vv in v.items():
+                    setattr(params.physx, kk, vv)
+            else:
+                setattr(params, k, v)
+    gymutil.parse_sim_config = parse_sim_config
+    try:
+        env_cfg = env_yaml["env"]
+        sim_freq, control_freq = env_cfg.get("sim_freq", 60), env_cfg.get("control_freq", 10)
+        stub = types.SimpleNamespace(_device="cuda:0")
+        sim_params = ig_env.IGEnv._parse_sim_params(stub, env_yaml, 1.0 / sim_freq).tree()
+        calls = []
+
+        class Gym:
+            def create_actor(self, env_ptr, asset, pose, name, col_group, col_filter, seg_id):
+                calls.append({"create_actor": {"name": name, "collision_group": col_group, "collision_filter": col_filter,
+                                               "segmentation_id": seg_id, "pose": pose.tree()}})
+                return "actor"
+
+            def get_asset_dof_properties(self, asset):
+                return {"driveMode": None, "stiffness": "from_asset", "damping": "from_asset"}
+
+            def set_actor_dof_properties(self, env_ptr, handle, prop):
+                calls.append({"set_actor_dof_properties": dict(prop)})
+
+            def add_triangle_mesh(self, sim, verts, tris, params):
+                calls.append({"add_triangle_mesh": params.tree()})
+
+            def enable_actor_dof_force_sensors(self, *a):
+                calls.append({"enable_actor_dof_force_sensors": True})
+        cstub = types.SimpleNamespace(_char_control_mode=ig_char_env.ControlMode[env_cfg["control_mode"]], _gym=Gym(), _char_asset="asset",
+                                      _char_handles=[], _enable_dof_force_sensors=lambda: False)
+        cstub._control_mode_to_drive_mode = lambda m: ig_char_env.IGCharEnv._control_mode_to_drive_mode(cstub, m)
+        asset_options = ig_char_env.IGCharEnv._build_char_asset_options(cstub, env_yaml).tree()
+        ig_char_env.IGCharEnv._build_character(cstub, 7, "env_ptr", env_yaml)          # env id 7: the collision group must come back as 7
+        ig_util.add_trimesh_to_gym(np.zeros((3, 3), np.float32), np.zeros((1, 3), np.int32), "sim", cstub._gym)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                if hasattr(gymapi, k):
+                    delattr(gymapi, k)
+            else:
+                setattr(gymapi, k, v)
+    out = {"mjcf": {"model": root.attrib.get("model"), "defaults": dflt, "bodies": bodies, "motors": motors},
+           "isaac_gym": {"sim_params": sim_params, "sim_steps_per_control_step": int(sim_freq / control_freq), "sim_dt": 1.0 / sim_freq,
+                         "control_dt": 1.0 / control_freq, "asset_options": asset_options, "calls": calls},
+           "env_yaml": env_yaml, "agent_yaml": agent_yaml}
+    path = os.path.join(OUT, "g23_sim_config.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print("wrote", path)
+
+
+
 def gen_core():
     rng = np.random.default_rng(0)
     torch.manual_seed(0)
@@ -1371,7 +1514,7 @@ def main():
     run = {"core": gen_core, "voxel-mesh": lambda: gen_voxel_mesh(np.random.default_rng(10)), "dataset-yaml": gen_dataset_yaml,
            "procgen": gen_procgen, "terrain-geometry": gen_terrain_geometry, "done-branches": gen_done_branches, "ppo-loss": gen_ppo_loss,
            "normalizer": gen_normalizer, "trackers": gen_trackers, "action-head": gen_action_head, "recorded-files": gen_recorded_files,
-           "motion-opt": gen_motion_opt, "mgdm": gen_mgdm, "motion-edit": gen_motion_edit}
+           "motion-opt": gen_motion_opt, "mgdm": gen_mgdm, "motion-edit": gen_motion_edit, "sim-config": gen_sim_config}
     picked = [s_ for s_ in STAGES if "--only-" + s_ in sys.argv]
     if "--check" in sys.argv:
         # regenerate everything into a scratch directory and compare with the committed fixtures array by array
