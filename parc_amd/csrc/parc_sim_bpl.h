@@ -179,7 +179,7 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
     unsigned long long overflow = 0ull;
     // ---- link-link contacts: every lane publishes its body's capsule and motion in the env frame (21 floats in the LDS exchange
     // buffer, free until the inward sweep), then tests it against the bodies of its self-collision set: the same pair is evaluated
-    // by both lanes from the same closest points and gains, so the explicit forces are equal and opposite (link_contact)
+    // by both lanes in canonical order (lower body index first), so the explicit forces are equal and opposite (link_contact)
     V3 flink = v3(0.f, 0.f, 0.f);
     {
         const CapsuleW mine = capsule_world(m, valid ? b : 0, k.R, k.P, k.v);
@@ -190,7 +190,8 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
         o[17] = mine.c.x; o[18] = mine.c.y; o[19] = mine.c.z; o[20] = mine.ext;
         __syncthreads();
         for (unsigned mm = (valid && mine.r > 0.f) ? m.self_mask[b] : 0u; mm; mm &= mm - 1) {
-            const float *q = lds + (__ffs((int)mm) - 1) * BPL_CONTRIB;
+            const int ob = __ffs((int)mm) - 1;
+            const float *q = lds + ob * BPL_CONTRIB;
             CapsuleW other;
             other.c = v3(q[17], q[18], q[19]); other.ext = q[20];
             {
@@ -201,8 +202,8 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
             other.a = v3(q[0], q[1], q[2]); other.b = v3(q[3], q[4], q[5]); other.r = q[6];
             other.o = v3(q[7], q[8], q[9]); other.v = v3(q[10], q[11], q[12]); other.w = v3(q[13], q[14], q[15]);
             LinkHit hit;
-            if (!link_contact(m, mine, k.R, L.mass, other, q[16], h, hit)) continue;
-            pA.a = pA.a - cross(hit.rc, hit.F);
+            if (!link_contact(m, mine, k.R, L.mass, other, q[16], h, b < ob, hit)) continue;
+            pA.a = pA.a - hit.tau;
             pA.l = pA.l - hit.F;
             flink = flink + hit.F;
         }

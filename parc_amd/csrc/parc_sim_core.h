@@ -326,11 +326,11 @@ PARC_HD float clampf01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
 
 // ---- link-link contact (self-collision) -----------------------------------------------------------------------------------
 // Every body carries one capsule (model.cap_*).  Two capsules of bodies not joined by a joint that overlap push each other apart
-// along the line between their closest points with a spring-damper force (no friction between links).  Unlike a terrain contact
+// along the line between their closest points with a spring-damper force, plus regularised Coulomb friction.  Unlike a terrain contact
 // the force is EXPLICIT and applied to the two bodies with opposite signs: an implicit one-sided impedance (what the terrain
 // contact uses, the ground being immovable) would act on each link like added mass anchored in the world and let a character
-// change its total momentum by rubbing its limbs together.  Both bodies evaluate the pair themselves from the same closest points
-// and the same gains, so the two forces are equal and opposite and momentum is conserved exactly.  The gains are limited by the
+// change its total momentum by rubbing its limbs together.  Both bodies evaluate the pair themselves, in canonical order (lower body
+// index first), from the same closest points and gains, so the two forces are equal and opposite.  The gains are limited by the
 // pair's reduced mass so that the explicit spring-damper stays inside the stability range of the semi-implicit Euler step:
 // k <= mu / h^2, c <= 0.5 mu / h (mu from the two LINK masses, a lower bound of the effective masses of the articulated bodies).
 struct CapsuleW {   // a body's capsule and motion in the world (env) frame
@@ -375,35 +375,45 @@ PARC_HD void seg_seg_closest(V3 p1, V3 q1, V3 p2, V3 q2, V3 &c1, V3 &c2) {
 }
 
 struct LinkHit {
-    V3 rc, F;          // contact point and force on this body, in the body's coordinates
+    V3 tau, F;         // torque about this body's origin and force on this body, in the body's coordinates
 };
 
-// Contact of body A's capsule with body B's, as felt by A (R = A's rotation, mass_a / mass_b the two link masses).  Returns false
-// when they do not touch or separate faster than the spring pushes.
+// Contact of body A's capsule with body B's, as felt by A (R = A's rotation, mass_a / mass_b the two link masses, a_first = A has the
+// lower body index).  Returns false when they do not touch or separate faster than the spring pushes.
+// The pair is evaluated in CANONICAL order - the lower body index is always segment 1 of the closest-point computation and every
+// quantity below is formed from (P = lower, Q = higher) - so the two lanes (or loop iterations) that own the two bodies run the same
+// arithmetic on the same operands and differ only in the final sign: seg_seg_closest is not symmetric under swapping its arguments
+// (near-parallel segments clamp s = 0 on segment 1), and without the ordering parallel thigh / shin capsules got two different
+// closest-point pairs, i.e. forces that were not equal and opposite.
+// Friction between links (Isaac Gym: collision filter 0 = link-link contacts with the material's friction, envs/ig_char_env.py:105-113):
+// regularised Coulomb, |Ft| = min(ct |vt|, mu fn) against the tangential relative velocity, applied to both bodies at the COMMON point
+// midway between the two surface points (equal and opposite forces on one line of action: no net force, no net torque); the normal
+// forces act at the two surface points, which lie on one line along n.
 PARC_HD bool link_contact(const parc_sim_model_t &m, const CapsuleW &A, const M3 &R, float mass_a, const CapsuleW &B, float mass_b, float h,
-                          LinkHit &hit) {
+                          bool a_first, LinkHit &hit) {
     {
         const V3 cc = A.c - B.c;
         const float far = A.ext + B.ext;
         if (dot(cc, cc) >= far * far) return false;        // bounding spheres apart (most pairs, most of the time)
     }
-    V3 ca, cb;
-    seg_seg_closest(A.a, A.b, B.a, B.b, ca, cb);
-    V3 d = ca - cb;
-    const float dist2 = dot(d, d), reach = A.r + B.r;
+    const CapsuleW &P = a_first ? A : B, &Q = a_first ? B : A;
+    V3 cp, cq;
+    seg_seg_closest(P.a, P.b, Q.a, Q.b, cp, cq);
+    V3 d = cp - cq;
+    const float dist2 = dot(d, d), reach = P.r + Q.r;
     if (dist2 >= reach * reach) return false;
     const float dist = p_sqrt(dist2);
-    // coincident axes: push along the line between the body origins (a direction both bodies agree on, mirrored)
-    V3 n = dist > 1e-6f ? p_rcp(dist) * d : v3(0.f, 0.f, 0.f);
+    // coincident axes: push along the line between the body origins
+    V3 n = dist > 1e-6f ? p_rcp(dist) * d : v3(0.f, 0.f, 0.f);          // from Q towards P
     if (!(dist > 1e-6f)) {
-        V3 oo = A.o - B.o;
+        V3 oo = P.o - Q.o;
         float l = p_sqrt(dot(oo, oo));
         n = l > 1e-6f ? p_rcp(l) * oo : v3(0.f, 0.f, 1.f);
     }
     const float pen = reach - dist;
-    const V3 pa = ca - A.r * n, pb = cb + B.r * n;            // surface points
-    const V3 va = A.v + cross(A.w, pa - A.o), vb = B.v + cross(B.w, pb - B.o);
-    const float vn = dot(va - vb, n);
+    const V3 pp = cp - P.r * n, pq = cq + Q.r * n;            // surface points
+    const V3 vp = P.v + cross(P.w, pp - P.o), vq = Q.v + cross(Q.w, pq - Q.o);
+    const float vn = dot(vp - vq, n);
     const float mu = mass_a * mass_b * p_rcp(mass_a + mass_b);
     const float ih = p_rcp(h);
     const float kcap = mu * ih * ih, ccap = 0.5f * mu * ih;
@@ -412,8 +422,26 @@ PARC_HD bool link_contact(const parc_sim_model_t &m, const CapsuleW &A, const M3
     const float d_eff = pen < m.contact_max_pen ? pen : m.contact_max_pen;
     const float fn = kn * d_eff - cn * vn;
     if (fn <= 0.f) return false;
-    hit.rc = mulT(R, pa - A.o);
-    hit.F = fn * mulT(R, n);
+    // friction on P at the common point (explicit damper, gain inside the step's stability range like the normal one, capped by mu fn)
+    const V3 pm = 0.5f * (pp + pq);
+    const V3 vr = (P.v + cross(P.w, pm - P.o)) - (Q.v + cross(Q.w, pm - Q.o));
+    const V3 vt = vr - dot(vr, n) * n;
+    const float vt2 = dot(vt, vt);
+    V3 Ft = v3(0.f, 0.f, 0.f);
+    if (vt2 > 1e-12f) {
+        const float vtl = p_sqrt(vt2);
+        const float ctc = 0.5f * ccap;
+        const float ct = m.contact_ct < ctc ? m.contact_ct : ctc;
+        const float lim = m.friction_mu * fn;
+        const float ft = ct * vtl < lim ? ct * vtl : lim;
+        Ft = (-ft * p_rcp(vtl)) * vt;
+    }
+    const float sg = a_first ? 1.f : -1.f;
+    const V3 Fn = (sg * fn) * n;
+    Ft = sg * Ft;
+    const V3 pa = a_first ? pp : pq;
+    hit.tau = mulT(R, cross(pa - A.o, Fn) + cross(pm - A.o, Ft));
+    hit.F = mulT(R, Fn + Ft);
     return true;
 }
 
@@ -492,8 +520,8 @@ PARC_HD void pass1(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_
         for (int j = 0; j < B; ++j) {
             if (!((m.self_mask[i] >> j) & 1u) || !(m.cap_radius[j] > 0.f)) continue;
             LinkHit hit;
-            if (!link_contact(m, ci, s.R[i], m.mass[i], capsule_world(m, j, s.R[j], s.P[j], s.v[j]), m.mass[j], h, hit)) continue;
-            s.pA[i].a = s.pA[i].a - cross(hit.rc, hit.F);
+            if (!link_contact(m, ci, s.R[i], m.mass[i], capsule_world(m, j, s.R[j], s.P[j], s.v[j]), m.mass[j], h, i < j, hit)) continue;
+            s.pA[i].a = s.pA[i].a - hit.tau;
             s.pA[i].l = s.pA[i].l - hit.F;
             s.flink[i] = s.flink[i] + hit.F;
         }

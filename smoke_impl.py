@@ -8,7 +8,7 @@ ULP1 = 2.0 ** -24                     # spacing of fp32 just below 1.0
 SLERP_ULP_SLACK = 2                   # how far a 1-ulp difference in one stored quaternion component can move the slerp cosine
 TIGHT = 5e-5                          # absolute tolerance on positions [m] / rotation entries / observation entries that do not
                                       # depend on a quaternion at one of slerp's two discontinuities
-BRANCH = 5e-4                         # bound on the effect of a flipped slerp branch: |0.5 - t| * |q1 - q0| <= 0.5 * 1e-3 per component
+FRAME_ATOL = 5e-7                     # stored frame quaternions, device build vs the oracle's (library sin / cos of two maths libraries)
 
 
 def oracle_models(env, clips):
@@ -19,6 +19,7 @@ def oracle_models(env, clips):
                     [full(j.axis) if j.axis is not None else np.zeros(3, np.float32) for j in km._joints], [j.dof_idx for j in km._joints])
     mlib = orc.MotionLib(char, [cl["frames"] for cl in clips], [cl["fps"] for cl in clips], [cl["loop"] for cl in clips],
                          [cl["weight"] for cl in clips], [cl["contacts"] for cl in clips])
+    mlib.fps_max = float(max(cl["fps"] for cl in clips))
     return char, mlib
 
 
@@ -52,13 +53,53 @@ def _dependency_tables(par, key_body_ids, J):
     return chain, dep
 
 
-def oracle_compare(env, clips, tiled, obs, r, ids=None, report=False):
+def adopt_device_frames(mlib, dev_mlib, stats):
+    """The oracle samples the clip rows the DEVICE stored (parc_motion_lib_build), after checking them against its own derivation.
+    Why: the two sides build the stored quaternions with two maths libraries (1-ulp differences in sinf / cosf), and slerp
+    (util/torch_util.py:443-468) is DISCONTINUOUS in the cosine between two frames - `cos >= 1 -> q0`, `sin < 0.001 -> average` - so for
+    nearly identical consecutive frames one ulp in a stored component selects another branch and moves the blend by up to
+    0.5 |q1 - q0| ~ 5e-4.  dof -> quaternion is continuous, so the stored frames themselves compare at FRAME_ATOL; given the same
+    stored frames both sides evaluate the cosine op by op in the same order and must then agree at TIGHT with no exception."""
+    rows = dev_mlib._rows.detach().cpu().numpy()
+    L = dev_mlib._layout
+    B, D = mlib.B, mlib.D
+    assert rows.shape[0] == mlib.root_rot.shape[0]
+    parts = {"root_rot": (rows[:, 0:4], FRAME_ATOL), "joint_rot": (rows[:, 4:4 * B].reshape(-1, B - 1, 4), FRAME_ATOL),
+             "root_pos": (rows[:, L["off_pos"]:L["off_pos"] + 3], 0.0), "contacts": (rows[:, L["off_contacts"]:L["off_contacts"] + B], 0.0),
+             "root_vel": (rows[:, L["off_root_vel"]:L["off_root_vel"] + 3], 2e-4), "root_ang_vel": (rows[:, L["off_root_ang_vel"]:L["off_root_ang_vel"] + 3], 2e-4),
+             "dof_vel": (rows[:, L["off_dof_vel"]:L["off_dof_vel"] + D], 2e-4)}
+    st = {}
+    # finite-difference velocities have a discontinuity of their own: quat_to_axis_angle (util/torch_util.py:68-88) returns angle 0 when
+    # the vector part of the frame-to-frame rotation is shorter than 1e-5, else 2 atan2(len, w) >= 2e-5, and compute_dof_vel
+    # (anim/kin_char_model.py:552-581) divides by dt: a joint that barely moves between two frames stores either 0 or ~2e-5 * fps.
+    vel_jump = 2.1e-5 * mlib.fps_max
+    for name, (dev, atol) in parts.items():
+        own = getattr(mlib, name)
+        e = np.abs(dev.astype(np.float64) - own.astype(np.float64))
+        is_vel = atol >= 1e-4
+        rtol = 2e-5 if is_vel else 0.0                    # fps x (1-ulp differences of two nearby poses), relative for fast joints
+        ok = e <= atol + rtol * np.abs(own)
+        at_threshold = np.zeros_like(ok)
+        if is_vel:
+            at_threshold = ~ok & ((dev == 0) | (own == 0)) & (e <= vel_jump)
+        w = np.unravel_index(int(np.argmax(np.where(at_threshold, 0.0, e - rtol * np.abs(own)))), e.shape)
+        st[name] = {"max_abs_diff": float(e.max()), "components_not_bit_equal": int((dev != own).sum()), "components": int(own.size),
+                    "at_the_1e-5_axis_angle_threshold": int(at_threshold.sum()), "worst_elsewhere": {"device": float(dev[w]), "oracle": float(own[w])}}
+        assert (ok | at_threshold).all(), "stored {}: device build {:g} vs the oracle's {:g} at {} (atol {:g}, rtol {:g})".format(
+            name, float(dev[w]), float(own[w]), w, atol, rtol)
+        setattr(mlib, name, np.ascontiguousarray(dev, dtype=np.float32))
+    stats["stored_frames_device_vs_oracle"] = st
+
+
+def oracle_compare(env, clips, tiled, obs, r, ids=None, report=False, oracle_frames="device"):
     """Reference pose, observation rows, reward and termination flags of the envs `ids` (all if None) recomputed by the CPU oracle from
-    the state the GPU holds, and compared at TIGHT.  The one excused difference is explained, not blanketed: an element may deviate
-    (by at most BRANCH) only if a quaternion it depends on sits at one of slerp's two discontinuities for the frame pair its query
-    blends (slerp_branch_marginal).  Used by smoke(), by the workload tests (a slice of a 4096-env launch) and, with report=True, by
-    tools/slerp_outliers.py (every env; returns the statistics instead of asserting)."""
+    the state the GPU holds, and compared at TIGHT - no blanket tolerance.  oracle_frames="device" (the tests, smoke): the oracle samples
+    the clip rows the device stored, which are first checked against its own (adopt_device_frames); nothing is excused.
+    oracle_frames="own" (tools/slerp_outliers.py, report=True): the oracle samples its own stored frames; elements beyond TIGHT are
+    counted and each must depend on a quaternion that sits at one of slerp's two discontinuities (slerp_branch_marginal) - the
+    explanation of round 2's red full-size run, kept as a measurement.  report=True returns the statistics instead of asserting."""
     from oracle import oracle as orc
+    assert oracle_frames in ("device", "own")
     c = env._core
     N_all = env.get_num_envs()
     ids = np.arange(N_all) if ids is None else np.asarray(ids)
@@ -75,33 +116,34 @@ def oracle_compare(env, clips, tiled, obs, r, ids=None, report=False):
     tar_dt = np.array(list(s.tar_dt)[:S], np.float32)
     key_ids = list(env._cfg.key_body_ids)
     chain, tar_dep = _dependency_tables(char.parent, key_ids, J)
+    stats = {"envs_compared": int(n), "oracle_frames": oracle_frames, "unexplained": []}
     # which quaternions sit at a slerp discontinuity: query 0 = the reference pose, queries 1..S = the target poses
     marg = np.zeros((n, 1 + S, B), bool)
-    kk = np.zeros((n, 1 + S, B))
-    for q in range(1 + S):
-        cos, _ = mlib.slerp_cosines(mids, times if q == 0 else (times + tar_dt[q - 1]).astype(np.float32))
-        marg[:, q], kk[:, q] = slerp_branch_marginal(cos)
-    stats = {"envs_compared": int(n), "quats_checked": int(marg.size), "quats_at_a_slerp_discontinuity": int(marg.sum()),
-             "of_them_at_cos_ge_1": int((kk[marg] <= 1 + SLERP_ULP_SLACK).sum()),
-             "of_them_at_sin_lt_1e-3": int((kk[marg] >= 8 - SLERP_ULP_SLACK).sum()), "unexplained": []}
+    if oracle_frames == "device":
+        adopt_device_frames(mlib, c.mlib, stats)
+    else:
+        kk = np.zeros((n, 1 + S, B))
+        for q in range(1 + S):
+            cos, _ = mlib.slerp_cosines(mids, times if q == 0 else (times + tar_dt[q - 1]).astype(np.float32))
+            marg[:, q], kk[:, q] = slerp_branch_marginal(cos)
+        stats.update({"quats_checked": int(marg.size), "quats_at_a_slerp_discontinuity": int(marg.sum()),
+                      "of_them_at_cos_ge_1": int((kk[marg] <= 1 + SLERP_ULP_SLACK).sum()),
+                      "of_them_at_sin_lt_1e-3": int((kk[marg] >= 8 - SLERP_ULP_SLACK).sum())})
 
-    def check(name, got, want, excused, tight, loose=BRANCH, rtol=0.0):
-        """elementwise: |got - want| <= tight (+ rtol |want|) everywhere, except where `excused`, where `loose` applies"""
+    def check(name, got, want, excused, tight, rtol=0.0):
+        """elementwise |got - want| <= tight (+ rtol |want|); an element beyond it must be `excused` (never the case on device frames)"""
         err = np.abs(got.astype(np.float64) - want.astype(np.float64))
-        tol = tight + rtol * np.abs(want)
-        out = err > tol
-        bad = out & ~np.broadcast_to(excused, out.shape)
-        too_far = out & (err > loose + rtol * np.abs(want))
+        out = err > tight + rtol * np.abs(want)
+        exc = np.broadcast_to(excused, out.shape)
+        bad = out & ~exc
         stats[name] = {"elements": int(out.size), "beyond_tight": int(out.sum()), "beyond_tight_not_at_a_discontinuity": int(bad.sum()),
-                       "beyond_branch_bound": int(too_far.sum()), "max_err": float(err.max()) if err.size else 0.0,
-                       "max_err_where_not_excused": float(err[~np.broadcast_to(excused, out.shape)].max()) if (~excused).any() else 0.0}
-        if bad.any() or too_far.any():
-            where = np.argwhere(bad | too_far)[:20]
+                       "max_err": float(err.max()) if err.size else 0.0, "max_err_where_not_excused": float(err[~exc].max()) if (~exc).any() else 0.0}
+        if bad.any():
+            where = np.argwhere(bad)[:20]
             stats["unexplained"].append({"what": name, "at": where.tolist(), "err": [float(err[tuple(w)]) for w in where]})
         if not report:
-            assert not bad.any(), "{}: {} of {} elements beyond {:g} without a slerp discontinuity on their chain (max {:g}), first at {}".format(
+            assert not bad.any(), "{}: {} of {} elements beyond {:g} (max {:g}), first at {}".format(
                 name, int(bad.sum()), out.size, tight, float(err[bad].max()), np.argwhere(bad)[:5].tolist())
-            assert not too_far.any(), "{}: {} elements beyond the branch bound {:g} (max {:g})".format(name, int(too_far.sum()), loose, float(err[too_far].max()))
 
     ref = orc.update_ref_motion(char, mlib, mids, times, off)
     none = np.zeros((n, 1), bool)
@@ -124,9 +166,13 @@ def oracle_compare(env, clips, tiled, obs, r, ids=None, report=False):
     Wc = 12 + 6 * J + 28 + 3 * len(key_ids)
     Wt = tar_dep.shape[0]
     assert Wc + S * Wt + S * B + B + hfs.shape[1] == g_obs.shape[1]
-    check("obs_char", g_obs[:, :Wc], o_obs[:, :Wc], none, TIGHT, rtol=1e-5)
+    # observation entries are differences of world coordinates expressed in the heading frame: their resolution is that of the
+    # coordinates themselves (tiles of a 1024-clip grid sit up to ~300 m from the origin, where one fp32 ulp is 3e-5 m)
+    far = np.maximum(np.abs(rs[:, 0:3]).max(-1), np.abs(ref["ref_root_pos"]).max(-1))
+    coord_ulp = (2.0 ** (np.floor(np.log2(np.maximum(far, 1.0))) - 23))[:, None]
+    check("obs_char", g_obs[:, :Wc], o_obs[:, :Wc], none, TIGHT + 2 * coord_ulp)
     tar_exc = (marg[:, 1:, None, :] & tar_dep[None, None]).any(-1).reshape(n, S * Wt)
-    check("obs_tar", g_obs[:, Wc:Wc + S * Wt], o_obs[:, Wc:Wc + S * Wt], tar_exc, TIGHT, rtol=1e-5)
+    check("obs_tar", g_obs[:, Wc:Wc + S * Wt], o_obs[:, Wc:Wc + S * Wt], tar_exc, TIGHT + 2 * coord_ulp)
     check("obs_contacts", g_obs[:, Wc + S * Wt:871], o_obs[:, Wc + S * Wt:871], none, 2e-5)
     flips = float(np.mean(g_obs[:, 871:] != o_obs[:, 871:]))
     stats["obs_hf_fraction_of_nearest_cell_flips"] = flips
@@ -137,8 +183,7 @@ def oracle_compare(env, clips, tiled, obs, r, ids=None, report=False):
               char_rigid_body_pos=z(c.rigid_body_state.view(N_all, 15, 13))[..., 0:3], contact_forces=cf)
     o_r, _ = orc.compute_reward(char, key_ids, st, ref, list(s.joint_err_w)[:14], list(s.dof_err_w)[:28], list(s.contact_w)[:15],
                                 list(s.reward_w))
-    # reward = weighted exp(-scale * err) terms: one flipped branch (5e-4 in a quaternion, a limb end) moves it by < 1e-3
-    check("reward", z(r), o_r, marg[:, 0].any(-1), 1e-4, loose=1e-3)
+    check("reward", z(r), o_r, marg[:, 0].any(-1), 1e-4)
     # ---- termination flags (compute_done mgdm_dm_util.py:392-460 + the motion-end override dm_env.py:746-783), from the DEVICE's
     # reference pose so that only the rule arithmetic is compared; a flag may differ from the oracle's only where the decision is
     # marginal, i.e. where the oracle itself answers differently with every threshold moved by 1e-4 of its value either way

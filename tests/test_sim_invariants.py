@@ -482,6 +482,73 @@ def test_momentum_is_conserved_through_link_contacts(model):
     assert np.abs(L1 - L0).max() < 0.05 * max(np.linalg.norm(L0), 1.0)
 
 
+def test_link_contact_forces_are_equal_and_opposite_for_parallel_capsules(model):
+    """The degenerate case of the closest-point computation: EXACTLY parallel, overlapping capsules (thighs and shins in the rest pose,
+    radii enlarged until they overlap).  seg_seg_closest clamps s = 0 on its FIRST segment there, so the two bodies of a pair must
+    evaluate it in the same (canonical) order: the reported contact forces of the two bodies then cancel to rounding, in every substep,
+    and momentum is conserved like without contact.  (With each body passing its own capsule first the two lanes picked different
+    closest-point pairs - round-2 advisor finding.)"""
+    km, sm = model
+    sim = make(model, gravity=0.0, angular_damping=0.0)
+    for b in (9, 10, 12, 13):                  # right / left thigh and shin: axes parallel, 0.17 m apart
+        sim.m.cap_radius[b] = 0.095
+    rng = np.random.default_rng(5)
+    sim.root_state[0, 0:3] = [0.0, 0.0, 3.0]
+    sim.root_state[0, 7:13] = rng.standard_normal(6) * 0.2
+    sim.refresh_bodies()
+    P0, L0, _ = momentum(model, sim)
+    act = np.zeros((1, 28), np.float32)
+    worst, peak = 0.0, 0.0
+    for _ in range(40):
+        sim.step(act, n_sub=1, h=1.0 / 120.0)   # one substep per call: contact_forces is that substep's force, not a mean
+        f = sim.contact_forces[0].astype(np.float64)
+        peak = max(peak, float(np.abs(f).max()))
+        worst = max(worst, float(np.abs(f.sum(axis=0)).max()))
+        # pairwise: thigh against thigh, shin against shin (nothing else touches in this pose)
+        assert np.abs(f[9] + f[12]).max() <= 1e-4 * max(np.abs(f[9]).max(), 1.0)
+        assert np.abs(f[10] + f[13]).max() <= 1e-4 * max(np.abs(f[10]).max(), 1.0)
+    assert peak > 20.0                          # they do press on each other
+    assert worst <= 1e-4 * peak                 # internal forces sum to zero
+    P1, L1, _ = momentum(model, sim)
+    assert np.abs(P1 - P0).max() < 0.02 * max(np.linalg.norm(P0), 1.0)
+    assert np.abs(L1 - L0).max() < 0.05 * max(np.linalg.norm(L0), 1.0)
+
+
+def test_crossed_legs_do_not_slide_freely(model):
+    """Friction between links (Isaac Gym: collision filter 0, envs/ig_char_env.py:105-113 - link-link contacts carry the material's
+    friction): the thighs are pressed against each other by the hip drives, then driven along each other.  With mu = 1 the sliding
+    is held back while they touch - the hips travel clearly less in the first steps than with mu = 0 - momentum stays conserved (the
+    friction forces are an equal and opposite pair on one line of action), and with mu = 0 the contact is the frictionless one."""
+    km, sm = model
+
+    def run(mu):
+        sim = make(model, gravity=0.0, angular_damping=0.0, friction_mu=mu)
+        sim.root_state[0, 0:3] = [0.0, 0.0, 3.0]
+        sim.refresh_bodies()
+        P0, L0, _ = momentum(model, sim)
+        act = np.zeros((1, 28), np.float32)
+        act[0, 14], act[0, 21] = 0.3, -0.3                  # hips adducted: the legs press on each other
+        for _ in range(45):
+            sim.step(act, n_sub=4, h=1.0 / 120.0)
+        pressed = float(np.linalg.norm(sim.contact_forces[0], axis=-1).max())
+        act[0, 15], act[0, 22] = -0.3, 0.3                  # ... and are now driven along each other (hip flexion, opposite signs)
+        travel = []
+        for _ in range(4):
+            sim.step(act, n_sub=4, h=1.0 / 120.0)
+            travel.append(0.5 * (abs(float(sim.dof_state[0, 15, 0])) + abs(float(sim.dof_state[0, 22, 0]))))
+        P1, L1, _ = momentum(model, sim)
+        return pressed, travel, max(np.abs(P1 - P0).max(), np.abs(L1 - L0).max())
+    p0, t0, dm0 = run(0.0)
+    p1, t1, dm1 = run(1.0)
+    assert p0 > 50.0 and p1 > 50.0                          # pressed together before the slide starts
+    assert t1[1] < 0.7 * t0[1] and t1[3] < 0.8 * t0[3]      # held back (0.028 / 0.052 rad after two steps, 0.12 / 0.18 after four)
+    assert t1[3] > 0.02                                     # regularised Coulomb friction: it slides, it is not glued
+    print("momentum drift without / with friction:", dm0, dm1)
+    assert dm1 < 1.5 * dm0 + 0.05                           # internal forces either way: no drift beyond the integrator's own (mu = 0 run)
+    # (mu is the only difference between the two runs, and the frictionless one is what round 2 shipped)
+    assert np.abs(np.array(t0) - np.array(t1)).max() > 0.02
+
+
 def test_forward_dynamics_against_independent_inverse_dynamics(model):
     """The simulator's forward dynamics (Featherstone's articulated-body algorithm in reduced coordinates, fp32) checked against an
     INDEPENDENT formulation: recursive Newton-Euler inverse dynamics written here in numpy float64 from the textbook vector
