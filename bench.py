@@ -80,13 +80,16 @@ def cpu_baseline(env, clips, tiled, budget_s=12.0):
 
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a child torch.distributed.run job and
-    relay rank 0's JSON line.  The parent makes no GPU call (device_count() does not initialise the GPU on this image), and it
-    starts a child rather than replacing itself."""
+    relay rank 0's JSON line.  The parent makes no GPU call at all - the device count comes from the visibility variables or the KFD
+    topology in sysfs (mp_util.visible_device_count), never from the HIP runtime - and it starts a child rather than replacing
+    itself.  A count of 0 means "could not tell": the ranks then check for themselves (each refuses if the runtime shows fewer
+    devices than ranks)."""
     import socket
     import subprocess
     backend = os.environ.get("PARC_DIST_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()
-    if backend == "nccl" and not args.launch_check and n_dev < args.gpus:
+    from parc_amd.util import mp_util
+    n_dev = mp_util.visible_device_count()
+    if backend == "nccl" and not args.launch_check and 0 < n_dev < args.gpus:
         sys.stderr.write("bench.py: --gpus {} needs {} visible GPUs, found {} (refusing to report a {}-GPU number from fewer)\n".format(
             args.gpus, args.gpus, n_dev, args.gpus))
         return 2

@@ -27,11 +27,8 @@ def run(rank, num_procs, master_port, args):
     mode = args.parse_string("mode", "train")
     num_envs = args.parse_int("num_envs", 1)
     device = args.parse_string("device", "cuda:0")
-    if num_procs > 1 and device.startswith("cuda"):
-        device = "cuda:{}".format(int(os.environ.get("LOCAL_RANK", rank)))
-    if device.startswith("cuda"):
-        torch.cuda.set_device(device)
-    mp_util.init(rank, num_procs, device, master_port)
+    mp_util.init(rank, num_procs, device, master_port)       # maps a bare cuda / cuda:0 to this rank's GPU (mp_util.rank_device)
+    device = mp_util.get_device()
     seed = args.parse_int("rand_seed") if args.has_key("rand_seed") else int(time.time() * 256) % (2 ** 31)
     util.set_rand_seed(seed + 41 * mp_util.get_proc_rank())            # run.py:90
     out_model_file = args.parse_string("out_model_file", "output/model.pt")

@@ -125,11 +125,12 @@ class SubTerrain:
 
 # Motion files and the terrain.pkl cache embed SubTerrain instances, and the reference reads them with a plain
 # pickle.load (anim/motion_lib.py:240, envs/ig_parkour/dm_env.py:136,161,496), which resolves the class by the module path
-# stored in the file.  The class therefore names the reference's path, and that path resolves to this module.
+# stored in the file.  The class therefore names the reference's path.  Nothing is registered in sys.modules at import time (a process
+# that imports this package next to the reference, or next to another project's top-level `util`, must not have its imports
+# redirected): the path resolves to this module inside `reference_pickle_path()` / `dump_reference_pickle()` - the writers of this
+# package - or after `parc_amd.install_reference_aliases()`; a plain `pickle.dump` of a SubTerrain anywhere else raises PicklingError.
 REFERENCE_MODULE = "util.terrain_util"
 SubTerrain.__module__ = REFERENCE_MODULE
-sys.modules.setdefault("util", sys.modules[__name__.rpartition(".")[0]])
-sys.modules.setdefault(REFERENCE_MODULE, sys.modules[__name__])
 
 
 # other modules whose classes are written into motion files under a reference path: reference module name -> module

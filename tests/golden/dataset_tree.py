@@ -26,7 +26,14 @@ FILES = [
 BAD_LOSS_FILE = ("A/jumping/j2.pkl", 33, 30, (20, 20), {"loss": 25.0})
 
 
-def build(root, make_terrain, files=None):
+def _plain_dump(obj, path):
+    with open(path, "wb") as f:
+        pickle.dump(obj, f)
+
+
+def build(root, make_terrain, files=None, dump=_plain_dump):
+    """dump(obj, path): the writer - plain pickle.dump where the terrain class is importable under the path it names (the reference's
+    own class in gen_golden.py), parc_amd's terrain_util.dump_reference_pickle for this package's SubTerrain"""
     rng = np.random.default_rng(4)
     for rel, nf, fps, dims, extra in (FILES if files is None else files):
         p = os.path.join(root, rel)
@@ -34,6 +41,30 @@ def build(root, make_terrain, files=None):
         d = {"frames": rng.standard_normal((nf, 34)).astype(np.float32), "fps": fps, "loop_mode": "CLAMP",
              "terrain": make_terrain(np.zeros(dims, np.float32))}
         d.update(extra)
-        with open(p, "wb") as f:
-            pickle.dump(d, f)
+        dump(d, p)
+    return [os.path.join(root, "A"), os.path.join(root, "B")]
+
+
+# ---- a small dataset of REAL motion (pieces of the two clips the reference ships, read from the committed fixtures) for the stage-script
+# fixture G24: gen_golden.py builds it in the build container, the GPU test rebuilds the identical tree on the box
+CLIP_FILES = [
+    ("A/running/civ_a.pkl", 0, 0, 70),         # (relative path, which shipped clip, first frame, last frame)
+    ("A/running/civ_b.pkl", 0, 70, 150),
+    ("B/jumping/civ_c.pkl", 0, 150, 254),
+    ("B/jumping/teaser.pkl", 1, 0, 58),
+]
+
+
+def build_clip_tree(root, make_terrain, golden_dir=None, dump=_plain_dump):
+    """-> the folder list for create_dataset.  Every piece keeps its clip's own heightfield (positions stay consistent with it)."""
+    golden_dir = golden_dir or os.path.dirname(os.path.abspath(__file__))
+    z3 = np.load(os.path.join(golden_dir, "g3_motion.npz"))
+    z5 = [np.load(os.path.join(golden_dir, n + ".npz")) for n in ("g5_hf_civ", "g5_hf_teaser")]
+    for rel, which, f0, f1 in CLIP_FILES:
+        p = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        ter = make_terrain(z5[which]["hf"].astype(np.float32), z5[which]["min_point"].astype(np.float32), z5[which]["dxdy"].astype(np.float32))
+        d = {"frames": z3["frames_%d" % which][f0:f1].astype(np.float32), "contacts": z3["contacts_%d" % which][f0:f1].astype(np.float32),
+             "fps": 30, "loop_mode": "CLAMP", "terrain": ter}
+        dump(d, p)
     return [os.path.join(root, "A"), os.path.join(root, "B")]

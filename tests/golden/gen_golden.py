@@ -1031,7 +1031,7 @@ def gen_recorded_files():
 
 
 STAGES = ["core", "voxel-mesh", "dataset-yaml", "procgen", "terrain-geometry", "done-branches", "ppo-loss", "normalizer", "trackers",
-          "action-head", "recorded-files", "motion-opt", "mgdm", "motion-edit", "sim-config"]
+          "action-head", "recorded-files", "motion-opt", "mgdm", "motion-edit", "sim-config", "stage-scripts"]
 
 
 def _icosa_points(radius):
@@ -1493,6 +1493,83 @@ def gen_sim_config():
 
 
 
+def gen_stage_scripts():
+    """G24: the reference's stage scripts parc_3_tracker.train_tracker (parc_3_tracker.py:8-78) and parc_4_phys_record.record_motions
+    (parc_4_phys_record.py:8-65) run UNCHANGED on top of this package's module aliases (tests/golden/stage_scripts_child.py, a fresh
+    process per script like `python parc_3_tracker.py`), on a small config derived from PARC/tracker_default.yaml /
+    phys_record_default.yaml / create_dataset_config.yaml: same keys, the two default tracker YAMLs as env / agent config, a 4-file
+    dataset of real motion, 32 envs.  env_builder.build_env / agent_builder.build_agent are recorders.  Stored: the files the scripts
+    write (dm_env.yaml, agent_config.yaml, train_args.txt, record_env.yaml, record_args.txt, the dataset YAML of create_dataset), the
+    argv handed to run.main and every call the reference's run.run makes into the package, with the scratch directory spelled <TMP>.
+    Three runs: tracker with in_model_file + create_dataset_config, tracker without either, record."""
+    import json
+    import subprocess
+    import yaml
+    sys.path.insert(0, HERE)
+    import dataset_tree
+    from parc_amd.util import terrain_util as our_terrain_util
+    tmp = tempfile.mkdtemp(prefix="parc_golden_stage_")
+
+    def make_terrain(hf, min_point, dxdy):
+        return our_terrain_util.SubTerrain.from_arrays(hf, min_point, dxdy, device="cpu").numpy_copy()
+    # files in the reference's format (class path util.terrain_util.SubTerrain), written by the package's own writer
+    folders = dataset_tree.build_clip_tree(os.path.join(tmp, "tree"), make_terrain, dump=our_terrain_util.dump_reference_pickle)
+    ds_cfg = {"save_path": os.path.join(tmp, "dataset", "motions.yaml"), "folder_paths": folders, "char_filepath": "data/assets/humanoid.xml",
+              "compute_preprocessing_data": False, "cut_some_classes_in_half": True, "motion_classes_to_cut_in_half": ["running"],
+              "max_terrain_dim_x": 120, "max_terrain_dim_y": 120}
+    os.makedirs(os.path.join(tmp, "dataset"))
+    ds_cfg_path = os.path.join(tmp, "create_dataset_config.yaml")
+    with open(ds_cfg_path, "w") as f:
+        yaml.safe_dump(ds_cfg, f)
+    base = {"env_config": "PARC/tracker_config/dm_env_default.yaml", "agent_config": "PARC/tracker_config/dm_agent_default.yaml",
+            "num_envs": 32, "max_samples": 2048, "device": "cuda:0", "dataset_file": ds_cfg["save_path"]}
+    runs = {
+        "tracker_resume": ("tracker", dict(base, output_dir=os.path.join(tmp, "tracker_resume") + "/", in_model_file=os.path.join(tmp, "tracker_fresh", "model.pt"),
+                                           create_dataset_config=ds_cfg_path)),
+        "tracker_fresh": ("tracker", dict(base, output_dir=os.path.join(tmp, "tracker_fresh") + "/")),
+        "record": ("record", {"output_dir": os.path.join(tmp, "record") + "/", "device": "cuda:0", "create_dataset_config": ds_cfg_path,
+                              "model_file": os.path.join(tmp, "tracker_fresh", "model.pt"), "agent_file": os.path.join(tmp, "tracker_fresh", "agent_config.yaml"),
+                              "env_file": os.path.join(tmp, "tracker_fresh", "dm_env.yaml")}),
+    }
+    os.makedirs(os.path.join(tmp, "record"))          # parc_4_phys_record writes into output_dir without creating it
+    sub = lambda x: json.loads(json.dumps(x).replace(tmp, "<TMP>"))
+    out = {"create_dataset_config": sub(ds_cfg), "runs": {}}
+    for name in ("tracker_resume", "tracker_fresh", "record"):
+        which, cfg = runs[name]
+        cfg_path = os.path.join(tmp, name + "_config.yaml")
+        with open(cfg_path, "w") as f:
+            yaml.safe_dump(cfg, f)
+        env = dict(os.environ, PYTHONHASHSEED="0")
+        r = subprocess.run([sys.executable, os.path.join(HERE, "stage_scripts_child.py"), which, cfg_path, REF], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("G24JSON ")][-1]
+        res = json.loads(line[len("G24JSON "):])
+        assert res["modules_loaded_from_the_reference"] == ["parc_3_tracker" if which == "tracker" else "parc_4_phys_record", "run"], res["modules_loaded_from_the_reference"]
+        files = {}
+        od = cfg["output_dir"]
+        for fn in sorted(os.listdir(od)):
+            if os.path.isfile(os.path.join(od, fn)):
+                files[fn] = open(os.path.join(od, fn)).read().replace(tmp, "<TMP>")
+        out["runs"][name] = {"script": {"tracker": "parc_3_tracker.train_tracker", "record": "parc_4_phys_record.record_motions"}[which],
+                             "config": sub(cfg), "files_written_to_output_dir": files, "argv": sub(res["argv"]), "calls": sub(res["calls"])}
+    out["dataset_yaml"] = open(ds_cfg["save_path"]).read().replace(tmp, "<TMP>")
+    # random master port and time-derived seed differ per run: keep their kind, not their value
+    for rn in out["runs"].values():
+        for c in rn["calls"]:
+            if c["call"] == "mp_util.init":
+                assert 6000 <= c["args"][3] < 7000
+                c["args"][3] = "<port in [6000, 7000)>"
+            if c["call"] == "util.set_rand_seed":
+                assert c["args"][0]["numpy"] == "uint64"
+                c["args"][0] = {"numpy": "uint64", "int": "<time-derived>"}
+    path = os.path.join(OUT, "g24_stage_scripts.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print("wrote", path)
+
+
+
 def gen_core():
     rng = np.random.default_rng(0)
     torch.manual_seed(0)
@@ -1514,7 +1591,7 @@ def main():
     run = {"core": gen_core, "voxel-mesh": lambda: gen_voxel_mesh(np.random.default_rng(10)), "dataset-yaml": gen_dataset_yaml,
            "procgen": gen_procgen, "terrain-geometry": gen_terrain_geometry, "done-branches": gen_done_branches, "ppo-loss": gen_ppo_loss,
            "normalizer": gen_normalizer, "trackers": gen_trackers, "action-head": gen_action_head, "recorded-files": gen_recorded_files,
-           "motion-opt": gen_motion_opt, "mgdm": gen_mgdm, "motion-edit": gen_motion_edit, "sim-config": gen_sim_config}
+           "motion-opt": gen_motion_opt, "mgdm": gen_mgdm, "motion-edit": gen_motion_edit, "sim-config": gen_sim_config, "stage-scripts": gen_stage_scripts}
     picked = [s_ for s_ in STAGES if "--only-" + s_ in sys.argv]
     if "--check" in sys.argv:
         # regenerate everything into a scratch directory and compare with the committed fixtures array by array

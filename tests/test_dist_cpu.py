@@ -156,3 +156,70 @@ def test_bench_launcher_starts_the_ranks_itself():
     if not torch.cuda.is_available():
         bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env, timeout=300)
         assert bad.returncode != 0 and "needs 8 visible GPUs" in bad.stderr and bad.stdout.strip() == ""
+
+
+def test_rank_device_rule():
+    """mp_util.rank_device: the reference's launcher hands the SAME --device string to every rank (run.py:98,150-162); a bare
+    cuda / cuda:0 with more than one process therefore means "this rank's GPU"."""
+    from parc_amd.util import mp_util
+    rd = mp_util.rank_device
+    assert [rd(r, 8, "cuda:0", num_devices=8, local_rank=r) for r in range(8)] == ["cuda:%d" % r for r in range(8)]
+    assert rd(5, 8, "cuda", num_devices=8, local_rank=5) == "cuda:5"
+    assert rd(1, 2, "cuda:0", num_devices=1, local_rank=1) == "cuda:0"        # two ranks rehearsing on a one-GPU box share it
+    assert rd(3, 8, "cuda:6", num_devices=8, local_rank=3) == "cuda:6"        # an explicit device is taken as given
+    assert rd(0, 1, "cuda:0", num_devices=8, local_rank=0) == "cuda:0" and rd(1, 2, "cpu", num_devices=0, local_rank=1) == "cpu"
+    assert rd(9, 16, "cuda:0", num_devices=8, local_rank=1) == "cuda:1"       # LOCAL_RANK (torchrun), not the global rank
+    # the count that needs no HIP call: a visibility variable wins over sysfs
+    old = {k: os.environ.pop(k, None) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
+    try:
+        os.environ["ROCR_VISIBLE_DEVICES"] = "2,3,5"
+        assert mp_util.visible_device_count() == 3
+        os.environ["HIP_VISIBLE_DEVICES"] = "0"
+        assert mp_util.visible_device_count() == 1
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def _mapping_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["PARC_MP_BACKEND"] = "gloo"            # the mapping logic without GPUs: the group itself runs on gloo
+    os.environ["HIP_VISIBLE_DEVICES"] = "0,1"         # "two GPUs visible" (nothing touches them: torch.cuda.is_available() is False here)
+    os.environ.pop("LOCAL_RANK", None)
+    torch.set_num_threads(1)
+    from parc_amd.util import mp_util
+    # exactly the calls the reference's run.run makes (run.py:95-117, fixture G24): the same string on every rank
+    mp_util.init(rank, world, "cuda:0", port)
+    t = torch.tensor([rank + 1.0])                     # (host tensor: the gloo group is real, the devices are only names here)
+    torch.distributed.all_reduce(t)
+    got = {"device": mp_util.get_device(), "env": mp_util.resolve_device("cuda:0"), "explicit": mp_util.resolve_device("cuda:5"),
+           "sum": int(t.item())}
+    out.put((rank, got))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_one_rank_per_gpu_under_the_reference_launcher_gloo_world2():
+    """Two ranks started the way the reference's run.main starts them - both with --device cuda:0 - end up on cuda:0 and cuda:1, and
+    that is the device env_builder / agent_builder build on (they resolve the launcher's string through mp_util.resolve_device)."""
+    if torch.cuda.is_available():
+        pytest.skip("mapping logic test for the CPU container (a GPU box has the real thing in test_dropin_gpu)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mapping_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert res[r] == {"device": "cuda:%d" % r, "env": "cuda:%d" % r, "explicit": "cuda:5", "sum": 3}, res
+    import inspect
+    from parc_amd.envs import env_builder
+    from parc_amd.learning import agent_builder
+    assert "mp_util.resolve_device(device)" in inspect.getsource(env_builder.build_env)
+    assert "mp_util.resolve_device(device)" in inspect.getsource(agent_builder.build_agent)

@@ -134,3 +134,59 @@ def test_collectives_on_the_real_backend_with_one_rank():
         assert r["finite"] and r["synced"] and r["max_abs_diff"] == 0.0 and r["loss"] == r["loss_single"], (cadence, r)
     assert res["minibatch"]["overlap"] and res["minibatch"]["buckets"] >= 2
     assert res["helpers"] == {"broadcast": True, "sum": True, "min": 3.5, "mean": True}
+
+
+def test_g24_files_and_argv_of_the_reference_stage_scripts_run(tmp_path, monkeypatch):
+    """What the reference's own parc_3_tracker.train_tracker / parc_4_phys_record.record_motions wrote and passed to run.main when they
+    ran unchanged on this package's aliases (fixture G24, tests/golden/gen_golden.py stage stage-scripts) - dm_env.yaml, agent_config.yaml,
+    record_env.yaml and the three argv lists, byte for byte with the scratch directory substituted - fed to parc_amd.run.main on the
+    GPU: stage 3 from scratch (writes model.pt + checkpoints + the terrain cache), stage 3 resuming from that model with the normaliser
+    frozen, stage 4 in record mode with one env per dataset entry.  The dataset is the identical 4-file tree of real motion rebuilt from
+    the committed fixtures; `char_file: data/assets/humanoid.xml` is relative to the launch directory like in the reference, so the
+    character file is put there."""
+    import json
+    import sys
+    from parc_amd import run as parc_run
+    from parc_amd.assets import humanoid_spec
+    from parc_amd.util import terrain_util
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import dataset_tree
+    with open(os.path.join(here, "golden", "g24_stage_scripts.json")) as f:
+        g = json.load(f)
+    tmp = str(tmp_path)
+    sub = lambda s: s.replace("<TMP>", tmp)
+
+    def make_terrain(hf, min_point, dxdy):
+        return terrain_util.SubTerrain.from_arrays(hf, min_point, dxdy, device="cpu").numpy_copy()
+    dataset_tree.build_clip_tree(os.path.join(tmp, "tree"), make_terrain, dump=terrain_util.dump_reference_pickle)
+    os.makedirs(os.path.join(tmp, "dataset"))
+    with open(os.path.join(tmp, "dataset", "motions.yaml"), "w") as f:
+        f.write(sub(g["dataset_yaml"]))
+    os.makedirs(os.path.join(tmp, "data", "assets"))
+    humanoid_spec.write_mjcf(os.path.join(tmp, "data", "assets", "humanoid.xml"))
+    monkeypatch.chdir(tmp)
+    for name in ("tracker_fresh", "tracker_resume", "record"):
+        run = g["runs"][name]
+        out_dir = sub(run["config"]["output_dir"])
+        os.makedirs(out_dir, exist_ok=True)
+        for fn, text in run["files_written_to_output_dir"].items():
+            with open(os.path.join(out_dir, fn), "w") as f:
+                f.write(sub(text))
+        argv = [sub(a) for a in run["argv"][0]]
+        # the arguments file the scripts leave next to the YAML is the argv (train_args.txt / record_args.txt)
+        args_txt = sub(run["files_written_to_output_dir"]["record_args.txt" if name == "record" else "train_args.txt"]).split()
+        assert args_txt == argv[1:]
+        parc_run.main(argv)
+        torch.cuda.synchronize()
+        if name != "record":
+            sd = torch.load(os.path.join(out_dir, "model.pt"), weights_only=True)
+            assert "_model._actor_layers.0.weight" in sd and "_obs_norm._mean" in sd
+            assert os.path.exists(os.path.join(out_dir, "checkpoints", "model_0000000000.pt")) and os.path.getsize(os.path.join(out_dir, "log.txt")) > 0
+            assert os.path.exists(os.path.join(out_dir, "terrain.pkl"))
+            if name == "tracker_resume":
+                # normalizer_samples: 0 (parc_3_tracker.py:35-36): the loaded normaliser is kept as it is
+                fresh = torch.load(os.path.join(tmp, "tracker_fresh", "model.pt"), weights_only=True)
+                assert torch.equal(sd["_obs_norm._mean"], fresh["_obs_norm._mean"]) and torch.equal(sd["_obs_norm._count"], fresh["_obs_norm._count"])
+        else:
+            assert os.path.exists(os.path.join(out_dir, "terrain.pkl"))

@@ -369,8 +369,8 @@ def test_create_dataset_preprocessing_writes_mask_inds(tmp_path):
     cls_dir.mkdir(parents=True)
     ter = terrain_util.SubTerrain.from_arrays(g["civ_hf"], g["civ_min_point"], g["civ_dxdy"])
     for k in range(2):
-        with open(cls_dir / "clip_{}.pkl".format(k), "wb") as f:
-            pickle.dump({"fps": 30, "loop_mode": "CLAMP", "frames": g["extra_frames"][10 * k:10 * k + 30], "terrain": ter.numpy_copy()}, f)
+        terrain_util.dump_reference_pickle({"fps": 30, "loop_mode": "CLAMP", "frames": g["extra_frames"][10 * k:10 * k + 30], "terrain": ter.numpy_copy()},
+                                           str(cls_dir / "clip_{}.pkl".format(k)))
     out = tmp_path / "dataset.yaml"
     create_dataset.create_dataset_yaml([tmp_path / "data"], out, compute_preprocessing_data=True, max_terrain_dim_x=64, max_terrain_dim_y=64)
     d = safe_pickle.load_motion_file_safe(str(cls_dir / "clip_0.pkl"))
