@@ -111,7 +111,9 @@ class ExperienceBuffer:
             idx = self._sample_buf[self._sample_buf_head:self._sample_buf_head + n]
             self._sample_buf_head += n
         else:
-            head = self._sample_buf[self._sample_buf_head:].clone()
+            # NOT cloned, like the reference (experience_buffer.py:102-110): the tail is a view, the new permutation is written
+            # in place, so a wrapping call returns [new[head:], new[:rem]] - indices of ONE permutation, no duplicates (fixture G25)
+            head = self._sample_buf[self._sample_buf_head:]
             rem = n - (L - self._sample_buf_head)
             self._reset_sample_buf()
             idx = torch.cat([head, self._sample_buf[:rem]], dim=0)

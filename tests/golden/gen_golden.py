@@ -1031,7 +1031,7 @@ def gen_recorded_files():
 
 
 STAGES = ["core", "voxel-mesh", "dataset-yaml", "procgen", "terrain-geometry", "done-branches", "ppo-loss", "normalizer", "trackers",
-          "action-head", "recorded-files", "motion-opt", "mgdm", "motion-edit", "sim-config", "stage-scripts"]
+          "action-head", "recorded-files", "motion-opt", "mgdm", "motion-edit", "sim-config", "stage-scripts", "experience-buffer"]
 
 
 def _icosa_points(radius):
@@ -1570,6 +1570,73 @@ def gen_stage_scripts():
 
 
 
+def gen_experience_buffer():
+    """G25: the experience buffer as the reference's agent builds and samples it.  (1) DMPPOAgent._build_exp_buffer -> PPOAgent ->
+    BaseAgent (learning/dm_ppo_agent.py:281-313, ppo_agent.py:62-80, base_agent.py:224-253) run on an agent object that skipped
+    __init__ (env = obs / action spaces of the tracker, `ig_parkour` => the two replan buffers): names in insertion order, dtypes,
+    shapes.  (2) ExperienceBuffer (learning/experience_buffer.py:3-115): record / inc / sample over a partly filled and a full
+    buffer, with minibatch sizes that do NOT divide the buffer so that _sample_rand_idx wraps in mid-call; every torch.randperm the
+    class draws is recorded, and so is the index list of every sample() call."""
+    import json
+    import learning.dm_ppo_agent as dm_ppo_agent
+    import learning.experience_buffer as experience_buffer
+    T_, N_ = 5, 3
+    ag = object.__new__(dm_ppo_agent.DMPPOAgent)
+    torch.nn.Module.__init__(ag)
+    ag._device = "cpu"
+    ag._steps_per_iter = T_
+    ag._is_terrain_runner = True
+    env = _Stub()
+    env.get_obs_space = lambda: _Box(-np.ones(1312, np.float32), np.ones(1312, np.float32))
+    env.get_action_space = lambda: _Box(-np.ones(28, np.float32), np.ones(28, np.float32))
+    env.get_num_envs = lambda: N_
+    ag._env = env
+    dm_ppo_agent.DMPPOAgent._build_exp_buffer(ag, {})
+    table = [[k, str(v.dtype).replace("torch.", ""), list(v.shape)] for k, v in ag._exp_buffer._buffers.items()]
+    flat = [[k, list(v.shape)] for k, v in ag._exp_buffer._flat_buffers.items()]
+    # ---- sampler walk
+    perms = []
+    real = torch.randperm
+
+    def randperm(*a, **k):
+        p_ = real(*a, **k)
+        perms.append(p_.tolist())
+        return p_
+    experience_buffer.torch.randperm = randperm
+    try:
+        torch.manual_seed(25)
+        buf = experience_buffer.ExperienceBuffer(buffer_length=T_, batch_size=N_, device="cpu")
+        buf.add_buffer("x", torch.zeros([T_, N_, 2]))
+        walk = []
+        for t_ in range(2):                                     # two of five rows written: 6 of 15 samples valid
+            buf.record("x", torch.full([N_, 2], float(t_ + 1)))
+            buf.inc()
+        for n_ in (4, 4):
+            idx = buf._sample_rand_idx(n_)
+            walk.append({"phase": "partly filled", "n": n_, "sample_count": buf.get_sample_count(), "idx": idx.tolist(), "head_after": buf._sample_buf_head})
+        for t_ in range(2, 7):                                  # fill it and go round once more (head wraps: 7 % 5 = 2)
+            buf.record("x", torch.full([N_, 2], float(t_ + 1)))
+            buf.inc()
+        head_row, total = buf._buffer_head, buf.get_total_samples()
+        buf.reset()                                             # _init_iter of every training iteration (ppo_agent.py:82-85)
+        for n_ in (4, 4, 4, 4, 4, 7, 15, 3):                    # 4th call wraps in mid-call (12 + 4 > 15); 15 = the whole buffer at once
+            idx = buf._sample_rand_idx(n_)
+            walk.append({"phase": "full", "n": n_, "sample_count": buf.get_sample_count(), "idx": idx.tolist(), "head_after": buf._sample_buf_head})
+        out_s = buf.sample(4)
+        sample_keys = list(out_s.keys())
+        x_rows = buf.get_data("x")[:, 0, 0].tolist()
+    finally:
+        experience_buffer.torch.randperm = real
+    out = {"T": T_, "N": N_, "buffers": table, "flat_views": flat, "randperm_draws": perms, "index_walk": walk,
+           "buffer_head_after_7_incs": head_row, "total_samples_after_7_incs": total, "rows_after_7_records": x_rows, "sample_keys": sample_keys}
+    path = os.path.join(OUT, "g25_experience_buffer.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print("wrote", path)
+
+
+
 def gen_core():
     rng = np.random.default_rng(0)
     torch.manual_seed(0)
@@ -1591,7 +1658,7 @@ def main():
     run = {"core": gen_core, "voxel-mesh": lambda: gen_voxel_mesh(np.random.default_rng(10)), "dataset-yaml": gen_dataset_yaml,
            "procgen": gen_procgen, "terrain-geometry": gen_terrain_geometry, "done-branches": gen_done_branches, "ppo-loss": gen_ppo_loss,
            "normalizer": gen_normalizer, "trackers": gen_trackers, "action-head": gen_action_head, "recorded-files": gen_recorded_files,
-           "motion-opt": gen_motion_opt, "mgdm": gen_mgdm, "motion-edit": gen_motion_edit, "sim-config": gen_sim_config, "stage-scripts": gen_stage_scripts}
+           "motion-opt": gen_motion_opt, "mgdm": gen_mgdm, "motion-edit": gen_motion_edit, "sim-config": gen_sim_config, "stage-scripts": gen_stage_scripts, "experience-buffer": gen_experience_buffer}
     picked = [s_ for s_ in STAGES if "--only-" + s_ in sys.argv]
     if "--check" in sys.argv:
         # regenerate everything into a scratch directory and compare with the committed fixtures array by array

@@ -543,6 +543,82 @@ print("ok")
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_g25_experience_buffer_table_and_sampler_walk(monkeypatch):
+    """Fixture G25 (the reference's DMPPOAgent._build_exp_buffer chain and ExperienceBuffer on CPU, learning/experience_buffer.py:3-115,
+    base_agent.py:224-253, ppo_agent.py:62-80, dm_ppo_agent.py:281-313): (1) this package's agent builds the same buffers - names in the
+    same order, dtypes, shapes - plus exactly two named update-phase caches; (2) the sampler replays the reference's index walk call
+    by call from the recorded torch.randperm draws: partly filled buffer (indices folded by the valid sample count), full buffer,
+    calls that wrap in mid-call, a call for the whole buffer."""
+    from parc_amd.learning import dm_ppo_agent, experience_buffer
+    with open(os.path.join(REPO, "tests", "golden", "g25_experience_buffer.json")) as f:
+        g = json.load(f)
+    T_, N_ = g["T"], g["N"]
+
+    class Space:
+        def __init__(self, n):
+            self.shape, self.dtype = (n,), np.float32
+
+    class Env:
+        NAME = "ig_parkour"
+
+        def get_obs_space(self):
+            return Space(1312)
+
+        def get_action_space(self):
+            return Space(28)
+
+        def get_num_envs(self):
+            return N_
+
+    class Agent:
+        _device, _steps_per_iter, _is_terrain_runner, _env = "cpu", T_, True, Env()
+
+        def get_num_envs(self):
+            return N_
+    ag = Agent()
+    dm_ppo_agent.DMPPOAgent._build_exp_buffer(ag, {})
+    ours = [[k, str(v.dtype).replace("torch.", ""), list(v.shape)] for k, v in ag._exp_buffer._buffers.items()]
+    extra = [b for b in ours if b[0] not in {r[0] for r in g["buffers"]}]
+    assert [b for b in ours if b not in extra] == sorted(g["buffers"], key=lambda r: [o[0] for o in ours].index(r[0]))
+    assert {b[0] for b in ours} - {b[0] for b in extra} == {r[0] for r in g["buffers"]}
+    for r in g["buffers"]:
+        assert r in ours, r                                                             # same name, dtype and shape
+    assert [b[0] for b in extra] == ["norm_obs", "loss_rec"] and extra[0][2] == [T_, N_, 1312] and extra[1][2] == [T_, N_, 32]
+    assert [[k, list(v.shape)] for k, v in ag._exp_buffer._flat_buffers.items() if k not in ("norm_obs", "loss_rec")] == \
+        sorted(g["flat_views"], key=lambda r: [o[0] for o in ours].index(r[0]))
+    # reference insertion order for the names both have, except that the two replan buffers come last here as there
+    ref_names = [r[0] for r in g["buffers"]]
+    assert [b[0] for b in ours if b[0] in ref_names] == ref_names
+    # ---- sampler
+    draws = [torch.tensor(p_, dtype=torch.long) for p_ in g["randperm_draws"]]
+    it = iter(draws)
+    monkeypatch.setattr(experience_buffer.torch, "randperm", lambda n, **k: next(it).clone())
+    buf = experience_buffer.ExperienceBuffer(buffer_length=T_, batch_size=N_, device="cpu")
+    # (the reference's constructor draws twice - allocation and _reset_sample_buf - this one once: skip the unused first draw)
+    buf._reset_sample_buf()
+    buf.add_buffer("x", torch.zeros([T_, N_, 2]))
+    walk = iter(g["index_walk"])
+    for t_ in range(2):
+        buf.record("x", torch.full([N_, 2], float(t_ + 1)))
+        buf.inc()
+    for _ in range(2):
+        w = next(walk)
+        assert w["phase"] == "partly filled" and buf.get_sample_count() == w["sample_count"]
+        assert buf._sample_rand_idx(w["n"]).tolist() == w["idx"] and buf._sample_buf_head == w["head_after"]
+    for t_ in range(2, 7):
+        buf.record("x", torch.full([N_, 2], float(t_ + 1)))
+        buf.inc()
+    assert buf._buffer_head == g["buffer_head_after_7_incs"] and buf.get_total_samples() == g["total_samples_after_7_incs"]
+    assert buf.get_data("x")[:, 0, 0].tolist() == g["rows_after_7_records"]
+    buf.reset()
+    for w in walk:
+        assert buf.get_sample_count() == w["sample_count"]
+        got = buf._sample_rand_idx(w["n"])
+        assert got.tolist() == w["idx"] and buf._sample_buf_head == w["head_after"], w
+    assert list(buf.sample(4).keys()) == g["sample_keys"] and list(buf.sample(4, keys=["x"]).keys()) == ["x"]
+    assert next(it, None) is None                                                       # every recorded draw was consumed, in order
+
+
 def test_torch_util_matches_reference_fixture():
     """parc_amd/util/torch_util.py (served as util.torch_util) against fixture G1 (reference util/torch_util.py on CPU)."""
     from parc_amd.util import torch_util as tu
