@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libparc_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["parc_kin.hip", "parc_sim.hip", "parc_ppo.hip", "parc_terrain.hip"]
+SOURCES = ["parc_kin.hip", "parc_sim.hip", "parc_sim_ref.hip", "parc_ppo.hip", "parc_terrain.hip"]
 
 MAX_BODIES = 16
 MAX_DOFS = 64
@@ -96,10 +96,11 @@ class PPOCfgS(ctypes.Structure):
 _lib = None
 
 
-# per-source optimisation level.  parc_sim.hip is built at -O2: at -O3 hipcc (ROCm 7.2, gfx950) miscompiles the
-# one-env-per-lane simulator core (results diverge from the -O0/-O1/-O2 builds and from the g++ host build of the
-# same source; -O3 -fno-unroll-loops or -O3 -fno-slp-vectorize are correct again) -- see DESIGN.md.
-OPT_LEVEL = {"parc_kin.hip": "-O3 -fno-slp-vectorize", "parc_sim.hip": "-O2"}
+# per-source optimisation level.  parc_sim_ref.hip (the one-env-per-lane reference kernel, not launched by the product) is built at
+# -O2: at -O3 hipcc (ROCm 7.2, gfx950) miscompiles it (results diverge from the -O0/-O1/-O2 builds and from the g++ host build of the
+# same source; GVN scalar PRE on the unrolled 3x3 helpers).  The product's simulator kernels (parc_sim.hip) are correct at
+# every level (profiles/r02_sim_o3_bisect.txt) and are built at whichever measured faster.
+OPT_LEVEL = {"parc_kin.hip": "-O3 -fno-slp-vectorize", "parc_sim.hip": os.environ.get("PARC_SIM_OPT", "-O3"), "parc_sim_ref.hip": "-O2"}
 
 
 def build(force=False, verbose=False):

@@ -1,25 +1,11 @@
-// Device entry points of the articulated-body simulator: one env per lane, 64 envs per workgroup.
+// Device entry points of the articulated-body simulator.  The product kernels are the body-per-lane ones below (16 lanes per env, 4 envs
+// per 64-thread workgroup, parc_sim_bpl.h); the one-env-per-lane reference formulation is a separate translation unit
+// (parc_sim_ref.hip, reached through parc_tune_sim_variant(0)).
 #include <hip/hip_runtime.h>
 
 #include "parc_sim_bpl.h"
 #include "parc_sim_core.h"
-
-#define SIM_THREADS 64
-
-__global__ __launch_bounds__(SIM_THREADS) void sim_step_kernel(const parc_sim_model_t *__restrict__ model, parc_terrain_t ter, int n_envs,
-                                                               float *root_state, float *dof_state, float *rigid_body_state,
-                                                               float *contact_forces, const float *__restrict__ env_offsets,
-                                                               const float *__restrict__ action, const float *__restrict__ act_lo,
-                                                               const float *__restrict__ act_hi, int n_sub, float h) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_envs) return;
-    const parc_sim_model_t &m = *model;
-    const int B = m.num_bodies, D = m.dof_size;
-    parc_sim::Scratch s;
-    parc_sim::env_step(m, ter, env_offsets + 3 * (size_t)e, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e,
-                       rigid_body_state + 13 * (size_t)B * e, contact_forces + 3 * (size_t)B * e, action + (size_t)D * e, act_lo, act_hi,
-                       n_sub, h, s);
-}
+#include "parc_sim_internal.h"
 
 // body-per-lane step: 16 lanes per env, 4 envs per 64-thread workgroup (parc_sim_bpl.h)
 __global__ __launch_bounds__(64) void sim_step_bpl_kernel(const parc_sim_model_t *__restrict__ model, parc_terrain_t ter, int n_envs,
@@ -78,20 +64,12 @@ __global__ __launch_bounds__(64) void sim_refresh_bpl_kernel(const parc_sim_mode
     store_lane_state<false>(L, b, maxd, x, nullptr, nullptr, rigid_body_state + 13 * (size_t)B * e, contact_forces + 3 * (size_t)B * e);
 }
 
-// envs (= lanes) per workgroup of the step kernel: 4096 envs are only 64 full waves on a 1024-SIMD chip, so partially
-// filled waves on more CUs can win; tuning knob, not part of the stable ABI
-static int g_sim_threads = SIM_THREADS;
 // 1 = body-per-lane kernel (default), 0 = one env per lane (the single-source reference core)
 static int g_sim_variant = 1;
 static const int model_bodies_hint = PARC_SIM_MAX_BODIES;      // PARC_SIM_MAX_BODIES == lanes per env
 extern "C" int parc_tune_sim_variant(int v) {
     if (v != 0 && v != 1) return PARC_EINVAL;
     g_sim_variant = v;
-    return PARC_OK;
-}
-extern "C" int parc_tune_sim_threads(int t) {
-    if (t != 8 && t != 16 && t != 32 && t != 64) return PARC_EINVAL;
-    g_sim_threads = t;
     return PARC_OK;
 }
 
@@ -109,12 +87,8 @@ static int sim_step_impl(void *stream, const parc_sim_model_t *model, parc_terra
         return e1 == hipSuccess ? PARC_OK : (int)e1;
     }
     if (timestep) return PARC_EUNSUPPORTED;          // the one-env-per-lane reference kernel does not carry the clock
-    const int th = g_sim_threads;
-    hipLaunchKernelGGL(sim_step_kernel, dim3((n_envs + th - 1) / th), dim3(th), 0, (hipStream_t)stream, model,
-                       terrain, n_envs, root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low,
-                       action_high, n_substeps, h);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? PARC_OK : (int)e;
+    return parc_sim_launch_env_per_lane(stream, model, terrain, n_envs, root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action,
+                                        action_low, action_high, n_substeps, h);
 }
 
 extern "C" int parc_sim_step(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,

@@ -1,6 +1,6 @@
 """Localise the -O3 divergence of the one-env-per-lane simulator kernel (sim_step_kernel, parc_sim_core.h).
 
-  python tools/bisect_sim_o3.py build            # here (no GPU): variants of parc_sim.hip -> gpurun_out/../_bisect/*.so
+  python tools/bisect_sim_o3.py build            # here (no GPU): variants of parc_sim.hip + parc_sim_ref.hip -> gpurun_out/../_bisect/*.so
   python tools/bisect_sim_o3.py run              # on the GPU box: every variant against the g++ host build of the same source
 
 A variant = optimisation flags + a set of loop tags kept rolled (-DPARC_BISECT -DPARC_ROLL_<k>, parc_sim_bisect.h).  `run` steps
@@ -49,7 +49,8 @@ def build():
         name, (flags, tags) = item
         so = os.path.join(OUT, "libsim_%s.so" % name)
         cmd = [hipcc, "--offload-arch=gfx950"] + flags.split() + ["-std=c++17", "-fPIC", "-shared", "-DPARC_BISECT"] + \
-            ["-DPARC_ROLL_%d" % k for k in tags] + ["-o", so, os.path.join(CSRC, "parc_sim.hip")]
+            ["-DPARC_ROLL_%d" % k for k in tags] + ["-I", os.path.dirname(os.path.abspath(__file__)), "-o", so,
+                                                     os.path.join(CSRC, "parc_sim.hip"), os.path.join(CSRC, "parc_sim_ref.hip")]
         subprocess.check_call(cmd)
         return name
     with ThreadPoolExecutor(max_workers=6) as ex:
@@ -159,7 +160,7 @@ def optbisect():
     def compile_and_run(limit):
         so = os.path.join(OUT, "libsim_bisect_%d.so" % limit)
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-opt-bisect-limit=%d" % limit, "-o", so,
-               os.path.join(CSRC, "parc_sim.hip")]
+               os.path.join(CSRC, "parc_sim.hip"), os.path.join(CSRC, "parc_sim_ref.hip")]
         res = subprocess.run(cmd, capture_output=True, text=True)
         assert res.returncode == 0, res.stderr[-2000:]
         # the device compilation is the one that names AMDGPU passes / the kernel; keep its numbered lines
