@@ -139,6 +139,9 @@ typedef struct {
     /* PARC_POST_TARGETS: DeepMimicEnv._update_motion_targets (dm_env.py:617-654) inside the launch */
     float *next_target_time;        /* [N]   time at which an env draws its next xy target */
     const float *target_rand;       /* [N,3] uniforms in [0,1): look-ahead time, and a Box-Muller pair for the 0.05 m target noise */
+    /* A launch on a ROW RANGE [e0, e0 + n) of larger allocations (a sub-env: every pointer above advanced by e0 rows, num_envs = n)
+     * keeps the term-major layout of reward_terms by naming the allocation's row length here; 0 = num_envs. */
+    int32_t reward_terms_stride;
 } parc_env_buffers_t;
 
 /* ---- K5: local heightmap ---------------------------------------------------------------------

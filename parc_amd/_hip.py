@@ -81,7 +81,8 @@ class EnvBuffersS(ctypes.Structure):
                 ("ref_joint_rot", c_vp), ("ref_dof_vel", c_vp), ("ref_dof_pos", c_vp),
                 ("ref_contacts", c_vp), ("ref_body_pos", c_vp),
                 ("obs", c_vp), ("reward", c_vp), ("reward_terms", c_vp), ("done", c_vp), ("done_kind", c_vp),
-                ("env_mask", c_vp), ("init_noise_xy", c_vp), ("next_target_time", c_vp), ("target_rand", c_vp)]
+                ("env_mask", c_vp), ("init_noise_xy", c_vp), ("next_target_time", c_vp), ("target_rand", c_vp),
+                ("reward_terms_stride", c_i32)]
 
 
 class RecordFieldS(ctypes.Structure):
@@ -103,13 +104,39 @@ _lib = None
 OPT_LEVEL = {"parc_kin.hip": "-O3 -fno-slp-vectorize", "parc_sim.hip": os.environ.get("PARC_SIM_OPT", "-O3"), "parc_sim_ref.hip": "-O2"}
 
 
+DIGEST_PATH = os.path.join(LIB_DIR, "libparc_hip.digest")
+
+
+def source_digest():
+    """sha256 over every source the library is built from (csrc/*, include/*.h) and the per-source flags.  Written next to the library
+    by build(); lib() refuses a library whose digest differs from the sources it sits beside - a stale .so would be called with
+    argument structs of another layout (file times are not used: a snapshot copy does not keep them)."""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))] + \
+        [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(repr((SOURCES, sorted(OPT_LEVEL.items()))).encode())
+    return h.hexdigest()
+
+
+def _stored_digest():
+    try:
+        with open(DIGEST_PATH) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
 def build(force=False, verbose=False):
     """Compile the HIP sources for gfx950 into parc_amd/lib/libparc_hip.so (hipcc cross-compiles without a GPU)."""
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    inc = os.path.join(os.path.dirname(_HERE), "include")
-    deps = [os.path.join(CSRC, s) for s in srcs] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
-        [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+    digest = source_digest()
+    if not force and os.path.exists(LIB_PATH) and _stored_digest() == digest:
         return LIB_PATH
     obj_dir = os.path.join(LIB_DIR, "obj")
     os.makedirs(obj_dir, exist_ok=True)
@@ -126,6 +153,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(DIGEST_PATH, "w") as f:
+        f.write(digest + "\n")
     return LIB_PATH
 
 
@@ -135,6 +164,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libparc_hip.so is not built ({}); run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "-- there is no CPU fallback".format(LIB_PATH))
+        if _stored_digest() != source_digest() and not os.environ.get("PARC_ALLOW_STALE_LIB"):
+            raise RuntimeError("libparc_hip.so was built from other sources than the ones beside it (csrc/, include/): rebuild with "
+                               "`python -c 'import __graft_entry__ as g; g.build()'` - calling a stale library would hand it argument "
+                               "structs of another layout")
         _lib = ctypes.CDLL(LIB_PATH)
         _declare(_lib)
     return _lib

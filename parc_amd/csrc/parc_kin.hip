@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                                rcfg.reward_w[3] * root_vel_r + rcfg.reward_w[4] * key_r;
                     dm += cp;
                     rbuf.reward[e] = rcfg.rel_deepmimic_w * dm;
-                    const int N = rbuf.num_envs;
+                    const int N = rbuf.reward_terms_stride > 0 ? rbuf.reward_terms_stride : rbuf.num_envs;
                     rbuf.reward_terms[0 * (size_t)N + e] = pose_r;
                     rbuf.reward_terms[1 * (size_t)N + e] = vel_r;
                     rbuf.reward_terms[2 * (size_t)N + e] = root_pose_r;

@@ -269,13 +269,17 @@ class IGParkourEnv(base_env.BaseEnv):
         """The host-side parameters a step / reset bakes into its kernel launches (a captured hipGraph of the step is only valid
         while they keep these values; learning/dm_ppo_agent keys its graphs by this tuple)."""
         dm = self._dm_env
-        if dm is None:
-            return (float(self._cfg.struct.episode_length),)
 
         def sig(v):
             return ("tensor", v.data_ptr()) if torch.is_tensor(v) else v        # device-resident values are read by the graph itself
-        return (float(self._cfg.struct.episode_length), dm._rand_reset, dm._demo_mode, sig(dm._rand_root_pos_offset_scale),
-                sig(dm._motion_start_time_fraction), dm.has_state_offsets())
+        out = (float(self._cfg.struct.episode_length),)
+        if dm is not None:
+            out += (dm._rand_reset, dm._demo_mode, sig(dm._rand_root_pos_offset_scale), sig(dm._motion_start_time_fraction), dm.has_state_offsets())
+        mg = self._mgdm_env
+        if mg is not None:         # (a replan may rebuild the plans' clip library with another shape: its table pointers are launch arguments)
+            ml = mg._motion_lib
+            out += ("mgdm", mg._demo_mode, None if ml is None else ml._rows.data_ptr(), mg._dont_auto_update_targets)
+        return out
 
     def set_rand_reset(self, val=None):
         val = (not self._rand_reset) if val is None else val
@@ -377,21 +381,45 @@ class IGParkourEnv(base_env.BaseEnv):
 
     # ------------------------------------------------------------------ device-side reset of finished envs
     def supports_device_reset(self):
-        dm = self._dm_env
-        return not self.has_mgdm_envs() and not dm.has_state_offsets() and dm._dm_motion_offsets is not None
+        """may the rows that finish in the NEXT step restart on the device (reset_done)?  Dataset rows: always, unless the GUI's state
+        offsets are set.  Generator rows: unless the reset after that step has to call the generator (replan) - a host decision the
+        fp32 mirror of the plan clock answers without a read-back - and only in the training configuration of the dataset rows."""
+        dm, mg = self._dm_env, self._mgdm_env
+        if dm is not None and (dm.has_state_offsets() or dm._dm_motion_offsets is None):
+            return False
+        if mg is not None:
+            if mg.replan_pending_after_next_step(self._timestep):
+                return False
+            if dm is not None and (dm._demo_mode or dm._one_motion_mode or not dm._rand_reset):
+                return False
+        return True
 
     def supports_graph_step(self):
-        """a step of the generator sub-env has host decisions in it (whose target timer ran out; whether it is time to replan)"""
-        return not self.has_mgdm_envs()
+        """every launch of a step is fixed-shape, for generator rows too (targets drawn for all rows and taken under a mask, the
+        replan-time rule decided on the device); what stays on the host is the replan itself, which happens in a reset, not in a step"""
+        return True
+
+    def host_step_replayed(self):
+        """host-side bookkeeping of a step that ran as a replayed hipGraph (learning/dm_ppo_agent calls it after every replay)"""
+        if self._mgdm_env is not None:
+            self._mgdm_env.host_step_replayed(self._timestep)
 
     def reset_done(self, done=None):
         """reset(nonzero(done)) without the nonzero: the same state changes as ``reset(env_ids)`` for every env whose
         done flag is set, as fixed-shape device work (no host sync, capturable in the rollout hipGraph).  Candidates are
         drawn for all envs and applied where the flag is set (parc_reset_apply), the reference pose / character state /
         observations of those envs come from masked launches of the post-step kernel."""
-        c, dm, N = self._core, self._dm_env, self._num_envs
+        c, dm = self._core, self._dm_env
         L = _hip.lib()
         done = self._done_buf if done is None else done
+        mixed = self.has_mgdm_envs()
+        if mixed:
+            c.reset_mask.copy_(done != base_env.DoneFlags.NULL.value)       # all rows; the dataset rows' launch rewrites its part
+        # the dataset rows are rows [0, N) of every buffer: a mixed env launches the same kernels on that row range
+        N = self._num_dm_envs
+        rows = (0, N) if mixed else None
+        if N == 0:
+            return self._reset_done_mgdm_rows()
         ml = dm._motion_lib
         if not (dm._demo_mode or dm._one_motion_mode) and dm._rand_reset and done.dtype == torch.int32 and done.is_contiguous():
             # the training configuration: sampling + bookkeeping in two launches from the step's uniform pool (no torch ops at all)
@@ -411,13 +439,16 @@ class IGParkourEnv(base_env.BaseEnv):
                                                  _hip.ptr(c.motion_terrain_ids), _hip.ptr(c.motion_time_offsets), _hip.ptr(c.motion_xy_offset),
                                                  _hip.ptr(c.timestep_buf), _hip.ptr(c.time_buf), _hip.ptr(c.done), _hip.ptr(c.next_target_xy_time),
                                                  _hip.ptr(self._ep_num_buf), _hip.ptr(c.init_noise_xy)), "parc_reset_sample_apply")
-            c.post_step(_hip.POST_REF | _hip.POST_INIT_CHAR | _hip.POST_MASKED)
+            c.post_step(_hip.POST_REF | _hip.POST_INIT_CHAR | _hip.POST_MASKED, rows=rows)
             _hip.check(L.parc_sim_refresh_bodies_masked(_hip.stream(), self._sim_model.device_ptr(self._device), N, _hip.ptr(c.reset_mask),
                                                         _hip.ptr(c.root_state), _hip.ptr(c.dof_state), _hip.ptr(c.rigid_body_state),
                                                         _hip.ptr(c.contact_forces)), "parc_sim_refresh_bodies_masked")
-            c.post_step(_hip.POST_OBS | _hip.POST_HF | _hip.POST_MASKED | _hip.POST_TARGETS, reset_rand=True)
+            c.post_step(_hip.POST_OBS | _hip.POST_HF | _hip.POST_MASKED | _hip.POST_TARGETS, reset_rand=True, rows=rows)
+            if mixed:
+                return self._reset_done_mgdm_rows()
             self._update_info()
             return self._obs_buf, self._info
+        assert not mixed, "generator rows restart on the device only in the training configuration (supports_device_reset)"
         c.reset_mask.copy_(done != base_env.DoneFlags.NULL.value)
         new_mid, new_tid, new_t = dm.sample_reset_all()
         offs = dm._dm_motion_offsets
@@ -438,6 +469,24 @@ class IGParkourEnv(base_env.BaseEnv):
                                                     _hip.ptr(c.contact_forces)), "parc_sim_refresh_bodies_masked")
         c.target_rand.uniform_()
         c.post_step(_hip.POST_OBS | _hip.POST_HF | _hip.POST_MASKED | _hip.POST_TARGETS)
+        self._update_info()
+        return self._obs_buf, self._info
+
+    def _reset_done_mgdm_rows(self):
+        """the generator rows' share of reset_done (c.reset_mask holds done != NULL for every row): a soft reset - the character goes back
+        onto the current frame of its plan - as masked, fixed-shape work; only reached while no replan is pending (supports_device_reset)"""
+        c, mg = self._core, self._mgdm_env
+        e0, n = self._num_dm_envs, self._num_mgdm_envs
+        B, D = self._cfg.num_bodies, self._cfg.dof_size
+        mask = c.reset_mask[e0:]
+        mg.reset_rows_masked(mask != 0)
+        p = _hip.ptr
+        _hip.check(_hip.lib().parc_sim_refresh_bodies_masked(_hip.stream(), self._sim_model.device_ptr(self._device), n, p(mask), p(c.root_state[e0:]),
+                                                             p(c.dof_state[e0 * D:]), p(c.rigid_body_state[e0 * B:]), p(c.contact_forces[e0 * B:])),
+                   "parc_sim_refresh_bodies_masked")
+        mg._post(_hip.POST_OBS | _hip.POST_HF | _hip.POST_MASKED)
+        self._ep_num_buf[e0:] += mask
+        self._publish_obs()
         self._update_info()
         return self._obs_buf, self._info
 
@@ -494,16 +543,16 @@ class IGParkourEnv(base_env.BaseEnv):
             self._sim_rows(act, 0, n_dm, c._terrain_struct)
         self._sim_rows(act, n_dm, n_mg, mg.terrain_struct())
         mg.update_time(self._timestep)
-        mg.update_misc()
+        mg.update_misc(fixed_shape=True)
         if n_dm > 0:
             c.rand_pool.uniform_()
             c.rand_pool_fresh = True
-            c.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS, self._dm_ids)
+            c.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS, rows=(0, n_dm))
             _hip.check(_hip.lib().parc_update_fail_rates(_hip.stream(), n_dm, c.mlib.num_motions(), _hip.ptr(c.motion_ids), _hip.ptr(c.done_kind),
                                                          float(self._dm_env._ema_weight), _hip.ptr(self._dm_env._motion_id_fail_rates)),
                        "parc_update_fail_rates")
         mg._post(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF)
-        mg.update_done_extra()
+        mg.update_done_extra(fixed_shape=True)
         self._publish_obs()
         if self._never_done:
             self._done_buf[:] = base_env.DoneFlags.NULL.value

@@ -114,6 +114,7 @@ class MotionGenDeepMimicEnv:
         e1 = e0 + n
         B, D = self._kin_char_model.get_num_joints(), self._kin_char_model.get_dof_size()
         self._core, self._first_env = core, e0
+        self._rows = (e0, n)
         self._abs_ids = torch.arange(e0, e1, device=self._device, dtype=torch.int64)
         rs = core.root_state[e0:e1]
         self._char_root_pos, self._char_root_rot = rs[:, 0:3], rs[:, 3:7]
@@ -153,9 +154,13 @@ class MotionGenDeepMimicEnv:
         return self._terrain_struct
 
     def _post(self, what, env_ids=None):
-        ids = self._abs_ids if env_ids is None else self._abs_ids[env_ids]
+        """the fused launch on this sub-env's rows: all of them as a contiguous row range (plain env indexing, may be masked by the
+        core's reset mask), or the listed ones"""
         self.sync_core_rows()
-        self._core.post_step(what | _hip.POST_PLAN_CLOCK, ids, mlib=self._motion_lib, terrain_struct=self.terrain_struct())
+        if env_ids is None:
+            self._core.post_step(what | _hip.POST_PLAN_CLOCK, rows=self._rows, mlib=self._motion_lib, terrain_struct=self.terrain_struct())
+        else:
+            self._core.post_step(what | _hip.POST_PLAN_CLOCK, self._abs_ids[env_ids], mlib=self._motion_lib, terrain_struct=self.terrain_struct())
 
     # ------------------------------------------------------------------ env protocol (reference :89-128)
     def reset(self, env_ids):
@@ -170,15 +175,34 @@ class MotionGenDeepMimicEnv:
             self._reset_char(env_ids)
 
     def pre_physics_step(self):
-        # the character's state before the simulator overwrites it: the generator continues from it
-        self._agent_state_hist = self._get_char_motion_frames(ref=False)
+        # the character's state before the simulator overwrites it: the generator continues from it (stored in place: the history
+        # tensors keep their addresses, a captured rollout step writes the same ones on every replay)
+        self._agent_state_hist.store(self._get_char_motion_frames(ref=False))
 
     def update_time(self, timestep):
         self._mgdm_time_buf[0] += timestep
         self._plan_time_host = np.float32(self._plan_time_host + np.float32(timestep))
 
-    def update_misc(self):
-        self._ref_state_hist = self._get_char_motion_frames(ref=True)
+    def host_step_replayed(self, timestep):
+        """What a step changes on the HOST, for a step that ran as a replayed hipGraph (the device part is in the graph): the plan
+        clock's fp32 mirror advances, and once it passes the plan length the next reset has to replan (update_done_extra)."""
+        self._plan_time_host = np.float32(self._plan_time_host + np.float32(timestep))
+        if self._plan_time_host > np.float32(self._plan_length):
+            self._replan_flag = True
+
+    def replan_pending_after_next_step(self, timestep):
+        """True if the reset that follows the NEXT step has to call the generator (host decision: such a step is followed by the
+        eager reset path, every other step restarts its finished rows on the device)"""
+        return self._replan_flag or np.float32(self._plan_time_host + np.float32(timestep)) > np.float32(self._plan_length)
+
+    def update_misc(self, fixed_shape=False):
+        """fixed_shape: targets are drawn for every row and taken where the timer ran out (no index list, no read-back: capturable;
+        same distribution, different consumption of the random stream than the reference's `nonzero` + per-id draws, which the
+        id-list path keeps for the fixture replay)"""
+        self._ref_state_hist.store(self._get_char_motion_frames(ref=True))
+        if fixed_shape:
+            self.pick_new_xy_targets_masked(self._time_buf > self._next_target_xy_time)
+            return
         due = (self._time_buf > self._next_target_xy_time).nonzero()
         if len(due) > 0:
             self.pick_new_xy_targets(due.squeeze(-1))
@@ -203,7 +227,7 @@ class MotionGenDeepMimicEnv:
         self._post(_hip.POST_REWARD_DONE)
         self.update_done_extra()
 
-    def update_done_extra(self):
+    def update_done_extra(self, fixed_shape=False):
         t = self._terrain
         NULL, FAIL, TIME = (base_env.DoneFlags.NULL.value, base_env.DoneFlags.FAIL.value, base_env.DoneFlags.TIME.value)
         HARD = ReplanFlags.HARD_RESET.value
@@ -216,7 +240,16 @@ class MotionGenDeepMimicEnv:
         rb[:] = torch.where(oob, torch.full_like(rb, HARD), rb)
         done[:] = torch.where(self._char_root_pos[..., 2] > 3.0, torch.full_like(done, FAIL), done)      # launched into the air
         rb[:] = torch.where(done == FAIL, torch.full_like(rb, HARD), rb)                      # a failed env re-spawns at the next replan
-        if self._plan_time_host > np.float32(self._plan_length):
+        if fixed_shape:
+            # the same rule with the decision on the device (the plan clock is a device element): nothing here depends on the host's
+            # branch, so a captured step stays valid across the replan boundary; the host's own consequence - the next reset replans -
+            # is drawn from the fp32 mirror of the clock (here, or in host_step_replayed for a replayed step)
+            due = self._mgdm_time_buf > self._plan_length                                     # [1], broadcasts over the rows
+            rb[:] = torch.where(due & (self._replan_counter >= self._max_replans), torch.full_like(rb, HARD), rb)
+            done[:] = torch.where(due & (done == NULL) & (rb == HARD), torch.full_like(done, TIME), done)
+            if self._plan_time_host > np.float32(self._plan_length):
+                self._replan_flag = True
+        elif self._plan_time_host > np.float32(self._plan_length):
             self._replan_flag = True
             hard = self._compute_hard_reset_envs_mask()
             done[:] = torch.where((done == NULL) & hard, torch.full_like(done, TIME), done)   # re-spawning envs end their episode
@@ -334,6 +367,37 @@ class MotionGenDeepMimicEnv:
         nxt = self._rand(n) * (self._target_dur_max - self._target_dur_min) + self._target_dur_min + self._time_buf[env_ids]
         self._next_target_xy_time[env_ids] = 100000.0 if self._dont_auto_update_targets else nxt
 
+    def pick_new_xy_targets_masked(self, mask):
+        """pick_new_xy_targets for the rows where `mask` [n] is set: three draws for ALL rows, taken under the mask"""
+        n = self._num_envs
+        heading = (self._rand(n) * (torch.pi * 2) - torch.pi) * self._target_heading_scale
+        dist = self._rand(n) * (self._target_dist_max - self._target_dist_min) + self._target_dist_min
+        rel = torch.zeros((n, 2), dtype=torch.float32, device=self._device)
+        rel[:, 0] = 1.0
+        rel = torch_util.rotate_2d_vec(rel * dist.unsqueeze(-1), heading)
+        rel = torch_util.rotate_2d_vec(rel, torch_util.calc_heading(self._char_root_rot))
+        new_xy = self._char_root_pos[:, 0:2] + rel
+        nxt = self._rand(n) * (self._target_dur_max - self._target_dur_min) + self._target_dur_min + self._time_buf
+        if self._dont_auto_update_targets:
+            nxt = torch.full_like(nxt, 100000.0)
+        self._target_xy.copy_(torch.where(mask.unsqueeze(-1), new_xy, self._target_xy))
+        self._next_target_xy_time.copy_(torch.where(mask, nxt, self._next_target_xy_time))
+
+    def reset_rows_masked(self, mask):
+        """reset(env_ids) without a pending replan (reference :89-128 second branch, _reset_char :499-505) for the rows whose bool mask
+        is set, as fixed-shape work: clocks and flag cleared, character put on the current frame of its plan, history restarted.
+        The caller refreshes body poses / observations of those rows (masked launches) and counts the episode."""
+        m1, m2 = mask, mask.unsqueeze(-1)
+        self._timestep_buf.masked_fill_(m1, 0)
+        self._time_buf.masked_fill_(m1, 0.0)
+        self._done_buf.masked_fill_(m1, base_env.DoneFlags.NULL.value)
+        self._char_rigid_body_vel.masked_fill_(m2.unsqueeze(-1), 0.0)
+        self._char_rigid_body_ang_vel.masked_fill_(m2.unsqueeze(-1), 0.0)
+        for dst, src in ((self._char_root_pos, self._ref_root_pos), (self._char_root_rot, self._ref_root_rot), (self._char_root_vel, self._ref_root_vel),
+                         (self._char_root_ang_vel, self._ref_root_ang_vel), (self._char_dof_pos, self._ref_dof_pos), (self._char_dof_vel, self._ref_dof_vel)):
+            dst.copy_(torch.where(m2, src, dst))
+        self._agent_state_hist.set_vals_masked(self._ref_state_hist, mask)
+
     # ------------------------------------------------------------------ state helpers (reference :499-565)
     def _reset_char(self, env_ids):
         """a soft reset puts the character on the CURRENT frame of its plan (plans change at replans only)"""
@@ -417,7 +481,7 @@ class MotionGenDeepMimicEnv:
         else:
             self._motion_lib.update_frames(frames, plan.contacts)
         frame_zero = self._get_state_dict_from_motion_lib(0.0, self._motion_ids)
-        self._ref_state_hist = frame_zero
+        self._ref_state_hist.store(frame_zero)
         if H > 0:
             # the re-spawned characters start on the plan's frame at one control step
             times = torch.ones(H, dtype=torch.float, device=dev) * self._timestep

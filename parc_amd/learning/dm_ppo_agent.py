@@ -387,8 +387,13 @@ class DMPPOAgent(torch.nn.Module):
                 self._graph_fallback_reset = True
                 return done
             self._graphs[key] = (g, done)
+            fresh = True          # the capture ran the step's host code once already (plan-clock mirror etc.): the replay below is that step
+        else:
+            fresh = False
         g, done = self._graphs[key]
         g.replay()
+        if not fresh and hasattr(self._env, "host_step_replayed"):
+            self._env.host_step_replayed()           # what the step changes on the host (the device part is the graph)
         if key[0]:
             self._obs_norm._new_count += self.get_num_envs()
         eb.get_data("compute_time")[eb._buffer_head].fill_(time.time() - self._env._start_compute_time)

@@ -179,8 +179,32 @@ class TrackerCore:
         self._hf = hf
         self._terrain_struct = _hip.terrain_struct(hf, terrain.min_point.tolist(), terrain.dxdy.tolist())
 
-    def buffers(self, reset=False):
-        """parc_env_buffers_t of this core; reset=True: the variant whose target uniforms are the restart slice of the pool"""
+    def buffers(self, reset=False, rows=None):
+        """parc_env_buffers_t of this core; reset=True: the variant whose target uniforms are the restart slice of the pool;
+        rows=(e0, n): the same buffers seen as a core of n envs starting at row e0 (every pointer advanced by e0 rows, reward_terms keeps
+        the allocation's row length) - how a sub-env launches on its contiguous row range with plain, coalesced env indexing and with
+        the per-env mask of the device-side reset, neither of which an env-id list allows."""
+        if rows is not None:
+            key = (bool(reset), int(rows[0]), int(rows[1]))
+            cache = self.__dict__.setdefault("_buf_struct_rows", {})
+            if key not in cache:
+                e0, n = key[1], key[2]
+                assert 0 <= e0 and e0 + n <= self.N
+                B, D = self.cfg.num_bodies, self.cfg.dof_size
+                s = _hip.EnvBuffersS.from_buffer_copy(self.buffers(reset))
+                rowlen = dict(root_state=13, dof_state=2 * D, rigid_body_state=13 * B, contact_forces=3 * B, env_offsets=3, motion_ids=2,
+                              motion_time_offsets=1, motion_xy_offset=2, time_buf=1, target_xy=2, ref_root_pos=3, ref_root_rot=4, ref_root_vel=3,
+                              ref_root_ang_vel=3, ref_joint_rot=4 * (B - 1), ref_dof_vel=D, ref_dof_pos=D, ref_contacts=B, ref_body_pos=3 * B,
+                              obs=self.cfg.obs_dim, reward=1, reward_terms=1, done=1, done_kind=1, env_mask=1, init_noise_xy=2,
+                              next_target_time=1, target_rand=3)          # in 4-byte words (motion_ids: int64 = 2 words)
+                for name, words in rowlen.items():
+                    base = getattr(s, name)
+                    if base:
+                        setattr(s, name, base + 4 * words * e0)
+                s.num_envs = n
+                s.reward_terms_stride = self.N
+                cache[key] = s
+            return cache[key]
         if reset:
             if self._buf_struct_reset is None:
                 self._buf_struct_reset = _hip.EnvBuffersS.from_buffer_copy(self.buffers())
@@ -195,7 +219,7 @@ class TrackerCore:
                 p(self.ref_root_pos), p(self.ref_root_rot), p(self.ref_root_vel), p(self.ref_root_ang_vel),
                 p(self.ref_joint_rot), p(self.ref_dof_vel), p(self.ref_dof_pos), p(self.ref_contacts), p(self.ref_body_pos),
                 p(self.obs), p(self.reward), p(self.reward_terms), p(self.done), p(self.done_kind),
-                p(self.reset_mask), p(self.init_noise_xy), p(self.next_target_xy_time), p(self.target_rand))
+                p(self.reset_mask), p(self.init_noise_xy), p(self.next_target_xy_time), p(self.target_rand), 0)
         return self._buf_struct
 
     # ---- K5 (IGParkourEnv._refresh_obs_hfs)
@@ -208,9 +232,10 @@ class TrackerCore:
                                                   self.cfg.obs_dim), "parc_refresh_obs_hfs")
 
     # ---- fused K3/K2/K4/K6-K10
-    def post_step(self, what, env_ids=None, reset_rand=False, mlib=None, terrain_struct=None):
+    def post_step(self, what, env_ids=None, reset_rand=False, mlib=None, terrain_struct=None, rows=None):
         """mlib / terrain_struct: the clip library and heightfield of a sub-env other than the default one (the motion-generator
-        sub-env launches on its own rows with its own)"""
+        sub-env launches on its own rows with its own); rows=(e0, n): launch on that contiguous row range (see buffers)"""
+        assert rows is None or env_ids is None
         mlib = self.mlib if mlib is None else mlib
         terrain_struct = self._terrain_struct if terrain_struct is None else terrain_struct
         if env_ids is not None:
@@ -221,12 +246,12 @@ class TrackerCore:
             ids = _hip.ptr(env_ids)
         else:
             n, ids = 0, _hip.c_vp(0)
-        timed = self.timing_events is not None and env_ids is None and (what & _hip.POST_REWARD_DONE)
+        timed = self.timing_events is not None and env_ids is None and rows is None and (what & _hip.POST_REWARD_DONE)
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         _hip.check(_hip.lib().parc_track_post_step(_hip.stream(), self.km.c_struct(), mlib.c_struct(), terrain_struct,
-                                                   self.cfg.struct, self.buffers(reset_rand), ids, n, what, _hip.ptr(self.ray_xy_points)),
+                                                   self.cfg.struct, self.buffers(reset_rand, rows), ids, n, what, _hip.ptr(self.ray_xy_points)),
                    "parc_track_post_step")
         if timed:
             ev1.record()

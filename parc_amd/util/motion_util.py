@@ -53,6 +53,21 @@ class MotionFrames:
             if mine is not None:
                 mine[ids] = getattr(other, f)[ids].clone()
 
+    def store(self, other):
+        """in place: every field takes `other`'s values (same shapes); the tensors keep their addresses (captured rollout steps)"""
+        for f in FIELDS:
+            mine = getattr(self, f)
+            if mine is not None:
+                mine.copy_(getattr(other, f))
+
+    def set_vals_masked(self, other, mask):
+        """set_vals for the rows where the bool mask [batch] is set, as fixed-shape work (no index list)"""
+        for f in FIELDS:
+            mine = getattr(self, f)
+            if mine is not None:
+                m = mask.reshape([-1] + [1] * (mine.dim() - 1))
+                mine.copy_(torch.where(m, getattr(other, f), mine))
+
     def get_copy(self, new_device):
         return self._map(lambda x: x.clone().to(device=new_device))
 

@@ -619,6 +619,22 @@ def test_g25_experience_buffer_table_and_sampler_walk(monkeypatch):
     assert next(it, None) is None                                                       # every recorded draw was consumed, in order
 
 
+def test_library_is_built_from_the_sources_beside_it():
+    """lib() refuses a stale libparc_hip.so (argument structs of another layout would be handed to it): the digest build() stored
+    equals the digest of csrc/ + include/ now, and a changed source is noticed."""
+    from parc_amd import _hip
+    assert _hip._stored_digest() == _hip.source_digest()
+    old = _hip.OPT_LEVEL.get("parc_terrain.hip")
+    _hip.OPT_LEVEL["parc_terrain.hip"] = "-O1"
+    try:
+        assert _hip._stored_digest() != _hip.source_digest()
+    finally:
+        if old is None:
+            del _hip.OPT_LEVEL["parc_terrain.hip"]
+        else:
+            _hip.OPT_LEVEL["parc_terrain.hip"] = old
+
+
 def test_torch_util_matches_reference_fixture():
     """parc_amd/util/torch_util.py (served as util.torch_util) against fixture G1 (reference util/torch_util.py on CPU)."""
     from parc_amd.util import torch_util as tu

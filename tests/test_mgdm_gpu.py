@@ -218,7 +218,7 @@ def test_env_with_both_sub_envs(fraction, timer):
     env, _, _ = workloads.build_env("boxes_64clips", N, DEV, seed=3, env_overrides={"fraction_dm_envs": fraction, "mgdm": mg_cfg, "enable_replan_timer_obs": timer})
     n_dm = env._num_dm_envs
     assert n_dm == int(fraction * N) and env.has_mgdm_envs() and env.has_dm_envs() == (n_dm > 0)
-    assert not env.supports_device_reset() and not env.supports_graph_step()
+    assert env.supports_graph_step()                                   # every launch of a step is fixed-shape, generator rows included
     mg = env.get_mgdm_env()
     assert WalkGenerator.calls == 1                                    # plans exist before the first observation
     obs, info = env.reset()
@@ -258,8 +258,9 @@ def test_env_with_both_sub_envs(fraction, timer):
 
 
 def test_agent_trains_on_an_env_with_generator_rows():
-    """The PPO agent on a split env: it steps such an env eagerly (no rollout graph: the sub-env takes host decisions), records the replan
-    timer / counter columns the reference's agent records for this env (dm_ppo_agent.py:278), and a training iteration goes through."""
+    """The PPO agent on a split env: the rollout step runs as a captured hipGraph like on a pure tracker env (round 3: the generator
+    rows' target picks, termination rules and restarts are fixed-shape), it records the replan timer / counter columns the reference's
+    agent records for this env (dm_ppo_agent.py:278), and a training iteration goes through."""
     from parc_amd import workloads
     N = 32
     WalkGenerator.calls = 0
@@ -269,17 +270,83 @@ def test_agent_trains_on_an_env_with_generator_rows():
     env, _, _ = workloads.build_env("boxes_64clips", N, DEV, seed=5, env_overrides={"fraction_dm_envs": 0.5, "mgdm": mg_cfg})
     assert env._enable_replan_timer_obs and env.get_obs_space().shape[0] == env._cfg.obs_dim + 1       # the tracker config's default
     agent = workloads.build_agent(env, DEV, steps_per_iter=16, update_epochs=1, batch_size=2)
-    assert not agent._graph_ok() or agent._mode.name != "TRAIN"
     agent._curr_obs, agent._curr_info = env.reset()
     agent._init_train()
-    assert not agent._graph_ok()
+    assert agent._graph_ok()
     w0 = agent._model._actor_layers[0].weight.clone()
     info = agent._train_iter()
+    assert len(agent._graphs) >= 1 and agent._use_hip_graph           # captured, not fallen back to eager launches
     assert np.isfinite(info["critic_loss"].item()) and np.isfinite(info["actor_loss"].item())
     assert not torch.equal(w0, agent._model._actor_layers[0].weight)
     assert WalkGenerator.calls >= 3                                     # construction + a replan every 0.2 s = 6 steps
     eb = agent._exp_buffer
     rc = eb.get_data("replan_counter")
     assert rc.shape[-1] == N and (rc[:, :16] == 0).all() and (rc[:, 16:] >= 1).all()
+    rt = eb.get_data("replan_timer")
+    assert float(rt.max()) <= 0.2 + 2.0 / 30.0 + 1e-6 and float(rt.min()) >= 1.0 / 30.0 - 1e-6
+
+
+@pytest.mark.parametrize("fraction", [0.5, 0.0])
+def test_generator_rows_inside_the_captured_rollout_step(fraction):
+    """Round-2 review item: a split env used to drop to eager stepping because the generator sub-env took host decisions inside a step
+    (`nonzero` of expired target timers, `is it time to replan`).  Now the agent's rollout step - policy, record, simulator on both
+    heightfields, both fused launches, target picks, termination rules, device-side restart of finished rows of BOTH kinds - is one
+    captured hipGraph; the only host decision left is the replan, which is a reset, runs eagerly between two graph replays, and is
+    predicted from the fp32 mirror of the plan clock (no read-back).  Checked over 3 iterations of 16 steps with a replan every 6 steps:
+    the device clock and its host mirror never part, the generator is called exactly on schedule, generator rows follow their plans,
+    rows that finish restart (episode counts move, clocks return to zero), counters stay within max_replans."""
+    from parc_amd import workloads
+    from parc_amd.envs import base_env
+    N, T = 64, 16
+    WalkGenerator.calls = 0
+    mg_cfg = {"plan_length": 0.2, "ddim_stride": 50, "max_replans": 3, "cfg_scale": 0.7, "target_dist_max": 4.0, "target_dist_min": 1.0,
+              "target_dur_max": 0.3, "target_dur_min": 0.1, "target_heading_scale": 0.5, "generator": WalkGenerator(),
+              "heightmap": {"horizontal_scale": 0.4, "sq_m_per_env": 0.5, "safety_region": 3.0, "num_segments": 6, "platform_heights": [0.0, 0.4]}}
+    env, _, _ = workloads.build_env("boxes_64clips", N, DEV, seed=7, env_overrides={"fraction_dm_envs": fraction, "mgdm": mg_cfg})
+    n_dm = env._num_dm_envs
+    mg = env.get_mgdm_env()
+    agent = workloads.build_agent(env, DEV, steps_per_iter=T, update_epochs=1, batch_size=2)
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    calls0 = WalkGenerator.calls
+    ep0 = env._ep_num_buf.clone()
+    eager_resets = 0
+    orig = agent._reset_done_envs
+
+    def counting(done):
+        nonlocal eager_resets
+        eager_resets += 1
+        return orig(done)
+    agent._reset_done_envs = counting
+    targets0 = env._target_xy[n_dm:].clone()
+    for it in range(3):
+        agent._train_iter()
+        torch.cuda.synchronize()
+        assert float(mg._mgdm_time_buf[0]) == float(mg._plan_time_host), (float(mg._mgdm_time_buf[0]), float(mg._plan_time_host))
+    steps = 3 * T
+    # plan_length 0.2 s at 30 Hz, plans start at one step: the clock passes 0.2 s on the 6th step after a replan -> a replan every 6 steps
+    assert WalkGenerator.calls - calls0 == steps // 6, (WalkGenerator.calls - calls0, steps // 6)
+    # only the steps that end in a replan (and the first two warm-up steps before the capture) take the eager reset path
+    assert eager_resets <= steps // 6 + 2, eager_resets
+    assert len(agent._graphs) == 2                                      # the step with and without the device-side restart
+    assert torch.isfinite(env._obs_buf).all() and torch.isfinite(env._reward_buf).all()
+    rp = mg._motion_lib.calc_motion_frame(mg._motion_ids, mg._mgdm_time_buf.expand(N - n_dm))[0]
+    assert (env._ref_root_pos[n_dm:] - rp).abs().max() < 1e-4           # generator rows: reference pose = their plan at the plan clock
+    assert not torch.equal(targets0, env._target_xy[n_dm:])              # targets were re-drawn under the mask (timers of 0.1 - 0.3 s)
+    # the five exp(-err) reward terms of EVERY row are positive: a row-range launch writes them with the allocation's row length
+    # (parc_env_buffers_t.reward_terms_stride), not with its own row count
+    assert (env._core.reward_terms[0:5] > 0).all() and (env._core.reward_terms[0:5] <= 1.0).all()
+    assert (mg._replan_counter >= 1).all() and (mg._replan_counter <= mg_cfg["max_replans"]).all()
+    eb = agent._exp_buffer
+    done = eb.get_data("done")
+    ts = eb.get_data("timestep")
+    epn = eb.get_data("ep_num")
+    # a row that finished at step t starts the next step with its clock at zero and one more episode counted - for both kinds of rows,
+    # whichever path restarted it (recorded timestep[t + 1] == 1 is the first step of the new episode)
+    fin = done[:-1] != base_env.DoneFlags.NULL.value
+    assert fin.any()
+    assert (ts[1:][fin] == 1).all()
+    assert (epn[1:][fin] == epn[:-1][fin] + 1).all() and (epn[1:][~fin] == epn[:-1][~fin]).all()
+    assert (env._ep_num_buf >= ep0).all() and (env._ep_num_buf[n_dm:] > ep0[n_dm:]).any()
     rt = eb.get_data("replan_timer")
     assert float(rt.max()) <= 0.2 + 2.0 / 30.0 + 1e-6 and float(rt.min()) >= 1.0 / 30.0 - 1e-6

@@ -1,6 +1,8 @@
 """Step rate of an env whose rows are split between dataset clips and generated plans (fraction_dm_envs < 1), with a stand-in planner
-(straight walk towards the target, 45 frames): env.step + env.reset(done ids) as the agent's eager loop issues them, and the cost of a
-replan (generator excluded / included).   python tools/mgdm_probe.py [envs] [steps]   -> one JSON line per fraction"""
+(straight walk towards the target, 45 frames): (a) env.step + env.reset(done ids) as an eager loop issues them, and the cost of a
+replan (generator excluded / included); (b) the way the agent's rollout issues them since round 3: env.step + env.reset_done captured
+ONCE in a hipGraph and replayed, the steps that end in a replan through the eager reset.
+python tools/mgdm_probe.py [envs] [steps]   -> one JSON line per fraction"""
 import json
 import os
 import sys
@@ -76,7 +78,62 @@ def main():
                 replans += 1
         torch.cuda.synchronize()
         dt = time.time() - t0
+        # ---- (b) captured step + device-side restart, replayed
+        graph_ms = None
+        a_buf = torch.minimum(torch.maximum(env._ref_dof_pos, low), high).clone()
+        env._info_snapshots = False
+        g, gsteps, greplans = None, 0, 0
+        for _ in range(3):                                   # eager warm-up of the paths the capture will record
+            if env.supports_device_reset():
+                env.step(a_buf)
+                env.reset_done()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(steps):
+            a_buf.copy_(torch.minimum(torch.maximum(env._ref_dof_pos, low), high))
+            if env.supports_device_reset():
+                if g is None:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        env.step(a_buf)
+                        env.reset_done()
+                    g.replay()
+                else:
+                    g.replay()
+                    env.host_step_replayed()
+            else:                                            # this step ends in a replan: eager step + the reset that calls the planner
+                _, _, done, _ = env.step(a_buf)
+                env.reset((done != base_env.DoneFlags.NULL.value).nonzero().flatten())
+                greplans += 1
+            gsteps += 1
+        torch.cuda.synchronize()
+        graph_ms = 1e3 * (time.time() - t0) / gsteps
+        # replayed steps alone (no replan in the window)
+        pure = None
+        if g is not None:
+            k = 0
+            torch.cuda.synchronize()
+            t0 = time.time()
+            while k < 200:
+                if not env.supports_device_reset():
+                    _, _, done, _ = env.step(a_buf)
+                    env.reset((done != base_env.DoneFlags.NULL.value).nonzero().flatten())
+                    torch.cuda.synchronize()
+                    t0 = time.time()
+                    k = 0
+                    continue
+                g.replay()
+                env.host_step_replayed()
+                k += 1
+                if k == 20:
+                    break
+            torch.cuda.synchronize()
+            pure = 1e3 * (time.time() - t0) / max(k, 1)
         print(json.dumps({"envs": N, "fraction_dm_envs": fraction, "steps": steps, "build_s": round(build_s, 2), "ms_per_step": round(1e3 * dt / steps, 3),
+                          "ms_per_step_captured_incl_replans": round(graph_ms, 3), "replans_in_captured_run": greplans,
+                          "ms_per_replayed_step": None if pure is None else round(pure, 3),
+                          "plan_clock_device_vs_host": [float(mg._mgdm_time_buf[0]), float(mg._plan_time_host)] if mg is not None else None,
                           "env_steps_per_s": round(N * steps / dt), "episodes_ended": dones, "replans": replans,
                           "ms_per_replan_with_generator": round(1e3 * reset_s / max(replans, 1), 3),
                           "ms_per_replan_generator_alone": round(1e3 * WalkGenerator.seconds / max(replans, 1), 3),
