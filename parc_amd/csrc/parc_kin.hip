@@ -989,11 +989,10 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                                                                      parc_track_cfg_t cfg, parc_env_buffers_t buf,
                                                                      const int64_t *__restrict__ env_ids, int n_total, int what,
                                                                      const float *__restrict__ ray_xy) {
-    __shared__ __attribute__((aligned(16))) float rows[POST_EPB * POST_MAX_ROW];   // 4 rows at stride obs_dim (contiguous, like the 4 output rows)
     __shared__ __attribute__((aligned(16))) float envd[POST_EPB][20];   // root pos 3 | root rot 4 | heading^-1 4 | env id | root vel 3 | ang vel 3
     __shared__ __attribute__((aligned(16))) float qryd[1 + PARC_MAX_TAR_STEPS][POST_EPB][12];   // idx0 idx1 blend - | loop shift xyz, time | tile offset xy, motion end
     __shared__ float tgt_xy[POST_EPB][2];
-    __shared__ __attribute__((aligned(16))) float cjq[POST_EPB][GRP][4];   // simulated character's joint rotations, for the pose reward                                                       // xy target the task terms read
+    if (what & 0x100000) return;                     // (timing diagnostic: the launch alone)
     const int tid = threadIdx.x;
     const int wv = tid >> 6, gg = (tid & 63) >> 4, b = tid & 15;
     const int B = m.num_bodies, J = B - 1, D = m.dof_size, K = cfg.num_key_bodies, S = cfg.num_tar_steps;
@@ -1013,7 +1012,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     }
     const bool live = el < n_total && (!masked || buf.env_mask[el] != 0);
     const int RS = cfg.obs_dim;
-    float *row = rows + le * RS;
     const int Wc = 12 + 6 * J + D + 3 * K;   // char_obs width (136)
     const int Wt = 9 + 6 * J + 3 * K;        // one target step (105)
     const int row_len = cfg.obs_dim - cfg.num_ray_points;  // 871
@@ -1105,8 +1103,11 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         const int he = env_ids ? (int)env_ids[hel] : hel;
         const hf_env_prm pr = hf_env_params<true>(he, buf.root_state, buf.env_offsets, ter, 1.0f / ter.dx, 1.0f / ter.dy);
         const float max_i = (float)(ter.dim_x - 1), max_j = (float)(ter.dim_y - 1);
-        float *hrow = rows + l2 * cfg.obs_dim + (cfg.obs_dim - P);
-        for (int p = ht - l2 * tpe; p < P; p += tpe) {
+        // straight into the observation row (consecutive lanes = consecutive columns: 256-byte runs per store instruction), long before
+        // the pose waves have anything to write: the 441 columns are a third of the row's bytes
+        float *hrow = buf.obs + (size_t)he * RS + (RS - P);
+        const bool hlive = (int)blockIdx.x * POST_EPB + l2 < n_total && (!masked || buf.env_mask[hel] != 0);
+        for (int p = hlive ? ht - l2 * tpe : P; p < P; p += tpe) {
             float rx = ray_xy[2 * p], ry = ray_xy[2 * p + 1];
             float ui = fmaf(rx, pr.ax, fmaf(ry, pr.bx, pr.cx));
             float uj = fmaf(rx, pr.ay, fmaf(ry, pr.by, pr.cy));
@@ -1115,6 +1116,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             hrow[p] = __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - pr.gz, cfg.min_obs_h, cfg.max_obs_h);
         }
     }
+    if (what & 0x200000) return;                     // (timing diagnostic: launch + phase 0 + heightmap gather, no barrier)
     // loads that do not depend on phase 0
     int key_slot = -1;
     for (int k = 0; k < K; ++k)
@@ -1125,6 +1127,10 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
 
     const int e = __float_as_int(envd[le][11]);
     const float *dofs = buf.dof_state + (size_t)e * D * 2;  // interleaved pos,vel
+    // every wave writes its own columns of the observation row straight to memory as it produces them: after the first barrier the
+    // waves of a workgroup never meet again, so the stores of the early finishers overlap the arithmetic of the late ones (until
+    // round 3 the rows were assembled in LDS and streamed out behind a second barrier: 3.6 of 17.7 us with every SIMD idle)
+    float *row = buf.obs + (size_t)e * RS;
 
     // ---- phase A: every group gets its pose (root transform + one joint rotation per lane)
     frame_query fq;
@@ -1135,7 +1141,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         p_root = mk3(envd[le][0], envd[le][1], envd[le][2]);
         r_root = mk4(envd[le][3], envd[le][4], envd[le][5], envd[le][6]);
         if (valid && b > 0) jq = joint_dof_to_rot(m, b, dofs, 2);      // K1 (kin_char_model.py:478-491)
-        *reinterpret_cast<float4 *>(cjq[le][b]) = make_float4(jq.x, jq.y, jq.z, jq.w);
     } else {
         const float4 q0 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[0];
         const float4 q1 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[1];
@@ -1175,7 +1180,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
 
     // ---- phase C: per-group epilogues
     if (is_char) {
-        if (what & PARC_POST_OBS) {
+        if ((what & PARC_POST_OBS) && live) {
             // compute_char_obs  envs/ig_char_env.py:582-626 (global_obs False, no root height)
             if (b == 0) {
                 quat_to_tan_norm(quat_mul(hinv, c_rot), row);
@@ -1194,7 +1199,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             }
         }
     } else if (is_tar) {
-        if (what & PARC_POST_OBS) {
+        if ((what & PARC_POST_OBS) && live) {
             // DeepMimicEnv.compute_tar_obs + compute_tar_obs  dm_env.py:686-718, mgdm_dm_util.py:462-519
             const int s = s_idx;
             float *o = row + Wc + s * Wt;
@@ -1266,7 +1271,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             }
         }
     }
-      if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) __syncthreads();   // B1 (reference wave's arrival)
         if (what & (PARC_POST_REF | PARC_POST_REWARD_DONE)) {
             if (what & PARC_POST_REWARD_DONE) {
                 // compute_deepmimic_reward  mgdm_dm_util.py:327-390 (track_root, track_root_h)
@@ -1276,8 +1280,9 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 const v3 sim_root = shfl16(sim_pos, 0);          // body 0 is the root
                 const v3 sim_f = ld3(rbuf.contact_forces + ((size_t)e * B + (valid ? b : 0)) * 3);
                 if (valid && b > 0) {
-                    const float4 cq = *reinterpret_cast<const float4 *>(cjq[le][b]);    // from the character wave (before B1)
-                    q4 cj = mk4(cq.x, cq.y, cq.z, cq.w);
+                    // the simulated character's joint rotation (K1), computed here too: taking it from the character wave would need a
+                    // second barrier, and with it every wave of the workgroup would wait for the slowest one
+                    const q4 cj = joint_dof_to_rot(m, b, dofs, 2);
                     float da = quat_diff_angle(cj, rq);
                     pose_e = rcfg.joint_err_w[b - 1] * da * da;
                 }
@@ -1393,60 +1398,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             }
         }
         return;
-    }
-    const int nthr = blockDim.x - 64;               // all waves but the reference wave
-    const int tid2 = is_char ? (int)threadIdx.x : (int)threadIdx.x - 64;
-    if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) __syncthreads();   // B1: all observation columns and cjq are in LDS
-    if (what & PARC_POST_OBS) {
-        const int tid = tid2;
-        int out_len = row_len;
-        if (do_hf) out_len = cfg.obs_dim;
-        const int nlive = min(POST_EPB, n_total - (int)blockIdx.x * POST_EPB);
-        if (!env_ids && !masked && out_len == RS) {
-            // consecutive envs, whole rows: the LDS image IS the output image
-            float4 *dst = reinterpret_cast<float4 *>(buf.obs + (size_t)blockIdx.x * POST_EPB * RS);
-            const float4 *src = reinterpret_cast<const float4 *>(rows);
-            const int tot4 = nlive * (RS >> 2);
-#pragma unroll 1
-            for (int i = tid; i < tot4; i += nthr) dst[i] = src[i];
-        } else {
-            // subset of envs and/or rows without the heightmap columns: walk the (env, float4) pairs
-            const int n4 = out_len >> 2;
-            size_t rowoff[POST_EPB];
-            bool rowlive[POST_EPB];
-#pragma unroll
-            for (int l2 = 0; l2 < POST_EPB; ++l2) {
-                int el2 = min((int)blockIdx.x * POST_EPB + l2, n_total - 1);
-                rowoff[l2] = (size_t)(env_ids ? (int)env_ids[el2] : el2) * RS;
-                rowlive[l2] = !masked || buf.env_mask[el2] != 0;
-            }
-            int l2 = 0, i = tid;
-#pragma unroll 1
-            for (;;) {
-#pragma unroll 1
-                while (i >= n4) {
-                    i -= n4;
-                    ++l2;
-                }
-                if (l2 >= nlive) break;
-                size_t ro = rowoff[0];
-                bool rl = rowlive[0];
-#pragma unroll
-                for (int k = 1; k < POST_EPB; ++k) {
-                    ro = l2 == k ? rowoff[k] : ro;
-                    rl = l2 == k ? rowlive[k] : rl;
-                }
-                if (rl)
-                    reinterpret_cast<float4 *>(buf.obs + ro)[i] = reinterpret_cast<const float4 *>(rows + l2 * RS)[i];
-                i += nthr;
-            }
-            const int tl = out_len & 3;     // only without the fused heightmap columns
-            if (tid < tl) {
-#pragma unroll
-                for (int k = 0; k < POST_EPB; ++k)
-                    if (k < nlive && rowlive[k]) buf.obs[rowoff[k] + 4 * n4 + tid] = rows[k * RS + 4 * n4 + tid];
-            }
-        }
     }
 }
 

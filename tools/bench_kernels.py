@@ -102,15 +102,42 @@ def bench_post_step(n, iters, workload="boxes_64clips"):
     abl = [int(a.split("=")[1], 0) for a in sys.argv if a.startswith("--ablate=")]
     if abl:                      # PMC runs of one role ablation: every launch of the process uses it
         full |= abl[0]
+    def graph_us(flags, n=200):
+        """us per launch of n launches captured in ONE hipGraph and replayed (best of 3): the product's launch mode, and the only
+        meaningful one for the cheap variants - an eager loop of this kernel is host-bound at ~8 us per launch (ctypes call with 2 KB
+        of by-value structs), whatever the kernel does"""
+        for _ in range(3):
+            core.post_step(flags)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+            for _ in range(n):
+                core.post_step(flags)
+        gr.replay()
+        torch.cuda.synchronize()
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(3):
+            s_.record()
+            gr.replay()
+            e_.record()
+            torch.cuda.synchronize()
+            best = min(best, s_.elapsed_time(e_) * 1e3 / n)
+        return best
     us_fused = time_loop(lambda: core.post_step(full), iters)
-    us_nohf = time_loop(lambda: core.post_step(full & ~_hip.POST_HF), iters)
-    for name, bits in () if "--plain" in sys.argv else (("no_tar", 0x10000), ("no_ref", 0x20000), ("no_char", 0x40000), ("only_char", 0x30000), ("only_ref", 0x50000), ("only_tar", 0x60000), ("none", 0x70000)):
-        print(json.dumps({"ablation": name, "us": time_loop(lambda: core.post_step(full | bits), iters)}))
+    us_graph = graph_us(full)
+    us_nohf = graph_us(full & ~_hip.POST_HF)
+    # timing diagnostics (bits of `what` the kernel honours for this purpose only): 0x10000 / 0x20000 / 0x40000 drop the target /
+    # reference / character waves after the barrier, 0x100000 returns at entry, 0x200000 returns in front of the barrier
+    for name, bits in () if "--plain" in sys.argv else (("launch_only", 0x100000), ("up_to_the_barrier", 0x200000), ("none", 0x70000), ("only_char", 0x30000),
+                                                         ("only_ref", 0x50000), ("only_tar", 0x60000), ("no_tar", 0x10000), ("no_ref", 0x20000), ("no_char", 0x40000)):
+        print(json.dumps({"ablation": name, "us_graph_replay": round(graph_us(full | bits), 2)}))
     # algorithmic bytes per env (SURVEY.md 8d): K5 3544 + K3 7*760 + state 456 + obs cols [0,871) 3484 + bodies 780 + 8 out
     alg = n * (3544 + 7 * 760 + 456 + 3484 + 780 + 8)
     print(json.dumps({"kernel": "track_post_kernel(fused hf)", "workload": workload, "clips": M, "hf_cells": list(hf.shape),
-                      "clip_row_bytes": int(sum(c["frames"].shape[0] for c in clips)) * 448, "envs": n, "us_per_launch": us_fused, "algorithmic_bytes": alg,
-                      "GBps": alg / us_fused / 1e3, "us_without_hf": us_nohf, "mean_reward": core.reward.mean().item(),
+                      "clip_row_bytes": int(sum(c["frames"].shape[0] for c in clips)) * 448, "envs": n, "us_per_launch_eager_back_to_back": us_fused,
+                      "us_per_launch": us_graph, "algorithmic_bytes": alg, "GBps": alg / us_graph / 1e3, "frac_of_8TBps": alg / us_graph / 1e3 / 8000.0,
+                      "us_without_hf": us_nohf, "mean_reward": core.reward.mean().item(),
                       "done_frac": (core.done != 0).float().mean().item()}))
 
 
