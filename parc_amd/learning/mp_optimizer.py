@@ -24,7 +24,10 @@ class MPOptimizer:
         wd = float(config.get("weight_decay", 0.0))
         # one multi-tensor launch per step where torch offers it (device parameters): same update rule, 1 kernel instead of 3
         fused = {"fused": True} if (param_list[0].is_cuda and config.get("fused_optimizer", True)) else {}
-        if config["type"] == "SGD":
+        will_be_flat = (config["type"] == "SGD" and param_list[0].is_cuda and param_list[0].dtype == torch.float32 and bool(config.get("flat_sgd", True)))
+        if will_be_flat:
+            self._optimizer = None            # the flat SGD step below replaces it: no torch optimizer object that is never stepped
+        elif config["type"] == "SGD":
             self._optimizer = torch.optim.SGD(param_list, lr, momentum=0.9, weight_decay=wd, **fused)
         elif config["type"] == "Adam":
             self._optimizer = torch.optim.AdamW(param_list, lr, weight_decay=wd, **fused)
@@ -173,7 +176,27 @@ class MPOptimizer:
         else:
             self._optimizer.state.clear()
 
+    CHECK_ALIAS_STEPS = 200
+
+    def _check_aliasing(self):
+        """Every parameter and its gradient must still BE the slice of the flat buffers they were bound to at construction: the flat
+        SGD step (and the in-place gradient exchange) update the flat buffers only, so anything that rebinds `p.data` / `p.grad`
+        afterwards - load_state_dict(assign=True), module.to() / .float() onto another device or dtype, zero_grad(set_to_none=True) -
+        would leave the model reading tensors that training no longer updates, silently.  Pointer compares only: no device work."""
+        off = 0
+        for p in self._param_list:
+            nb = p.element_size()
+            if self._flat_sgd and p.data_ptr() != self._flat_param.data_ptr() + off * nb:
+                raise RuntimeError("a parameter of shape {} no longer aliases the optimizer's flat parameter buffer (something rebound "
+                                   "p.data after the optimizer was built): rebuild the MPOptimizer".format(tuple(p.shape)))
+            if p.grad is None or p.grad.data_ptr() != self._flat_grad.data_ptr() + off * nb:
+                raise RuntimeError("the gradient of a parameter of shape {} no longer aliases the flat gradient buffer (e.g. "
+                                   "zero_grad(set_to_none=True) was called on the model): rebuild the MPOptimizer".format(tuple(p.shape)))
+            off += p.numel()
+
     def _finish_step(self, **kwargs):
+        if self._steps % self.CHECK_ALIAS_STEPS == 0:
+            self._check_aliasing()
         if self._flat_sgd:
             from .. import _hip
             max_norm = float(kwargs["max_norm"]) if "model" in kwargs else -1.0

@@ -687,3 +687,78 @@ def test_clipped_norm_scale_matches_torch_expression():
         nrm = torch.linalg.vector_norm(x).reshape(1)
         _hip.check(_hip.lib().parc_scale_by_clipped_norm(_hip.stream(), x.numel(), _hip.ptr(x), _hip.ptr(nrm), 1.0), "scale")
         assert torch.equal(x, ref)
+
+
+def test_config0_motion_lib_and_fk_batch_at_its_full_size(km, oracle):
+    """BASELINE.json configs[0] at the size SURVEY section 8(d) row 1 gives it: 64 clips = the authors' civilization clip (254 frames)
+    under a per-clip yaw and translation, MotionLib + forward kinematics on 64 x 254 grid queries (every frame time of every clip)
+    plus 28 672 random ones with times up to 1.1 clip lengths (past the end: clamped).  HIP calc_motion_frame + forward_kinematics
+    against the C oracle on all 44 928 queries, at the parity tolerance; the oracle samples the clip rows the device stored, checked
+    against its own first (see smoke_impl.adopt_device_frames for why)."""
+    import smoke_impl
+    from parc_amd.anim.motion_lib import MotionLib
+    z = golden("g3_motion")
+    fr0, con0 = z["frames_0"].astype(np.float32), z["contacts_0"].astype(np.float32)
+    assert fr0.shape == (254, 34)
+    rng = np.random.default_rng(80)
+
+    def em_to_q(e):
+        a = np.linalg.norm(e, axis=-1, keepdims=True)
+        ax = np.where(a > 1e-8, e / np.maximum(a, 1e-8), np.array([0.0, 0.0, 1.0]))
+        return np.concatenate([ax * np.sin(a / 2), np.cos(a / 2)], -1)
+
+    def q_to_em(q):
+        q = np.where(q[..., 3:4] < 0, -q, q)
+        n = np.linalg.norm(q[..., :3], axis=-1, keepdims=True)
+        ang = 2 * np.arctan2(n, q[..., 3:4])
+        return np.where(n > 1e-8, q[..., :3] / np.maximum(n, 1e-8) * ang, 0.0)
+
+    def q_mul(a, b):
+        x1, y1, z1, w1 = [a[..., i] for i in range(4)]
+        x2, y2, z2, w2 = [b[..., i] for i in range(4)]
+        return np.stack([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                         w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2], -1)
+    clips = []
+    for k in range(64):
+        yaw = rng.random() * 2 * np.pi
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        f = fr0.astype(np.float64).copy()
+        xy = f[:, 0:2].copy()
+        f[:, 0] = c * xy[:, 0] - s_ * xy[:, 1] + rng.normal() * 3.0
+        f[:, 1] = s_ * xy[:, 0] + c * xy[:, 1] + rng.normal() * 3.0
+        qy = np.array([0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2)])
+        f[:, 3:6] = q_to_em(q_mul(np.broadcast_to(qy, (254, 4)), em_to_q(f[:, 3:6])))
+        clips.append(dict(frames=f.astype(np.float32), contacts=con0, fps=30.0, loop=0, weight=1.0, name="civ_%02d" % k))
+    ml = MotionLib(clips, km, DEV, init_type="clips", contact_info=True)
+    ids = np.concatenate([np.repeat(np.arange(64), 254), rng.integers(0, 64, 28672)]).astype(np.int64)
+    length = 253.0 / 30.0
+    times = np.concatenate([np.tile(np.arange(254) / 30.0, 64), rng.random(28672) * 1.1 * length]).astype(np.float32)
+    assert ids.shape == (44928,)
+    rp, rr, rv, rav, jr, dv, con = ml.calc_motion_frame(T(ids, torch.int64), T(times))
+    bp, br = km.forward_kinematics(rp, rr, jr)
+    torch.cuda.synchronize()
+    # ---- oracle
+    full = lambda t: t.detach().cpu().numpy()
+    char = oracle.Char(full(km._parent_indices), full(km._local_translation), full(km._local_rotation), [j.joint_type.value for j in km._joints],
+                       [full(j.axis) if j.axis is not None else np.zeros(3, np.float32) for j in km._joints], [j.dof_idx for j in km._joints])
+    om = oracle.MotionLib(char, [c_["frames"] for c_ in clips], [30.0] * 64, [0] * 64, [1.0] * 64, [c_["contacts"] for c_ in clips])
+    om.fps_max = 30.0
+    st = {}
+    smoke_impl.adopt_device_frames(om, ml, st)
+    assert st["stored_frames_device_vs_oracle"]["root_rot"]["max_abs_diff"] <= 5e-7
+    o = om.calc_motion_frame(ids, times)
+    obp, obr = oracle.forward_kinematics(char, o["root_pos"], o["root_rot"], o["joint_rot"])
+    close(rp, o["root_pos"], atol=2e-5)
+    close(rr, o["root_rot"], atol=2e-5)
+    close(jr, o["joint_rot"], atol=2e-5)
+    close(rv, o["root_vel"], atol=0, rtol=0)
+    close(rav, o["root_ang_vel"], atol=0, rtol=0)
+    close(dv, o["dof_vel"], atol=0, rtol=0)
+    close(con, o["contacts"], atol=2e-5)                    # the blend weight carries the rounding of time / length x (frames - 1)
+    close(bp, obp, atol=5e-5)
+    close(br, obr, atol=2e-5)
+    # queries past the end of a clamped clip sit on its last frame
+    past = times > length
+    assert past.sum() > 1000
+    last = np.stack([c_["frames"][-1, 0:3] for c_ in clips])[ids[past]]
+    close(rp[T(past, torch.bool)], last, atol=1e-6)

@@ -282,3 +282,30 @@ def test_flat_sgd_step_equals_torch_sgd_with_clipping():
     sd = mine.state_dict()                                        # parameters are views of the flat buffer: state_dict round trip
     mine.load_state_dict({k: v.clone() + 1.0 for k, v in sd.items()})
     assert torch.allclose(opt._flat_param, torch.cat([p.reshape(-1) for p in mine.parameters()]))
+
+
+def test_flat_sgd_notices_a_rebound_parameter():
+    """The flat SGD step updates the flat parameter / momentum buffers only; every nn.Parameter is a view into them.  Anything that
+    rebinds p.data or p.grad afterwards (load_state_dict(assign=True), module.float() / .to(), zero_grad(set_to_none=True)) would leave
+    the model reading tensors training no longer updates: MPOptimizer checks the aliasing (pointer compares) every CHECK_ALIAS_STEPS
+    steps and raises.  No torch optimizer object is built in this mode (round-2 advisor finding)."""
+    from parc_amd.learning import mp_optimizer
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2)).to(DEV)
+    opt = mp_optimizer.MPOptimizer({"type": "SGD", "learning_rate": 0.1}, list(m.parameters()))
+    assert opt._flat_sgd and opt._optimizer is None
+    opt.CHECK_ALIAS_STEPS = 1
+    x = torch.randn(5, 8, device=DEV)
+    w0 = m[0].weight.detach().clone()
+    opt.step(torch.mean(torch.square(m(x))))
+    assert not torch.equal(w0, m[0].weight)                   # the view moved with the flat buffer
+    opt._check_aliasing()
+    m[0].weight.data = m[0].weight.data.clone()               # what load_state_dict(assign=True) / .to() would do
+    with pytest.raises(RuntimeError, match="no longer aliases the optimizer's flat parameter buffer"):
+        opt.step(torch.mean(torch.square(m(x))))
+    m2 = torch.nn.Linear(4, 4).to(DEV)
+    opt2 = mp_optimizer.MPOptimizer({"type": "SGD", "learning_rate": 0.1}, list(m2.parameters()))
+    opt2.CHECK_ALIAS_STEPS = 1
+    m2.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match="no longer aliases the flat gradient buffer"):
+        opt2._check_aliasing()
