@@ -267,7 +267,7 @@ def main():
     # separate passes, gfx950-corrected; SQ_INSTS_VALU), committed under profiles/: counters cannot be read from inside this process, so
     # these two are PROFILE CONSTANTS valid for exactly this workload and env count (null otherwise), and are labelled as such.
     def committed_profile(workload, what):
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             for name in ("{}_post_step_{}_{}.json".format(rnd, workload, what), "{}_post_step_{}.json".format(rnd, what)):
                 pth = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(pth) and (workload in name or workload == "boxes_64clips"):
@@ -334,7 +334,11 @@ def main():
                                                                c.cfg.obs_dim), 200 if nn == N else 50)
             byts = nn * 3544
             extra.append({"kernel": "hf_gather_kernel (K5 alone)", "envs": nn, "us_per_launch": us, "bound": "hbm", "algorithmic_bytes": byts,
-                          "achieved_GBps": byts / us / 1e3, "frac_of_peak": byts / us / 1e3 / HBM_PEAK_GBPS})
+                          "achieved_GBps": byts / us / 1e3, "frac_of_peak": byts / us / 1e3 / HBM_PEAK_GBPS,
+                          "note": ("the north-star's >= 40 % of HBM peak on the heightmap gather is NOT met by the standalone kernel at this env "
+                                   "count (a 14.5 MB launch is launch-bound: the same grid without gathers or stores takes 2.8 us); the product "
+                                   "never launches K5 alone - it runs inside track_post_kernel, the roofline object above") if nn == N else
+                                  "the standalone kernel where the launch is large enough to be bandwidth-bound"})
             del obs_big, rs_big, eo_big
         # the same fused kernel where its inputs do NOT sit in L2: the iter-0 stand-in of BASELINE configs[3] (1024 clips = 83 MB of clip
         # rows, 1504^2 heightfield = 9 MB), every env on its own clip / tile
@@ -402,7 +406,9 @@ def main():
                                         "and heightfield of this workload sit in L2, so the HBM-side traffic is lower",
                          "traffic_source": (traffic_src + " (committed profile, not measured in this run)") if traffic else None,
                          "frac_measured_traffic": (traffic / (kern_graph_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         "binding_roofline": "VALU issue (see valu.frac_of_valu_issue_peak); HBM by SURVEY's classification",
+                         "binding_roofline": "HBM by SURVEY's classification; measured: neither HBM (frac_measured_traffic) nor vector issue "
+                                             "(valu.frac_of_valu_issue_peak) is saturated - the launch is bound by its dependent chains at 8 waves "
+                                             "per SIMD and 64 VGPRs (DESIGN.md section 3, profiles/r03_post_step_attempts.txt)",
                          "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": kern_graph_us, "us_per_launch_eager_back_to_back": kern_b2b_us,
                          "us_per_launch_event_pairs_in_rollout_loop": kern_us, "launches_event_timed": len(evs), "valu": valu},
             "rollout": ("one hipGraph replay per env step" + (", finished envs reset on the device inside the graph" if any(k[2] for k in agent._graphs)
