@@ -89,6 +89,14 @@ def launch_ranks(args):
     backend = os.environ.get("PARC_DIST_BACKEND", "nccl")
     from parc_amd.util import mp_util
     n_dev = mp_util.visible_device_count()
+    if 0 < n_dev < args.gpus:
+        # sysfs says "fewer than asked for": before refusing, let a CHILD ask the runtime (this process stays free of HIP); the larger
+        # answer counts - a wrong refusal would be worse than a late one (the ranks check again themselves)
+        try:
+            out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+            n_dev = max(n_dev, int(out.stdout.strip().splitlines()[-1]))
+        except Exception:       # noqa: BLE001
+            pass
     if backend == "nccl" and not args.launch_check and 0 < n_dev < args.gpus:
         sys.stderr.write("bench.py: --gpus {} needs {} visible GPUs, found {} (refusing to report a {}-GPU number from fewer)\n".format(
             args.gpus, args.gpus, n_dev, args.gpus))
