@@ -238,7 +238,8 @@ def main():
     evs = env._core.timing_events
     env._core.timing_events = None
     kern_us = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3 if evs else float("nan")
-    full = _hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS      # the product step's flags
+    # the product step's flags (the reference STATE is published by the step's tail launch, parc_step_tail, since round 3)
+    full = _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS
     for _ in range(10):
         env._core.post_step(full)
     torch.cuda.synchronize()

@@ -243,6 +243,9 @@ int parc_motion_lib_build(void *stream, parc_char_model_t model, parc_motion_lib
  * global plan clock, mgdm_env.py:476-480 - not env time + offset), and no end-of-clip termination (DeepMimicEnv.update_done's rule
  * dm_env.py:746-783 does not apply; the sub-env's termination is RefCharEnv.update_done, mgdm_dm_util.py:205-230). */
 #define PARC_POST_PLAN_CLOCK 128
+/* Two kernels since round 3: bit0 (the reference STATE: ref_* buffers, bit5's character state) is `ref_state_kernel`, enqueued first;
+ * bits 1-3 / 6 the fused `track_post_kernel`, whose reward wave samples the reference pose itself.  They write disjoint outputs and
+ * read nothing of each other.  A call with bit0 only (a restart's first launch) enqueues the small kernel alone. */
 int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
                          parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
                          const float *ray_xy);
@@ -270,6 +273,12 @@ int parc_reset_sample_apply(void *stream, int n_envs, const int32_t *done_flags,
 
 /* DeepMimicEnv.update_done's per-done-env Python loop (dm_env.py:758-772): EMA of per-clip failure rates,
  * applied in increasing env order exactly as the reference's loop does. */
+/* The tail of an env step in one launch of heterogeneous workgroups: the fail-rate update above (one workgroup per clip) and, with
+ * what = PARC_POST_REF (| PARC_POST_PLAN_CLOCK), the per-step publication of the reference state - ref_* buffers of `buf`,
+ * DeepMimicEnv._update_ref_motion dm_env.py:570-595 - by further workgroups that run on the CUs the fail-rate walk leaves idle.  A
+ * caller that uses it leaves PARC_POST_REF out of the parc_track_post_step of that step. */
+int parc_step_tail(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_env_buffers_t buf, int what, int n_motions,
+                   const int32_t *done_kind, float ema_w, float *fail_rates);
 int parc_update_fail_rates(void *stream, int n_envs, int n_motions, const int64_t *motion_ids, const int32_t *done_kind,
                            float ema_w, float *fail_rates);
 

@@ -192,6 +192,8 @@ def _declare(L):
     L.parc_motion_lib_build.argtypes = [c_vp, CharModelS, MotionLibS, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
     L.parc_track_post_step.argtypes = [c_vp, CharModelS, MotionLibS, TerrainS, TrackCfgS, EnvBuffersS, c_vp, c_int, c_int, c_vp]
     L.parc_update_fail_rates.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_vp]
+    L.parc_step_tail.argtypes = [c_vp, CharModelS, MotionLibS, EnvBuffersS, c_int, c_int, c_vp, c_f, c_vp]
+    L.parc_step_tail.restype = c_int
     L.parc_td_lambda_return.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_f, c_f, c_vp]
     L.parc_adv_normalize.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp]
     L.parc_ppo_loss.argtypes = [c_vp, c_int, c_int] + [c_vp] * 8 + [PPOCfgS] + [c_vp] * 5
@@ -249,7 +251,7 @@ EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hf
             "parc_action_head", "parc_points_hf_sdf", "parc_moments_workspace_floats", "parc_moments_accumulate", "parc_reset_sample_apply", "parc_return_tracker_workspace_floats", "parc_scale_by_clipped_norm", "parc_relu_bwd_workspace_floats",
             "parc_relu_bwd_bias_grad", "parc_ppo_loss_packed", "parc_weighted_colsum", "parc_sgd_workspace_floats", "parc_sgd_momentum_step",
             "parc_pose_chain_forward", "parc_pose_chain_backward", "parc_points_hf_sdf_grad", "parc_body_points_world", "parc_body_points_world_grad",
-            "parc_quat_diff_angle", "parc_quat_diff_angle_grad", "parc_temporal_terms", "parc_temporal_terms_grad"]
+            "parc_quat_diff_angle", "parc_quat_diff_angle_grad", "parc_temporal_terms", "parc_temporal_terms_grad", "parc_step_tail"]
 
 
 def check(rc, what):

@@ -1124,6 +1124,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     __syncthreads();
     // diagnostic role ablations (timing only): bits 16/17/18 drop the target / reference / character waves
     if (((what & 0x10000) && is_tar) || ((what & 0x20000) && is_ref) || ((what & 0x40000) && is_char)) return;
+    if (is_ref && !(what & PARC_POST_REWARD_DONE)) return;      // the reference wave computes reward / termination; the reference STATE is ref_state_group's
 
     const int e = __float_as_int(envd[le][11]);
     const float *dofs = buf.dof_state + (size_t)e * D * 2;  // interleaved pos,vel
@@ -1233,43 +1234,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         r_contact = valid ? lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend) : 0.f;
         r_vel = ld3(fq.row0 + ml.off_root_vel);
         r_avel = ld3(fq.row0 + ml.off_root_ang_vel);
-        if ((what & PARC_POST_REF) && live) {
-            if (b == 0) {
-                st3(rbuf.ref_root_pos + 3 * (size_t)e, r_pos);
-                st4(rbuf.ref_root_rot + 4 * (size_t)e, r_rot);
-                st3(rbuf.ref_root_vel + 3 * (size_t)e, r_vel);
-                st3(rbuf.ref_root_ang_vel + 3 * (size_t)e, r_avel);
-            } else if (valid) {
-                st4(rbuf.ref_joint_rot + ((size_t)e * J + (b - 1)) * 4, rq);
-                joint_rot_to_dof(m, b, rq, rbuf.ref_dof_pos + (size_t)e * D);      // K4
-            }
-            if (valid) {
-                rbuf.ref_contacts[(size_t)e * B + b] = r_contact;
-                st3(rbuf.ref_body_pos + ((size_t)e * B + b) * 3, pos);
-            }
-#pragma unroll 1
-            for (int d = b; d < D; d += GRP) rbuf.ref_dof_vel[(size_t)e * D + d] = fq.row0[ml.off_dof_vel + d];
-            if (what & PARC_POST_INIT_CHAR) {
-                // RefCharEnv._char_state_init_from_ref + add_noise_to_char_state  mgdm_dm_util.py:119-136
-                float *wrs = const_cast<float *>(rbuf.root_state) + (size_t)e * 13;
-                float *wds = const_cast<float *>(rbuf.dof_state) + (size_t)e * D * 2;
-                if (b == 0) {
-                    v3 ip = r_pos;
-                    if (rbuf.init_noise_xy) {
-                        ip.x += rbuf.init_noise_xy[2 * e];
-                        ip.y += rbuf.init_noise_xy[2 * e + 1];
-                    }
-                    st3(wrs, ip);
-                    st4(wrs + 3, r_rot);
-                    st3(wrs + 7, r_vel);
-                    st3(wrs + 10, r_avel);
-                } else if (valid) {
-                    joint_rot_to_dof(m, b, rq, rbuf.ref_dof_pos + (size_t)e * D, wds);
-                }
-#pragma unroll 1
-                for (int d = b; d < D; d += GRP) wds[2 * d + 1] = fq.row0[ml.off_dof_vel + d];
-            }
-        }
     }
         if (what & (PARC_POST_REF | PARC_POST_REWARD_DONE)) {
             if (what & PARC_POST_REWARD_DONE) {
@@ -1401,6 +1365,84 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     }
 }
 
+// =============================================================================================
+// The reference STATE of one env: DeepMimicEnv._update_ref_motion (dm_env.py:570-595: ref_* buffers, K3 + K2 + K4 at the clip time) and,
+// for a restart, the character state initialised from it (RefCharEnv._char_state_init_from_ref + add_noise_to_char_state,
+// mgdm_dm_util.py:119-136), by one 16-lane group (lane b = body b).
+// Until round 3 this was the first half of the reference wave of track_post_kernel, in front of the reward: the tail every launch
+// waited for (full launch 16.5 us, without these stores 15.1 us).  Nothing in a step reads what it writes - the reward wave samples the
+// pose itself - so it left the fused kernel: ref_state_kernel runs it alone (a restart's first launch is this small kernel instead of
+// the 8-wave one), and in the rollout step it rides as extra workgroups of the fail-rate launch (step_tail_kernel), whose 64 workgroups
+// leave almost the whole chip idle for the 10 us their serial walk takes.
+// =============================================================================================
+PARC_DEV void ref_state_group(const parc_char_model_t &m, const parc_motion_lib_t &ml, const parc_env_buffers_t &buf, const int64_t *env_ids,
+                              int n_total, int what, int el, int b) {
+    const bool masked = (what & PARC_POST_MASKED) != 0;
+    const int elc = min(el, n_total - 1);
+    const bool live = el < n_total && (!masked || buf.env_mask[elc] != 0);
+    if (masked && !__any(live)) return;                         // wave-uniform: nothing flagged among this wave's 4 envs
+    const int e = env_ids ? (int)env_ids[elc] : elc;
+    const int B = m.num_bodies, J = B - 1, D = m.dof_size;
+    const bool valid = b < B;
+    const int64_t mid = buf.motion_ids[e];
+    // dataset clips: env time + the clip time the episode started at; generated plans: the plan clock itself (see track_post_kernel)
+    const float mtime = (what & PARC_POST_PLAN_CLOCK) ? buf.motion_time_offsets[e] : buf.time_buf[e] + buf.motion_time_offsets[e];
+    const frame_query fq = make_query(ml, mid, mtime);
+    q4 rq = mk4(0.f, 0.f, 0.f, 1.f);
+    if (valid) rq = query_quat(fq, b);
+    // root position in the reference's order: lerp, + loop shift, + tile offset (query_root_pos, dm_env.py:604-615)
+    v3 r_pos = query_root_pos(ml, fq, mid);
+    r_pos.x += buf.motion_xy_offset[2 * e] - buf.env_offsets[3 * e];
+    r_pos.y += buf.motion_xy_offset[2 * e + 1] - buf.env_offsets[3 * e + 1];
+    const q4 r_rot = shfl16(rq, 0);
+    v3 pos;
+    q4 rot;
+    group_fk<false>(m, b, r_pos, r_rot, rq, pos, rot);
+    if (!live) return;
+    const float r_contact = valid ? lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend) : 0.f;
+    const v3 r_vel = ld3(fq.row0 + ml.off_root_vel), r_avel = ld3(fq.row0 + ml.off_root_ang_vel);
+    if (b == 0) {
+        st3(buf.ref_root_pos + 3 * (size_t)e, r_pos);
+        st4(buf.ref_root_rot + 4 * (size_t)e, r_rot);
+        st3(buf.ref_root_vel + 3 * (size_t)e, r_vel);
+        st3(buf.ref_root_ang_vel + 3 * (size_t)e, r_avel);
+    } else if (valid) {
+        st4(buf.ref_joint_rot + ((size_t)e * J + (b - 1)) * 4, rq);
+        joint_rot_to_dof(m, b, rq, buf.ref_dof_pos + (size_t)e * D);      // K4
+    }
+    if (valid) {
+        buf.ref_contacts[(size_t)e * B + b] = r_contact;
+        st3(buf.ref_body_pos + ((size_t)e * B + b) * 3, pos);
+    }
+#pragma unroll 1
+    for (int d = b; d < D; d += GRP) buf.ref_dof_vel[(size_t)e * D + d] = fq.row0[ml.off_dof_vel + d];
+    if (what & PARC_POST_INIT_CHAR) {
+        float *wrs = const_cast<float *>(buf.root_state) + (size_t)e * 13;
+        float *wds = const_cast<float *>(buf.dof_state) + (size_t)e * D * 2;
+        if (b == 0) {
+            v3 ip = r_pos;
+            if (buf.init_noise_xy) {
+                ip.x += buf.init_noise_xy[2 * e];
+                ip.y += buf.init_noise_xy[2 * e + 1];
+            }
+            st3(wrs, ip);
+            st4(wrs + 3, r_rot);
+            st3(wrs + 7, r_vel);
+            st3(wrs + 10, r_avel);
+        } else if (valid) {
+            joint_rot_to_dof(m, b, rq, buf.ref_dof_pos + (size_t)e * D, wds);
+        }
+#pragma unroll 1
+        for (int d = b; d < D; d += GRP) wds[2 * d + 1] = fq.row0[ml.off_dof_vel + d];
+    }
+}
+
+#define REF_STATE_THREADS 256      // 16 envs per workgroup
+__global__ __launch_bounds__(REF_STATE_THREADS) void ref_state_kernel(parc_char_model_t m, parc_motion_lib_t ml, parc_env_buffers_t buf,
+                                                                      const int64_t *__restrict__ env_ids, int n_total, int what) {
+    ref_state_group(m, ml, buf, env_ids, n_total, what, (int)(blockIdx.x * (REF_STATE_THREADS / GRP) + (threadIdx.x >> 4)), threadIdx.x & 15);
+}
+
 extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
                                     parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
                                     const float *ray_xy) {
@@ -1419,9 +1461,18 @@ extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_
     int n = env_ids ? n_sel : buf.num_envs;
     if (n < 0) return PARC_EINVAL;
     if (n == 0) return PARC_OK;
-    hipLaunchKernelGGL(track_post_kernel, dim3((n + POST_EPB - 1) / POST_EPB), dim3(64 * (2 + (cfg.num_tar_steps > 0 ? cfg.num_tar_steps : 0))), 0,
-                       (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, n, what, ray_xy);
-    PARC_CHECK_LAUNCH();
+    if (what & PARC_POST_REF) {
+        // the reference state is its own small kernel (a caller that also updates the fail rates can have it co-scheduled with that
+        // launch instead: parc_step_tail, and leave PARC_POST_REF out here)
+        hipLaunchKernelGGL(ref_state_kernel, dim3((n + REF_STATE_THREADS / GRP - 1) / (REF_STATE_THREADS / GRP)), dim3(REF_STATE_THREADS), 0,
+                           (hipStream_t)stream, model, mlib, buf, env_ids, n, what);
+        PARC_CHECK_LAUNCH();
+    }
+    if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) {
+        hipLaunchKernelGGL(track_post_kernel, dim3((n + POST_EPB - 1) / POST_EPB), dim3(64 * (2 + (cfg.num_tar_steps > 0 ? cfg.num_tar_steps : 0))), 0,
+                           (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, n, what, ray_xy);
+        PARC_CHECK_LAUNCH();
+    }
     return PARC_OK;
 }
 
@@ -1555,10 +1606,9 @@ extern "C" int parc_reset_sample_apply(void *stream, int n_envs, const int32_t *
 // =============================================================================================
 #define FR_THREADS 256
 #define FR_MAX_PASSES 64          // up to 16384 envs per launch segment; larger counts loop over segments
-__global__ __launch_bounds__(FR_THREADS) void fail_rate_kernel(int n_envs, int n_motions, const int64_t *__restrict__ motion_ids,
-                                                               const int32_t *__restrict__ done_kind, float ema_w, float *fail_rates) {
-    __shared__ unsigned long long hit[FR_MAX_PASSES][FR_THREADS / 64], fail[FR_MAX_PASSES][FR_THREADS / 64];
-    const int mi = blockIdx.x;
+typedef unsigned long long fr_masks_t[FR_MAX_PASSES][FR_THREADS / 64];
+PARC_DEV void fail_rate_block(int mi, int n_envs, const int64_t *__restrict__ motion_ids, const int32_t *__restrict__ done_kind, float ema_w,
+                              float *fail_rates, fr_masks_t &hit, fr_masks_t &fail) {
     const int wv = threadIdx.x >> 6;
     const float keep = (float)(1.0 - (double)ema_w);       // the reference multiplies by the python double (1.0 - w), cast to fp32
     float fr = 0.f;
@@ -1603,6 +1653,41 @@ __global__ __launch_bounds__(FR_THREADS) void fail_rate_kernel(int n_envs, int n
         __syncthreads();
     }
     if (threadIdx.x == 0 && touched) fail_rates[mi] = fr;
+}
+
+__global__ __launch_bounds__(FR_THREADS) void fail_rate_kernel(int n_envs, int n_motions, const int64_t *__restrict__ motion_ids,
+                                                               const int32_t *__restrict__ done_kind, float ema_w, float *fail_rates) {
+    __shared__ fr_masks_t hit, fail;
+    fail_rate_block(blockIdx.x, n_envs, motion_ids, done_kind, ema_w, fail_rates, hit, fail);
+}
+
+// The tail of an env step in ONE launch of heterogeneous workgroups: blocks [0, n_motions) walk the fail-rate EMA of one clip each
+// (64 workgroups that keep the chip almost idle for the ~10 us the bit-exact serial walk takes), blocks behind them publish the
+// reference STATE of 16 envs each (ref_state_group) on the idle CUs.  Both only read what the fused launch and the simulator left.
+static_assert(FR_THREADS == REF_STATE_THREADS, "one block size for both kinds of workgroup");
+__global__ __launch_bounds__(FR_THREADS) void step_tail_kernel(parc_char_model_t m, parc_motion_lib_t ml, parc_env_buffers_t buf, int n_envs, int what,
+                                                               int n_motions, const int32_t *__restrict__ done_kind, float ema_w, float *fail_rates) {
+    __shared__ fr_masks_t hit, fail;
+    if ((int)blockIdx.x < n_motions) {
+        fail_rate_block(blockIdx.x, n_envs, buf.motion_ids, done_kind, ema_w, fail_rates, hit, fail);
+        return;
+    }
+    const int blk = (int)blockIdx.x - n_motions;
+    ref_state_group(m, ml, buf, nullptr, n_envs, what, blk * (REF_STATE_THREADS / GRP) + (int)(threadIdx.x >> 4), threadIdx.x & 15);
+}
+
+extern "C" int parc_step_tail(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_env_buffers_t buf, int what, int n_motions,
+                              const int32_t *done_kind, float ema_w, float *fail_rates) {
+    if (!model_ok(model) || mlib.num_bodies != model.num_bodies || mlib.dof_size != model.dof_size) return PARC_EINVAL;
+    if (n_motions != mlib.num_motions || !done_kind || !fail_rates || buf.num_envs < 0) return PARC_EINVAL;
+    if (what & ~(PARC_POST_REF | PARC_POST_PLAN_CLOCK)) return PARC_EINVAL;      // the per-step publication only (no restart variants)
+    const int n = buf.num_envs;
+    if (n == 0) return PARC_OK;
+    const int state_blocks = (what & PARC_POST_REF) ? (n + REF_STATE_THREADS / GRP - 1) / (REF_STATE_THREADS / GRP) : 0;
+    hipLaunchKernelGGL(step_tail_kernel, dim3(n_motions + state_blocks), dim3(FR_THREADS), 0, (hipStream_t)stream, model, mlib, buf, n, what, n_motions,
+                       done_kind, ema_w, fail_rates);
+    PARC_CHECK_LAUNCH();
+    return PARC_OK;
 }
 
 extern "C" int parc_update_fail_rates(void *stream, int n_envs, int n_motions, const int64_t *motion_ids, const int32_t *done_kind,

@@ -512,8 +512,9 @@ class IGParkourEnv(base_env.BaseEnv):
         # _update_misc (incl. the xy target resample) / _update_observations / _update_reward / _update_done in one launch
         c.rand_pool.uniform_()          # all uniforms of this step and of the restarts that follow it (tracker_core.rand_pool)
         c.rand_pool_fresh = True
-        c.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS)
-        c.update_fail_rates(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight)
+        # (the reference STATE - ref_* buffers - rides in the fail-rate launch below: nothing in the fused launch reads it)
+        c.post_step(_hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS)
+        c.step_tail(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight)
         if self._never_done:
             self._done_buf[:] = base_env.DoneFlags.NULL.value
         self._update_info(step=True)

@@ -257,6 +257,12 @@ class TrackerCore:
             ev1.record()
             self.timing_events.append((ev0, ev1))
 
+    def step_tail(self, fail_rates, ema_w, publish_ref_state=True):
+        """fail-rate EMA of the step + (optionally) the per-step publication of the reference state, co-scheduled in one launch"""
+        _hip.check(_hip.lib().parc_step_tail(_hip.stream(), self.km.c_struct(), self.mlib.c_struct(), self.buffers(),
+                                             _hip.POST_REF if publish_ref_state else 0, self.mlib.num_motions(), _hip.ptr(self.done_kind),
+                                             float(ema_w), _hip.ptr(fail_rates)), "parc_step_tail")
+
     def update_fail_rates(self, fail_rates, ema_w):
         _hip.check(_hip.lib().parc_update_fail_rates(_hip.stream(), self.N, self.mlib.num_motions(), _hip.ptr(self.motion_ids),
                                                      _hip.ptr(self.done_kind), float(ema_w), _hip.ptr(fail_rates)),

@@ -762,3 +762,44 @@ def test_config0_motion_lib_and_fk_batch_at_its_full_size(km, oracle):
     assert past.sum() > 1000
     last = np.stack([c_["frames"][-1, 0:3] for c_ in clips])[ids[past]]
     close(rp[T(past, torch.bool)], last, atol=1e-6)
+
+
+def test_step_tail_equals_the_two_separate_launches():
+    """parc_step_tail co-schedules the per-step publication of the reference state (ref_* buffers) with the fail-rate update in one launch
+    of heterogeneous workgroups; the env's step uses it and leaves PARC_POST_REF out of the fused launch.  Same bits as the two
+    separate paths (parc_track_post_step with PARC_POST_REF -> ref_state_kernel, parc_update_fail_rates), and the fused launch without
+    PARC_POST_REF leaves the reference buffers alone while reward / termination (which sample the reference pose themselves) do not
+    change."""
+    from parc_amd import _hip, workloads
+    n = 1000                                             # not a multiple of 16: a partly filled last state workgroup
+    A, clips, _ = workloads.build_core("boxes_64clips", n, DEV, seed=6)
+    Bc, _, _ = workloads.build_core("boxes_64clips", n, DEV, seed=6)
+    g = torch.Generator().manual_seed(3)
+    fused = _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS
+    M = len(clips)
+    frA = (torch.rand(M, generator=g) * 0.5 + 0.25).to(DEV)
+    frB = frA.clone()
+    names = ("ref_root_pos", "ref_root_rot", "ref_root_vel", "ref_root_ang_vel", "ref_joint_rot", "ref_dof_pos", "ref_dof_vel", "ref_contacts",
+             "ref_body_pos")
+    for step in range(3):
+        for c in (A, Bc):
+            c.time_buf += 1.0 / 30.0
+            c.root_state[:, 0:3] += 0.01 * (step + 1)
+            if step == 1:                                 # push some envs over a termination threshold so that fail rates move
+                c.rigid_body_state.view(n, 15, 13)[::5, :, 2] += 1.0
+            c.target_rand.copy_(A.target_rand)
+        for nm in names:
+            getattr(Bc, nm).fill_(-7.0)
+        A.post_step(fused | _hip.POST_REF)
+        A.update_fail_rates(frA, 0.01)
+        Bc.post_step(fused)
+        assert all(bool((getattr(Bc, nm) == -7.0).all()) for nm in names)          # the fused launch does not touch the reference state
+        Bc.step_tail(frB, 0.01)
+        torch.cuda.synchronize()
+        for nm in names:
+            assert torch.equal(getattr(A, nm), getattr(Bc, nm)), (step, nm)
+        for nm in ("obs", "reward", "reward_terms", "done", "done_kind"):
+            assert torch.equal(getattr(A, nm), getattr(Bc, nm)), (step, nm)
+        assert torch.equal(frA, frB)
+    fr0 = (torch.rand(M, generator=torch.Generator().manual_seed(3)) * 0.5 + 0.25).to(DEV)
+    assert (A.done != 0).any() and not torch.equal(frA, fr0)                        # the scene did move the fail rates

@@ -98,10 +98,31 @@ def bench_post_step(n, iters, workload="boxes_64clips"):
     from parc_amd import workloads
     core, clips, (hf, mn, dxdy, offs) = workloads.build_core(workload, n, "cuda:0")
     M = len(clips)
-    full = _hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS      # the product step's flags
+    # the product step's flags (the reference STATE is published by the step's tail launch, parc_step_tail, since round 3)
+    full = _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS
     abl = [int(a.split("=")[1], 0) for a in sys.argv if a.startswith("--ablate=")]
     if abl:                      # PMC runs of one role ablation: every launch of the process uses it
         full |= abl[0]
+    def graph_us_fn(fn, n=200):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+            for _ in range(n):
+                fn()
+        gr.replay()
+        torch.cuda.synchronize()
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(3):
+            s_.record()
+            gr.replay()
+            e_.record()
+            torch.cuda.synchronize()
+            best = min(best, s_.elapsed_time(e_) * 1e3 / n)
+        return best
+
     def graph_us(flags, n=200):
         """us per launch of n launches captured in ONE hipGraph and replayed (best of 3): the product's launch mode, and the only
         meaningful one for the cheap variants - an eager loop of this kernel is host-bound at ~8 us per launch (ctypes call with 2 KB
@@ -132,6 +153,13 @@ def bench_post_step(n, iters, workload="boxes_64clips"):
     for name, bits in () if "--plain" in sys.argv else (("launch_only", 0x100000), ("up_to_the_barrier", 0x200000), ("none", 0x70000), ("only_char", 0x30000),
                                                          ("only_ref", 0x50000), ("only_tar", 0x60000), ("no_tar", 0x10000), ("no_ref", 0x20000), ("no_char", 0x40000)):
         print(json.dumps({"ablation": name, "us_graph_replay": round(graph_us(full | bits), 2)}))
+    # the step's tail launch: fail-rate EMA alone, and with the reference state co-scheduled
+    fr = torch.full((M,), 0.5, device="cuda:0")
+    us_fr = graph_us_fn(lambda: core.update_fail_rates(fr, 0.01))
+    us_tail = graph_us_fn(lambda: core.step_tail(fr, 0.01))
+    us_state = graph_us_fn(lambda: core.post_step(_hip.POST_REF))
+    print(json.dumps({"kernel": "step tail", "us_fail_rate_kernel_alone": round(us_fr, 2), "us_step_tail_kernel (fail rates + reference state)": round(us_tail, 2),
+                      "us_ref_state_kernel_alone": round(us_state, 2)}))
     # algorithmic bytes per env: K5 3544 + K3 7*760 + state 456 + obs cols [0,871) 3484 + bodies 780 + 8 out
     alg = n * (3544 + 7 * 760 + 456 + 3484 + 780 + 8)
     print(json.dumps({"kernel": "track_post_kernel(fused hf)", "workload": workload, "clips": M, "hf_cells": list(hf.shape),
