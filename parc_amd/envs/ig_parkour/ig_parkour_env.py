@@ -548,10 +548,8 @@ class IGParkourEnv(base_env.BaseEnv):
         if n_dm > 0:
             c.rand_pool.uniform_()
             c.rand_pool_fresh = True
-            c.post_step(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS, rows=(0, n_dm))
-            _hip.check(_hip.lib().parc_update_fail_rates(_hip.stream(), n_dm, c.mlib.num_motions(), _hip.ptr(c.motion_ids), _hip.ptr(c.done_kind),
-                                                         float(self._dm_env._ema_weight), _hip.ptr(self._dm_env._motion_id_fail_rates)),
-                       "parc_update_fail_rates")
+            c.post_step(_hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS, rows=(0, n_dm))
+            c.step_tail(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight, rows=(0, n_dm))     # fail rates + reference state
         mg._post(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF)
         mg.update_done_extra(fixed_shape=True)
         self._publish_obs()

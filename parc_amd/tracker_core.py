@@ -257,9 +257,11 @@ class TrackerCore:
             ev1.record()
             self.timing_events.append((ev0, ev1))
 
-    def step_tail(self, fail_rates, ema_w, publish_ref_state=True):
-        """fail-rate EMA of the step + (optionally) the per-step publication of the reference state, co-scheduled in one launch"""
-        _hip.check(_hip.lib().parc_step_tail(_hip.stream(), self.km.c_struct(), self.mlib.c_struct(), self.buffers(),
+    def step_tail(self, fail_rates, ema_w, publish_ref_state=True, rows=None):
+        """fail-rate EMA of the step + (optionally) the per-step publication of the reference state, co-scheduled in one launch;
+        rows=(0, n): the dataset rows of a split env (they start at row 0, so done_kind needs no offset)"""
+        assert rows is None or rows[0] == 0
+        _hip.check(_hip.lib().parc_step_tail(_hip.stream(), self.km.c_struct(), self.mlib.c_struct(), self.buffers(False, rows),
                                              _hip.POST_REF if publish_ref_state else 0, self.mlib.num_motions(), _hip.ptr(self.done_kind),
                                              float(ema_w), _hip.ptr(fail_rates)), "parc_step_tail")
 
