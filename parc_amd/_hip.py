@@ -101,7 +101,7 @@ _lib = None
 # -O2: at -O3 hipcc (ROCm 7.2, gfx950) miscompiles it (results diverge from the -O0/-O1/-O2 builds and from the g++ host build of the
 # same source; GVN scalar PRE on the unrolled 3x3 helpers).  The product's simulator kernels (parc_sim.hip) are correct at
 # every level (profiles/r02_sim_o3_bisect.txt) and are built at whichever measured faster.
-OPT_LEVEL = {"parc_kin.hip": "-O3 -fno-slp-vectorize", "parc_sim.hip": os.environ.get("PARC_SIM_OPT", "-O3"), "parc_sim_ref.hip": "-O2"}
+OPT_LEVEL = {"parc_kin.hip": os.environ.get("PARC_KIN_OPT", "-O3 -fno-slp-vectorize"), "parc_sim.hip": os.environ.get("PARC_SIM_OPT", "-O3"), "parc_sim_ref.hip": "-O2"}
 
 
 DIGEST_PATH = os.path.join(LIB_DIR, "libparc_hip.digest")

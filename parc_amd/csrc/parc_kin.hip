@@ -957,7 +957,6 @@ extern "C" int parc_pose_chain_backward(void *stream, parc_char_model_t model, i
 #define POST_EPB 4            // envs per workgroup
 #define POST_MAX_THREADS 512  // 64 * (2 + PARC_MAX_TAR_STEPS)
 #define POST_MAX_ROW 1408
-#ifndef POST_MIN_WAVES
 // Kernel arguments passed by value are loaded by the compiler in the entry block, all of them, and then live in scalar registers
 // for the whole kernel: with ~2 KB of argument structs that is far more than the 102 SGPRs a wave has, and the overflow is kept in
 // VGPR lanes (v_writelane at entry, v_readlane at every use - vector-issue slots).  kernarg_late hands out a pointer to a struct
@@ -976,6 +975,7 @@ PARC_DEV const __attribute__((address_space(4))) T *kernarg_late(size_t off) {
     return (const __attribute__((address_space(4))) T *)(p + off);
 }
 
+#ifndef POST_MIN_WAVES
 #define POST_MIN_WAVES 8   // 64 VGPRs: all 1024 workgroups of a 4096-env launch resident in one round (needs -fno-slp-vectorize: 5 spills; with SLP packing 22 spills and slower)
 #endif
 
