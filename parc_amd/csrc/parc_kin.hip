@@ -6,6 +6,18 @@
 
 #include "../../include/parc_hip.h"
 #include "parc_math.h"
+#include "parc_math_pk.h"
+
+// 4 floats moved by one 16-byte instruction from / to an address that is only 4-byte aligned (global memory takes it)
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+// The observation rows are written with the non-temporal hint: a launch ends when its last dirty line has left the XCD's L2 (the L2s
+// of the 8 XCDs are not coherent, the next kernel may read the row from another one), and 22 MB of rows held back until then were a
+// 1 us tail; streamed out as they are produced they overlap the pose arithmetic (15.8 -> 14.7 us per launch, same box).
+#ifndef POST_PLAIN_STORES
+#define POST_STORE4(p, v) __builtin_nontemporal_store((v), reinterpret_cast<f4u *>(p))
+#else
+#define POST_STORE4(p, v) (*reinterpret_cast<f4u *>(p) = (v))
+#endif
 
 #define PARC_CHECK_LAUNCH()                         \
     do {                                            \
@@ -368,6 +380,33 @@ PARC_DEV void group_fk(const parc_char_model_t &m, int b, v3 root_pos, q4 root_r
     for (int lev = 1; lev <= m.max_depth; ++lev) {
         v3 pp = shfl16(pos, par);
         q4 pr = shfl16(rot, par);
+        if (dep == lev) {
+            pos = pp + quat_rotate(pr, lt);
+            if (LEAF_ROT || lev < m.max_depth) rot = quat_mul(pr, lq);
+        }
+    }
+}
+
+// ---- the same on two poses per lane (parc_math_pk.h): the cross-lane moves are per component, the arithmetic is packed
+PARC_DEV f2 shfl16(f2 v, int src) { return f2{shfl16(v.x, src), shfl16(v.y, src)}; }
+PARC_DEV q4p shfl16(q4p q, int src) { return q4p{shfl16(q.x, src), shfl16(q.y, src), shfl16(q.z, src), shfl16(q.w, src)}; }
+PARC_DEV v3p shfl16(v3p v, int src) { return v3p{shfl16(v.x, src), shfl16(v.y, src), shfl16(v.z, src)}; }
+template <bool LEAF_ROT = true>
+PARC_DEV void group_fk(const parc_char_model_t &m, int b, v3p root_pos, q4p root_rot, q4p jq, v3p &pos, q4p &rot) {
+    const bool valid = b < m.num_bodies;
+    const int par = (valid && b > 0) ? m.parent[b] : 0;
+    const int dep = valid ? m.depth[b] : -1;
+    q4p lq = sp4(mk4(0.f, 0.f, 0.f, 1.f));
+    v3p lt = sp3(mk3(0.f, 0.f, 0.f));
+    if (valid && b > 0) {
+        lq = quat_mul(sp4(ld4(m.local_rotation[b])), jq);
+        lt = sp3(ld3(m.local_translation[b]));
+    }
+    pos = root_pos;
+    rot = root_rot;
+    for (int lev = 1; lev <= m.max_depth; ++lev) {
+        v3p pp = shfl16(pos, par);
+        q4p pr = shfl16(rot, par);
         if (dep == lev) {
             pos = pp + quat_rotate(pr, lt);
             if (LEAF_ROT || lev < m.max_depth) rot = quat_mul(pr, lq);
@@ -955,8 +994,10 @@ extern "C" int parc_pose_chain_backward(void *stream, parc_char_model_t model, i
 // 16-lane group, lane b = body b; the observation rows are assembled in LDS and written with float4 stores.
 // =============================================================================================
 #define POST_EPB 4            // envs per workgroup
-#define POST_MAX_THREADS 512  // 64 * (2 + PARC_MAX_TAR_STEPS)
+#define POST_MAX_THREADS 384  // 64 * (3 + (PARC_MAX_TAR_STEPS + 1) / 2): character, reference, target waves (two target steps per lane), heightmap wave
 #define POST_MAX_ROW 1408
+#define POST_STAGE_T 248      // two target steps of one env: 2 (9 + 6 (PARC_MAX_BODIES - 1) + 3 PARC_MAX_KEY_BODIES) = 246 floats
+#define POST_STAGE_C 192      // the character's own columns: 12 + 6 (PARC_MAX_BODIES - 1) + PARC_MAX_DOFS + 3 PARC_MAX_KEY_BODIES = 190 floats
 // Kernel arguments passed by value are loaded by the compiler in the entry block, all of them, and then live in scalar registers
 // for the whole kernel: with ~2 KB of argument structs that is far more than the 102 SGPRs a wave has, and the overflow is kept in
 // VGPR lanes (v_writelane at entry, v_readlane at every use - vector-issue slots).  kernarg_late hands out a pointer to a struct
@@ -976,8 +1017,29 @@ PARC_DEV const __attribute__((address_space(4))) T *kernarg_late(size_t off) {
 }
 
 #ifndef POST_MIN_WAVES
-#define POST_MIN_WAVES 8   // 64 VGPRs: all 1024 workgroups of a 4096-env launch resident in one round (needs -fno-slp-vectorize: 5 spills; with SLP packing 22 spills and slower)
+// 6 waves per workgroup at <= 72 VGPRs: four workgroups per CU, all 1024 workgroups of a 4096-env launch resident in one round
+// (measured, profiles/r03_wg_residency.txt: 6-wave workgroups stay one round at 72 VGPRs and need two at 80, 5-wave ones stay one round
+// up to 80; until round 3 the kernel ran 8 waves per workgroup at 64 VGPRs)
+#define POST_MIN_WAVES 7
 #endif
+
+// The columns a 16-lane group has written to its LDS segment go to the observation row as 16-byte stores, 4 consecutive floats per lane:
+// the launch is bound by the number of vector-memory instructions (a wave-wide store of one float per lane at a 24-byte stride costs the
+// CU's address path the same ~22 cycles as a store of 16 contiguous bytes per lane), so 23 strided stores of a target wave become 5.
+// LDS operations of one wave complete in order: the wave barrier + fences only keep the compiler from moving them.
+PARC_DEV void stage_out(const float *seg, float *dst, int n, int b) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n4 = n >> 2;
+    for (int c = b; c < n4; c += GRP) {
+        const float4 v = *reinterpret_cast<const float4 *>(seg + 4 * c);
+        f4u o;
+        o.x = v.x, o.y = v.y, o.z = v.z, o.w = v.w;
+        POST_STORE4(dst + 4 * c, o);
+    }
+    for (int i = 4 * n4 + b; i < n; i += GRP) dst[i] = seg[i];
+}
 
 // Workgroup = POST_EPB envs, one ROLE per wave so no wave diverges:
 //   wave 0      the simulated character of the 4 envs   (4 x 16 body lanes)
@@ -992,12 +1054,16 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     __shared__ __attribute__((aligned(16))) float envd[POST_EPB][20];   // root pos 3 | root rot 4 | heading^-1 4 | env id | root vel 3 | ang vel 3
     __shared__ __attribute__((aligned(16))) float qryd[1 + PARC_MAX_TAR_STEPS][POST_EPB][12];   // idx0 idx1 blend - | loop shift xyz, time | tile offset xy, motion end
     __shared__ float tgt_xy[POST_EPB][2];
+    // per-wave staging of the observation columns a wave produces (see stage_out): never shared between waves, no barrier
+    __shared__ __attribute__((aligned(16))) float stage_t[(PARC_MAX_TAR_STEPS + 1) / 2][POST_EPB][POST_STAGE_T];
+    __shared__ __attribute__((aligned(16))) float stage_c[POST_EPB][POST_STAGE_C];
     if (what & 0x100000) return;                     // (timing diagnostic: the launch alone)
     const int tid = threadIdx.x;
     const int wv = tid >> 6, gg = (tid & 63) >> 4, b = tid & 15;
     const int B = m.num_bodies, J = B - 1, D = m.dof_size, K = cfg.num_key_bodies, S = cfg.num_tar_steps;
-    const bool is_char = wv == 0, is_ref = wv == 1, is_tar = wv >= 2;
-    const int le = gg, s_idx = is_tar ? wv - 2 : 0;     // a target wave = one target step of the 4 envs
+    const int H = (S + 1) >> 1;                          // target waves: two target steps per lane
+    const bool is_char = wv == 0, is_ref = wv == 1, is_tar = wv >= 2 && wv < 2 + H, is_gat = wv == 2 + H;
+    const int le = gg;
     const int el = blockIdx.x * POST_EPB + le;
     const bool masked = (what & PARC_POST_MASKED) != 0;
     if (masked) {
@@ -1016,7 +1082,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     const int Wt = 9 + 6 * J + 3 * K;        // one target step (105)
     const int row_len = cfg.obs_dim - cfg.num_ray_points;  // 871
     const bool valid = b < B;
-    const bool do_hf = (what & PARC_POST_HF) != 0;
 
     // ---- phase 0 (wave 0): the per-env and per-query scalars, ONE lane each instead of once per 16-lane group in
     // every wave: lane l -> env l & 3, query l >> 2 (0 = reference at t, s + 1 = target step s)
@@ -1091,30 +1156,20 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         tgt_xy[ple][0] = tx;
         tgt_xy[ple][1] = ty;
     }
-    // K5 fused, ahead of everything: RefCharEnv._refresh_ray_obs_hfs (mgdm_dm_util.py:158-179) for the 4 envs of this workgroup.
-    // The heightmap columns need the simulated root state only, so waves 1.. gather them while wave 0 walks the dependent loads of
-    // phase 0 (clip ids -> clip table -> frame rows) that they would otherwise just wait for.  Same affine cell-unit form as
-    // hf_gather_kernel; every thread derives the map of its env itself.
-    if ((what & PARC_POST_OBS) && do_hf && wv >= 1) {
-        const int P = cfg.num_ray_points;
-        const int hthr = blockDim.x - 64, ht = tid - 64;
-        const int tpe = hthr / POST_EPB, l2 = ht / tpe;            // blockDim = 64*(2+S): hthr is a multiple of POST_EPB
-        const int hel = min((int)blockIdx.x * POST_EPB + l2, n_total - 1);
-        const int he = env_ids ? (int)env_ids[hel] : hel;
-        const hf_env_prm pr = hf_env_params<true>(he, buf.root_state, buf.env_offsets, ter, 1.0f / ter.dx, 1.0f / ter.dy);
-        const float max_i = (float)(ter.dim_x - 1), max_j = (float)(ter.dim_y - 1);
-        // straight into the observation row (consecutive lanes = consecutive columns: 256-byte runs per store instruction), long before
-        // the pose waves have anything to write: the 441 columns are a third of the row's bytes
-        float *hrow = buf.obs + (size_t)he * RS + (RS - P);
-        const bool hlive = (int)blockIdx.x * POST_EPB + l2 < n_total && (!masked || buf.env_mask[hel] != 0);
-        for (int p = hlive ? ht - l2 * tpe : P; p < P; p += tpe) {
-            float rx = ray_xy[2 * p], ry = ray_xy[2 * p + 1];
-            float ui = fmaf(rx, pr.ax, fmaf(ry, pr.bx, pr.cx));
-            float uj = fmaf(rx, pr.ay, fmaf(ry, pr.by, pr.cy));
-            ui = __builtin_amdgcn_fmed3f(rintf(ui), 0.f, max_i);
-            uj = __builtin_amdgcn_fmed3f(rintf(uj), 0.f, max_j);
-            hrow[p] = __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - pr.gz, cfg.min_obs_h, cfg.max_obs_h);
-        }
+    // K5 fused: RefCharEnv._refresh_ray_obs_hfs (mgdm_dm_util.py:158-179) for the 4 envs of this workgroup, by a wave of its own (the
+    // last one, launched only when PARC_POST_HF is asked for): 16 lanes per env, 28 points per lane, same affine cell-unit form as
+    // hf_gather_kernel.  The heightmap columns need the simulated root state only, nothing of phase 0: the wave derives the map of its
+    // envs while wave 0 walks the dependent loads of phase 0, and walks its points while the pose waves work - nobody waits for it.
+    // (Until round 3 all waves but wave 0 shared the gather in front of the barrier: 3.2 us during which no pose wave computed.)
+    hf_env_prm gpr;
+    int ghe = 0;
+    bool glive = false;
+    if (is_gat) {
+        const int hel = (int)blockIdx.x * POST_EPB + gg;
+        const int helc = min(hel, n_total - 1);
+        ghe = env_ids ? (int)env_ids[helc] : helc;
+        gpr = hf_env_params<true>(ghe, buf.root_state, buf.env_offsets, ter, 1.0f / ter.dx, 1.0f / ter.dy);
+        glive = hel < n_total && (!masked || buf.env_mask[helc] != 0);
     }
     if (what & 0x200000) return;                     // (timing diagnostic: launch + phase 0 + heightmap gather, no barrier)
     // loads that do not depend on phase 0
@@ -1124,7 +1179,116 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     __syncthreads();
     // diagnostic role ablations (timing only): bits 16/17/18 drop the target / reference / character waves
     if (((what & 0x10000) && is_tar) || ((what & 0x20000) && is_ref) || ((what & 0x40000) && is_char)) return;
+    if (is_gat) {
+        if (what & 0x80000) return;                              // (timing diagnostic: no heightmap wave)
+        const int P = cfg.num_ray_points;
+        const float max_i = (float)(ter.dim_x - 1), max_j = (float)(ter.dim_y - 1);
+        // straight into the observation row; the 441 columns are a third of the row's bytes.  The launch is bound by the NUMBER of
+        // vector-memory instructions its waves issue (about 22 cycles of a CU's address path each, whatever they move), so a lane takes
+        // 4 consecutive points: their (x, y) pairs arrive as two 16-byte loads and leave as one 16-byte store, 4 scattered cell reads
+        // in between - 7 instructions per 4 points instead of 12.
+        float *hrow = buf.obs + (size_t)ghe * RS + (RS - P);
+        auto cell = [&](float rx, float ry) {
+            float ui = fmaf(rx, gpr.ax, fmaf(ry, gpr.bx, gpr.cx));
+            float uj = fmaf(rx, gpr.ay, fmaf(ry, gpr.by, gpr.cy));
+            ui = __builtin_amdgcn_fmed3f(rintf(ui), 0.f, max_i);
+            uj = __builtin_amdgcn_fmed3f(rintf(uj), 0.f, max_j);
+            return __builtin_amdgcn_fmed3f(ter.hf[(int)ui * ter.dim_y + (int)uj] - gpr.gz, cfg.min_obs_h, cfg.max_obs_h);
+        };
+        const int full = P >> 2;                                 // chunks of 4 points
+#pragma unroll 2
+        for (int c = glive ? b : full; c < full; c += GRP) {
+            const f4u r0 = *reinterpret_cast<const f4u *>(ray_xy + 8 * c), r1 = *reinterpret_cast<const f4u *>(ray_xy + 8 * c + 4);
+            f4u h;
+            h.x = cell(r0.x, r0.y);
+            h.y = cell(r0.z, r0.w);
+            h.z = cell(r1.x, r1.y);
+            h.w = cell(r1.z, r1.w);
+            POST_STORE4(hrow + 4 * c, h);
+        }
+        for (int p = glive ? 4 * full + b : P; p < P; p += GRP) hrow[p] = cell(ray_xy[2 * p], ray_xy[2 * p + 1]);
+        return;
+    }
     if (is_ref && !(what & PARC_POST_REWARD_DONE)) return;      // the reference wave computes reward / termination; the reference STATE is ref_state_group's
+
+    // ---- target waves: DeepMimicEnv.compute_tar_obs + compute_tar_obs  dm_env.py:686-718, mgdm_dm_util.py:462-519
+    // Wave 2 + p carries target steps 2p and 2p + 1 of the 4 envs, one in each component of float2 values: the clip
+    // sampling (K3), the tree walk (K2) and the heading-frame epilogue (K7) of both steps issue as packed multiply-adds.
+    if (is_tar) {
+        if (!((what & PARC_POST_OBS) && live)) return;          // (a whole 16-lane group: the cross-lane moves stay inside a group)
+        const int sA = 2 * (wv - 2), sB = sA + 1;                // adjacent steps: their columns are one contiguous run of the row
+        const bool hasB = sB < S;                                // odd S: the last wave's second component repeats step sA and stores nothing
+        const int qB = hasB ? sB : sA;
+        const int e = __float_as_int(envd[le][11]);
+        float *row = buf.obs + (size_t)e * RS;
+        const float4 a0 = reinterpret_cast<const float4 *>(qryd[1 + sA][le])[0], a1 = reinterpret_cast<const float4 *>(qryd[1 + sA][le])[1],
+                     a2 = reinterpret_cast<const float4 *>(qryd[1 + sA][le])[2];
+        const float4 b0 = reinterpret_cast<const float4 *>(qryd[1 + qB][le])[0], b1 = reinterpret_cast<const float4 *>(qryd[1 + qB][le])[1],
+                     b2 = reinterpret_cast<const float4 *>(qryd[1 + qB][le])[2];
+        const float *rA0 = ml.frames + (size_t)__float_as_int(a0.x) * ml.row_stride, *rA1 = ml.frames + (size_t)__float_as_int(a0.y) * ml.row_stride;
+        const float *rB0 = ml.frames + (size_t)__float_as_int(b0.x) * ml.row_stride, *rB1 = ml.frames + (size_t)__float_as_int(b0.y) * ml.row_stride;
+        const f2 blend = mk2(a0.z, b0.z);
+        q4p jq = sp4(mk4(0.f, 0.f, 0.f, 1.f));
+        if (valid) {
+            const float4 xa = *reinterpret_cast<const float4 *>(rA0 + 4 * b), ya = *reinterpret_cast<const float4 *>(rA1 + 4 * b);
+            const float4 xb = *reinterpret_cast<const float4 *>(rB0 + 4 * b), yb = *reinterpret_cast<const float4 *>(rB1 + 4 * b);
+            jq = slerp(q4p{mk2(xa.x, xb.x), mk2(xa.y, xb.y), mk2(xa.z, xb.z), mk2(xa.w, xb.w)},
+                       q4p{mk2(ya.x, yb.x), mk2(ya.y, yb.y), mk2(ya.z, yb.z), mk2(ya.w, yb.w)}, blend);
+        }
+        if ((what & 0x400000) && jq.x.x != 123.f) return;       // (timing diagnostic: a target wave up to its blended joint rotations)
+        // root position: lerp of the two rows, + loop shift, + tile offset (the order of query_root_pos and dm_env.py:604-615)
+        v3p p_root;
+        {
+            const float *pa0 = rA0 + ml.off_pos, *pa1 = rA1 + ml.off_pos, *pb0 = rB0 + ml.off_pos, *pb1 = rB1 + ml.off_pos;
+            p_root = v3p{lerp_ref(mk2(pa0[0], pb0[0]), mk2(pa1[0], pb1[0]), blend), lerp_ref(mk2(pa0[1], pb0[1]), mk2(pa1[1], pb1[1]), blend),
+                         lerp_ref(mk2(pa0[2], pb0[2]), mk2(pa1[2], pb1[2]), blend)};
+            p_root = p_root + v3p{mk2(a1.x, b1.x), mk2(a1.y, b1.y), mk2(a1.z, b1.z)};
+            p_root.x += mk2(a2.x, b2.x);
+            p_root.y += mk2(a2.y, b2.y);
+        }
+        if (valid) {
+            const f2 ct = lerp_ref(mk2(rA0[ml.off_contacts + b], rB0[ml.off_contacts + b]), mk2(rA1[ml.off_contacts + b], rB1[ml.off_contacts + b]), blend);
+            row[Wc + S * Wt + sA * B + b] = ct.x;
+            if (hasB) row[Wc + S * Wt + sB * B + b] = ct.y;
+        }
+        // The tree walk starts from (root position, root rotation) in lane 0 and overwrites every other lane at its level, so the lanes'
+        // own joint rotations serve as the initial value; the root pose is fetched from lane 0 again afterwards instead of being kept
+        // in 14 registers through the walk.
+        v3p pos;
+        q4p rot;
+        group_fk<false>(m, b, p_root, jq, jq, pos, rot);
+        asm volatile("" ::: "memory");                          // the simulated root pose and heading are only needed from here on
+        if ((what & 0x800000) && pos.x.x != 123.f) return;      // (timing diagnostic: a target wave up to the end of its tree walk)
+        p_root = shfl16(pos, 0);
+        const q4p r_root = shfl16(jq, 0);
+        const float4 e0 = reinterpret_cast<const float4 *>(envd[le])[0], e1 = reinterpret_cast<const float4 *>(envd[le])[1],
+                     e2 = reinterpret_cast<const float4 *>(envd[le])[2];
+        const v3p c_pos = sp3(mk3(e0.x, e0.y, e0.z));
+        const q4p hinv = sp4(mk4(e1.w, e2.x, e2.y, e2.z));
+        float *seg = stage_t[wv - 2][le];                        // step sA at seg[0, Wt), step sB at seg[Wt, 2 Wt)
+        const v3p rpo = quat_rotate(hinv, p_root - c_pos);
+        if (b == 0) {
+            seg[0] = rpo.x.x, seg[1] = rpo.y.x, seg[2] = rpo.z.x;
+            seg[Wt] = rpo.x.y, seg[Wt + 1] = rpo.y.y, seg[Wt + 2] = rpo.z.y;
+        }
+        // lane 0: heading-relative root rotation at o+3; lane b: joint b-1 at o + 9 + 6 (b-1) = o + 3 + 6 b
+        const q4p hr = quat_mul(hinv, r_root);
+        if (valid) {
+            f2 tn[6];
+            quat_to_tan_norm(b == 0 ? hr : jq, tn);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) seg[3 + 6 * b + k] = tn[k].x, seg[Wt + 3 + 6 * b + k] = tn[k].y;
+        }
+        if (key_slot >= 0) {
+            const v3p kp = quat_rotate(hinv, pos - p_root) + rpo;
+            float *ka = seg + 9 + 6 * J + 3 * key_slot;
+            ka[0] = kp.x.x, ka[1] = kp.y.x, ka[2] = kp.z.x;
+            ka[Wt] = kp.x.y, ka[Wt + 1] = kp.y.y, ka[Wt + 2] = kp.z.y;
+        }
+        if ((what & 0x1000000) && seg[b] != 123.f) return;      // (timing diagnostic: a target wave without its stores)
+        stage_out(seg, row + Wc + sA * Wt, hasB ? 2 * Wt : Wt, b);
+        return;
+    }
 
     const int e = __float_as_int(envd[le][11]);
     const float *dofs = buf.dof_state + (size_t)e * D * 2;  // interleaved pos,vel
@@ -1143,9 +1307,9 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         r_root = mk4(envd[le][3], envd[le][4], envd[le][5], envd[le][6]);
         if (valid && b > 0) jq = joint_dof_to_rot(m, b, dofs, 2);      // K1 (kin_char_model.py:478-491)
     } else {
-        const float4 q0 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[0];
-        const float4 q1 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[1];
-        const float4 q2 = reinterpret_cast<const float4 *>(qryd[is_tar ? 1 + s_idx : 0][le])[2];
+        const float4 q0 = reinterpret_cast<const float4 *>(qryd[0][le])[0];
+        const float4 q1 = reinterpret_cast<const float4 *>(qryd[0][le])[1];
+        const float4 q2 = reinterpret_cast<const float4 *>(qryd[0][le])[2];
         fq.idx0 = __float_as_int(q0.x);
         fq.idx1 = __float_as_int(q0.y);
         fq.blend = q0.z;
@@ -1182,36 +1346,25 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     // ---- phase C: per-group epilogues
     if (is_char) {
         if ((what & PARC_POST_OBS) && live) {
-            // compute_char_obs  envs/ig_char_env.py:582-626 (global_obs False, no root height)
+            // compute_char_obs  envs/ig_char_env.py:582-626 (global_obs False, no root height); the Wc columns are collected in the
+            // wave's LDS segment and leave as 16-byte stores (stage_out)
+            float *seg = stage_c[le];
             if (b == 0) {
-                quat_to_tan_norm(quat_mul(hinv, c_rot), row);
-                st3(row + 6, quat_rotate(hinv, ld3(envd[le] + 12)));     // simulated root velocities, staged by phase 0
-                st3(row + 9, quat_rotate(hinv, ld3(envd[le] + 15)));
+                quat_to_tan_norm(quat_mul(hinv, c_rot), seg);
+                st3(seg + 6, quat_rotate(hinv, ld3(envd[le] + 12)));     // simulated root velocities, staged by phase 0
+                st3(seg + 9, quat_rotate(hinv, ld3(envd[le] + 15)));
             } else if (valid) {
-                quat_to_tan_norm(jq, row + 12 + 6 * (b - 1));
+                quat_to_tan_norm(jq, seg + 12 + 6 * (b - 1));
             }
             #pragma unroll 1
-            for (int d = b; d < D; d += GRP) row[12 + 6 * J + d] = dofs[2 * d + 1];
-            if (key_slot >= 0) st3(row + 12 + 6 * J + D + 3 * key_slot, quat_rotate(hinv, pos - c_pos));
+            for (int d = b; d < D; d += GRP) seg[12 + 6 * J + d] = dofs[2 * d + 1];
+            if (key_slot >= 0) st3(seg + 12 + 6 * J + D + 3 * key_slot, quat_rotate(hinv, pos - c_pos));
+            stage_out(seg, row, Wc, b);
             // char contacts  ig_parkour_env.py:841-848
             if (valid) {
                 v3 f = ld3(buf.contact_forces + ((size_t)e * B + b) * 3);
                 row[Wc + S * Wt + S * B + b] = fsqrt(dot3(f, f)) > cfg.contact_eps ? 1.f : 0.f;
             }
-        }
-    } else if (is_tar) {
-        if ((what & PARC_POST_OBS) && live) {
-            // DeepMimicEnv.compute_tar_obs + compute_tar_obs  dm_env.py:686-718, mgdm_dm_util.py:462-519
-            const int s = s_idx;
-            float *o = row + Wc + s * Wt;
-            v3 rpo = quat_rotate(hinv, p_root - c_pos);
-            if (b == 0) st3(o, rpo);
-            // lane 0: heading-relative root rotation at o+3; lane b: joint b-1 at o + 9 + 6 (b-1) = o + 3 + 6 b
-            const q4 hr = quat_mul(hinv, r_root);
-            if (valid) quat_to_tan_norm(b == 0 ? hr : jq, o + 3 + 6 * b);
-            if (key_slot >= 0) st3(o + 9 + 6 * J + 3 * key_slot, quat_rotate(hinv, pos - p_root) + rpo);
-            if (valid)
-                row[Wc + S * Wt + s * B + b] = lerp_ref(fq.row0[ml.off_contacts + b], fq.row1[ml.off_contacts + b], fq.blend);
         }
     }
     // ---- reference wave, part 1 (before the barrier, while the target waves are still busy): reference state out
@@ -1469,7 +1622,7 @@ extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_
         PARC_CHECK_LAUNCH();
     }
     if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) {
-        hipLaunchKernelGGL(track_post_kernel, dim3((n + POST_EPB - 1) / POST_EPB), dim3(64 * (2 + (cfg.num_tar_steps > 0 ? cfg.num_tar_steps : 0))), 0,
+        hipLaunchKernelGGL(track_post_kernel, dim3((n + POST_EPB - 1) / POST_EPB), dim3(64 * (2 + (cfg.num_tar_steps > 0 ? (cfg.num_tar_steps + 1) / 2 : 0) + (((what & PARC_POST_OBS) && (what & PARC_POST_HF)) ? 1 : 0))), 0,
                            (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, n, what, ray_xy);
         PARC_CHECK_LAUNCH();
     }

@@ -149,9 +149,13 @@ def bench_post_step(n, iters, workload="boxes_64clips"):
     us_graph = graph_us(full)
     us_nohf = graph_us(full & ~_hip.POST_HF)
     # timing diagnostics (bits of `what` the kernel honours for this purpose only): 0x10000 / 0x20000 / 0x40000 drop the target /
-    # reference / character waves after the barrier, 0x100000 returns at entry, 0x200000 returns in front of the barrier
+    # reference / character waves after the barrier, 0x80000 the heightmap wave, 0x100000 returns at entry, 0x200000 returns in front of the
+    # barrier, 0x400000 / 0x800000 end a target wave after its slerp / its tree walk
     for name, bits in () if "--plain" in sys.argv else (("launch_only", 0x100000), ("up_to_the_barrier", 0x200000), ("none", 0x70000), ("only_char", 0x30000),
-                                                         ("only_ref", 0x50000), ("only_tar", 0x60000), ("no_tar", 0x10000), ("no_ref", 0x20000), ("no_char", 0x40000)):
+                                                         ("only_ref", 0x50000), ("only_tar", 0x60000), ("no_tar", 0x10000), ("no_ref", 0x20000), ("no_char", 0x40000),
+                                                         ("no_heightmap_wave", 0x80000), ("only_tar_no_heightmap_wave", 0xe0000),
+                                                         ("only_tar_no_stores", 0xe0000 | 0x1000000), ("all_but_target_stores", 0x1000000), ("only_tar_up_to_slerp", 0xe0000 | 0x400000), ("only_tar_up_to_tree_walk", 0xe0000 | 0x800000),
+                                                         ("only_ref_no_heightmap_wave", 0xd0000), ("only_char_no_heightmap_wave", 0xb0000)):
         print(json.dumps({"ablation": name, "us_graph_replay": round(graph_us(full | bits), 2)}))
     # the step's tail launch: fail-rate EMA alone, and with the reference state co-scheduled
     fr = torch.full((M,), 0.5, device="cuda:0")
