@@ -335,6 +335,13 @@ PARC_DEV q4 joint_dof_to_rot(const parc_char_model_t &m, int b, const float *dof
     return mk4(0.f, 0.f, 0.f, 1.f);
 }
 
+// the same with the joint's constants already at hand (type, first dof, hinge axis)
+PARC_DEV q4 joint_dof_to_rot(int jt, int d, v3 ax, const float *dof, int stride) {
+    if (jt == PARC_JOINT_HINGE) return axis_angle_to_quat(ax, dof[d * stride]);
+    if (jt == PARC_JOINT_SPHERICAL) return exp_map_to_quat(mk3(dof[d * stride], dof[(d + 1) * stride], dof[(d + 2) * stride]));
+    return mk4(0.f, 0.f, 0.f, 1.f);
+}
+
 // anim/kin_char_model.py:79-100: one joint's quaternion -> dofs
 // (dof2, when given, receives the same values at stride 2: the position slots of an interleaved dof_state row)
 PARC_DEV void joint_rot_to_dof(const parc_char_model_t &m, int b, q4 q, float *dof, float *dof2 = nullptr) {
@@ -364,27 +371,44 @@ PARC_DEV void joint_rot_to_dof(const parc_char_model_t &m, int b, q4 q, float *d
 // anim/kin_char_model.py:509-541, level-synchronous over the tree: lane b ends with body b's world
 // position/rotation.  jq = joint rotation of lane's body (ignored for the root lane).
 // LEAF_ROT = false: the rotations of the deepest level are not produced (callers that only use positions)
-template <bool LEAF_ROT = true>
-PARC_DEV void group_fk(const parc_char_model_t &m, int b, v3 root_pos, q4 root_rot, q4 jq, v3 &pos, q4 &rot) {
+// what the walk needs to know about a lane's body (fk_consts reads it from the model struct; the post-step kernel keeps one copy per
+// workgroup in LDS instead of having every wave load the four tables)
+struct fk_consts {
+    int par, dep;         // parent lane (0 for the root and for lanes without a body), depth (-1 without a body)
+    q4 lrot;              // local_rotation
+    v3 lt;                // local_translation
+};
+PARC_DEV fk_consts fk_consts_of(const parc_char_model_t &m, int b) {
+    fk_consts k;
     const bool valid = b < m.num_bodies;
-    const int par = (valid && b > 0) ? m.parent[b] : 0;
-    const int dep = valid ? m.depth[b] : -1;
-    q4 lq = mk4(0.f, 0.f, 0.f, 1.f);
-    v3 lt = mk3(0.f, 0.f, 0.f);
+    k.par = (valid && b > 0) ? m.parent[b] : 0;
+    k.dep = valid ? m.depth[b] : -1;
+    k.lrot = mk4(0.f, 0.f, 0.f, 1.f);
+    k.lt = mk3(0.f, 0.f, 0.f);
     if (valid && b > 0) {
-        lq = quat_mul(ld4(m.local_rotation[b]), jq);
-        lt = ld3(m.local_translation[b]);
+        k.lrot = ld4(m.local_rotation[b]);
+        k.lt = ld3(m.local_translation[b]);
     }
+    return k;
+}
+template <bool LEAF_ROT = true>
+PARC_DEV void group_fk(const fk_consts &k, int max_depth, v3 root_pos, q4 root_rot, q4 jq, v3 &pos, q4 &rot) {
+    q4 lq = mk4(0.f, 0.f, 0.f, 1.f);
+    if (k.dep > 0) lq = quat_mul(k.lrot, jq);
     pos = root_pos;
     rot = root_rot;
-    for (int lev = 1; lev <= m.max_depth; ++lev) {
-        v3 pp = shfl16(pos, par);
-        q4 pr = shfl16(rot, par);
-        if (dep == lev) {
-            pos = pp + quat_rotate(pr, lt);
-            if (LEAF_ROT || lev < m.max_depth) rot = quat_mul(pr, lq);
+    for (int lev = 1; lev <= max_depth; ++lev) {
+        v3 pp = shfl16(pos, k.par);
+        q4 pr = shfl16(rot, k.par);
+        if (k.dep == lev) {
+            pos = pp + quat_rotate(pr, k.lt);
+            if (LEAF_ROT || lev < max_depth) rot = quat_mul(pr, lq);
         }
     }
+}
+template <bool LEAF_ROT = true>
+PARC_DEV void group_fk(const parc_char_model_t &m, int b, v3 root_pos, q4 root_rot, q4 jq, v3 &pos, q4 &rot) {
+    group_fk<LEAF_ROT>(fk_consts_of(m, b), m.max_depth, root_pos, root_rot, jq, pos, rot);
 }
 
 // ---- the same on two poses per lane (parc_math_pk.h): the cross-lane moves are per component, the arithmetic is packed
@@ -392,24 +416,18 @@ PARC_DEV f2 shfl16(f2 v, int src) { return f2{shfl16(v.x, src), shfl16(v.y, src)
 PARC_DEV q4p shfl16(q4p q, int src) { return q4p{shfl16(q.x, src), shfl16(q.y, src), shfl16(q.z, src), shfl16(q.w, src)}; }
 PARC_DEV v3p shfl16(v3p v, int src) { return v3p{shfl16(v.x, src), shfl16(v.y, src), shfl16(v.z, src)}; }
 template <bool LEAF_ROT = true>
-PARC_DEV void group_fk(const parc_char_model_t &m, int b, v3p root_pos, q4p root_rot, q4p jq, v3p &pos, q4p &rot) {
-    const bool valid = b < m.num_bodies;
-    const int par = (valid && b > 0) ? m.parent[b] : 0;
-    const int dep = valid ? m.depth[b] : -1;
+PARC_DEV void group_fk(const fk_consts &k, int max_depth, v3p root_pos, q4p root_rot, q4p jq, v3p &pos, q4p &rot) {
     q4p lq = sp4(mk4(0.f, 0.f, 0.f, 1.f));
-    v3p lt = sp3(mk3(0.f, 0.f, 0.f));
-    if (valid && b > 0) {
-        lq = quat_mul(sp4(ld4(m.local_rotation[b])), jq);
-        lt = sp3(ld3(m.local_translation[b]));
-    }
+    if (k.dep > 0) lq = quat_mul(sp4(k.lrot), jq);
+    const v3p lt = sp3(k.lt);
     pos = root_pos;
     rot = root_rot;
-    for (int lev = 1; lev <= m.max_depth; ++lev) {
-        v3p pp = shfl16(pos, par);
-        q4p pr = shfl16(rot, par);
-        if (dep == lev) {
+    for (int lev = 1; lev <= max_depth; ++lev) {
+        v3p pp = shfl16(pos, k.par);
+        q4p pr = shfl16(rot, k.par);
+        if (k.dep == lev) {
             pos = pp + quat_rotate(pr, lt);
-            if (LEAF_ROT || lev < m.max_depth) rot = quat_mul(pr, lq);
+            if (LEAF_ROT || lev < max_depth) rot = quat_mul(pr, lq);
         }
     }
 }
@@ -1057,6 +1075,10 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     // per-wave staging of the observation columns a wave produces (see stage_out): never shared between waves, no barrier
     __shared__ __attribute__((aligned(16))) float stage_t[(PARC_MAX_TAR_STEPS + 1) / 2][POST_EPB][POST_STAGE_T];
     __shared__ __attribute__((aligned(16))) float stage_c[POST_EPB][POST_STAGE_C];
+    // per-body constants of the tree walk + the body's key slot, loaded once per workgroup (by the reference wave, which has nothing
+    // else to do in front of the barrier) instead of as four (character and reference wave: nine) vector loads in every pose wave: lrot 4 | lt 3, parent | depth, key slot,
+    // | joint type, first dof, - | hinge axis 3, -
+    __shared__ __attribute__((aligned(16))) float bodyk[GRP][16];
     if (what & 0x100000) return;                     // (timing diagnostic: the launch alone)
     const int tid = threadIdx.x;
     const int wv = tid >> 6, gg = (tid & 63) >> 4, b = tid & 15;
@@ -1172,11 +1194,33 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         glive = hel < n_total && (!masked || buf.env_mask[helc] != 0);
     }
     if (what & 0x200000) return;                     // (timing diagnostic: launch + phase 0 + heightmap gather, no barrier)
-    // loads that do not depend on phase 0
-    int key_slot = -1;
-    for (int k = 0; k < K; ++k)
-        if (cfg.key_body_ids[k] == b) key_slot = k;
+    if (is_ref && gg == 0) {
+        const fk_consts k = fk_consts_of(m, b);
+        int ks = -1;
+        for (int i = 0; i < K; ++i)
+            if (cfg.key_body_ids[i] == b) ks = i;
+        float4 *bk = reinterpret_cast<float4 *>(bodyk[b]);
+        bk[0] = make_float4(k.lrot.x, k.lrot.y, k.lrot.z, k.lrot.w);
+        bk[1] = make_float4(k.lt.x, k.lt.y, k.lt.z, __int_as_float(k.par));
+        const bool jv = b > 0 && b < B;
+        bk[2] = make_float4(__int_as_float(k.dep), __int_as_float(ks), __int_as_float(jv ? m.joint_type[b] : -1), __int_as_float(jv ? m.dof_idx[b] : 0));
+        bk[3] = jv ? make_float4(m.joint_axis[b][0], m.joint_axis[b][1], m.joint_axis[b][2], 0.f) : make_float4(0.f, 0.f, 1.f, 0.f);
+    }
     __syncthreads();
+    const int key_slot = __float_as_int(bodyk[b][9]);
+    auto joint_rot_lds = [&](const float *dof2) {                // K1 (kin_char_model.py:478-491) on the staged joint constants
+        const float4 k3 = reinterpret_cast<const float4 *>(bodyk[b])[3];
+        return joint_dof_to_rot(__float_as_int(bodyk[b][10]), __float_as_int(bodyk[b][11]), mk3(k3.x, k3.y, k3.z), dof2, 2);
+    };
+    auto fk_consts_lds = [&]() {                                 // read where the walk starts, not held in registers until then
+        fk_consts k;
+        const float4 k0 = reinterpret_cast<const float4 *>(bodyk[b])[0], k1 = reinterpret_cast<const float4 *>(bodyk[b])[1];
+        k.lrot = mk4(k0.x, k0.y, k0.z, k0.w);
+        k.lt = mk3(k1.x, k1.y, k1.z);
+        k.par = __float_as_int(k1.w);
+        k.dep = __float_as_int(bodyk[b][8]);
+        return k;
+    };
     // diagnostic role ablations (timing only): bits 16/17/18 drop the target / reference / character waves
     if (((what & 0x10000) && is_tar) || ((what & 0x20000) && is_ref) || ((what & 0x40000) && is_char)) return;
     if (is_gat) {
@@ -1256,11 +1300,10 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         // in 14 registers through the walk.
         v3p pos;
         q4p rot;
-        group_fk<false>(m, b, p_root, jq, jq, pos, rot);
+        group_fk<false>(fk_consts_lds(), m.max_depth, p_root, jq, jq, pos, rot);
         asm volatile("" ::: "memory");                          // the simulated root pose and heading are only needed from here on
         if ((what & 0x800000) && pos.x.x != 123.f) return;      // (timing diagnostic: a target wave up to the end of its tree walk)
         p_root = shfl16(pos, 0);
-        const q4p r_root = shfl16(jq, 0);
         const float4 e0 = reinterpret_cast<const float4 *>(envd[le])[0], e1 = reinterpret_cast<const float4 *>(envd[le])[1],
                      e2 = reinterpret_cast<const float4 *>(envd[le])[2];
         const v3p c_pos = sp3(mk3(e0.x, e0.y, e0.z));
@@ -1271,8 +1314,9 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             seg[0] = rpo.x.x, seg[1] = rpo.y.x, seg[2] = rpo.z.x;
             seg[Wt] = rpo.x.y, seg[Wt + 1] = rpo.y.y, seg[Wt + 2] = rpo.z.y;
         }
-        // lane 0: heading-relative root rotation at o+3; lane b: joint b-1 at o + 9 + 6 (b-1) = o + 3 + 6 b
-        const q4p hr = quat_mul(hinv, r_root);
+        // lane 0: heading-relative root rotation at o+3 (the lane's own quaternion IS the root rotation); lane b: joint b-1 at
+        // o + 9 + 6 (b-1) = o + 3 + 6 b
+        const q4p hr = quat_mul(hinv, jq);
         if (valid) {
             f2 tn[6];
             quat_to_tan_norm(b == 0 ? hr : jq, tn);
@@ -1305,7 +1349,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     if (is_char) {
         p_root = mk3(envd[le][0], envd[le][1], envd[le][2]);
         r_root = mk4(envd[le][3], envd[le][4], envd[le][5], envd[le][6]);
-        if (valid && b > 0) jq = joint_dof_to_rot(m, b, dofs, 2);      // K1 (kin_char_model.py:478-491)
+        if (valid && b > 0) jq = joint_rot_lds(dofs);      // K1 (kin_char_model.py:478-491)
     } else {
         const float4 q0 = reinterpret_cast<const float4 *>(qryd[0][le])[0];
         const float4 q1 = reinterpret_cast<const float4 *>(qryd[0][le])[1];
@@ -1332,7 +1376,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     // doubling in the root frame - drifts ~1e-4 from the reference's body positions)
     v3 pos;
     q4 rot;
-    group_fk<false>(m, b, p_root, r_root, jq, pos, rot);
+    group_fk<false>(fk_consts_lds(), m.max_depth, p_root, r_root, jq, pos, rot);
 
     // the simulated root pose and heading are only needed from here on: read them after the tree walk (11 fewer live
     // registers through it; the compiler barrier keeps the LDS reads from being hoisted back up)
@@ -1399,7 +1443,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 if (valid && b > 0) {
                     // the simulated character's joint rotation (K1), computed here too: taking it from the character wave would need a
                     // second barrier, and with it every wave of the workgroup would wait for the slowest one
-                    const q4 cj = joint_dof_to_rot(m, b, dofs, 2);
+                    const q4 cj = joint_rot_lds(dofs);
                     float da = quat_diff_angle(cj, rq);
                     pose_e = rcfg.joint_err_w[b - 1] * da * da;
                 }
