@@ -173,8 +173,9 @@ def oracle_compare(env, clips, tiled, obs, r, ids=None, report=False, oracle_fra
     check("obs_char", g_obs[:, :Wc], o_obs[:, :Wc], none, TIGHT + 2 * coord_ulp)
     tar_exc = (marg[:, 1:, None, :] & tar_dep[None, None]).any(-1).reshape(n, S * Wt)
     check("obs_tar", g_obs[:, Wc:Wc + S * Wt], o_obs[:, Wc:Wc + S * Wt], tar_exc, TIGHT + 2 * coord_ulp)
-    check("obs_contacts", g_obs[:, Wc + S * Wt:871], o_obs[:, Wc + S * Wt:871], none, 2e-5)
-    flips = float(np.mean(g_obs[:, 871:] != o_obs[:, 871:]))
+    RL = Wc + S * Wt + S * B + B                                           # pose-derived columns (871 with six target steps)
+    check("obs_contacts", g_obs[:, Wc + S * Wt:RL], o_obs[:, Wc + S * Wt:RL], none, 2e-5)
+    flips = float(np.mean(g_obs[:, RL:] != o_obs[:, RL:]))
     stats["obs_hf_fraction_of_nearest_cell_flips"] = flips
     if not report:
         assert flips < 5e-3                                            # nearest-cell flips only at cell boundaries

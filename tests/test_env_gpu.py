@@ -627,3 +627,31 @@ def test_reset_state_offsets(env):
         dm.set_rand_root_pos_offset_scale(scale)
     assert env.supports_device_reset()
     env.reset()
+
+
+@pytest.mark.parametrize("steps", [[1, 2, 3, 4, 5], [2], []], ids=["five", "one", "none"])
+def test_other_target_step_counts_against_the_oracle(steps):
+    """The target waves of the fused post-step kernel carry two adjacent target steps per lane; an odd count leaves the last wave's second
+    component empty, a single step uses one half-filled wave, no step launches no target wave at all (dm_env.py:686-718 takes any
+    `tar_obs_steps`).  Every env's reference pose, observation row, reward and termination flag against the oracle, after a few steps and
+    after a restart of half the envs."""
+    import smoke_impl
+    from parc_amd import workloads
+    torch.manual_seed(0)
+    n = 256
+    env, clips, tiled = workloads.build_env("boxes_64clips", n, DEV, seed=1, env_overrides={"tar_obs_steps": steps})
+    S = len(steps)
+    assert int(env._cfg.struct.num_tar_steps) == S
+    obs, info = env.reset()
+    assert obs.shape[1] == 136 + S * 105 + S * 15 + 15 + 441
+    lo, hi = env._action_bound_low, env._action_bound_high
+    mid, half = 0.5 * (hi + lo), 0.5 * (hi - lo)
+    for _ in range(3):
+        obs, r, done, info = env.step(mid + 0.2 * half * torch.randn((n, 28), device=DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(r).all()
+    assert smoke_impl.oracle_compare(env, clips, tiled, obs, r) == n
+    env.reset(torch.arange(0, n, 2, device=DEV))
+    obs, r, done, info = env.step(mid + 0.2 * half * torch.randn((n, 28), device=DEV))
+    torch.cuda.synchronize()
+    assert smoke_impl.oracle_compare(env, clips, tiled, obs, r) == n
