@@ -416,8 +416,9 @@ def main():
                          "traffic_source": (traffic_src + " (committed profile, not measured in this run)") if traffic else None,
                          "frac_measured_traffic": (traffic / (kern_graph_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "binding_roofline": "HBM by SURVEY's classification; measured: neither HBM (frac_measured_traffic) nor vector issue "
-                                             "(valu.frac_of_valu_issue_peak) is saturated - the launch is bound by its dependent chains at 8 waves "
-                                             "per SIMD and 64 VGPRs (DESIGN.md section 3, profiles/r03_post_step_attempts.txt)",
+                                             "(valu.frac_of_valu_issue_peak) is saturated - the launch is bound by the dependent chains of its pose waves "
+                                             "(6 waves per workgroup, 70 VGPRs) and the drain of its row stores (DESIGN.md section 3, "
+                                             "profiles/r03_post_step_attempts.txt)",
                          "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": kern_graph_us, "us_per_launch_eager_back_to_back": kern_b2b_us,
                          "us_per_launch_event_pairs_in_rollout_loop": kern_us, "launches_event_timed": len(evs), "valu": valu},
             "rollout": ("one hipGraph replay per env step" + (", finished envs reset on the device inside the graph" if any(k[2] for k in agent._graphs)

@@ -1008,8 +1008,8 @@ extern "C" int parc_pose_chain_backward(void *stream, parc_char_model_t model, i
 }
 
 // =============================================================================================
-// Fused post-physics pass.  A pose (simulated character, reference at t, 6 targets at t+dt_s) is handled by a
-// 16-lane group, lane b = body b; the observation rows are assembled in LDS and written with float4 stores.
+// Fused post-physics pass.  A pose (simulated character, reference at t, targets at t+dt_s - two of those per group) is handled by a
+// 16-lane group, lane b = body b; every wave writes the observation columns it produces itself.
 // =============================================================================================
 #define POST_EPB 4            // envs per workgroup
 #define POST_MAX_THREADS 384  // 64 * (3 + (PARC_MAX_TAR_STEPS + 1) / 2): character, reference, target waves (two target steps per lane), heightmap wave
@@ -1060,11 +1060,12 @@ PARC_DEV void stage_out(const float *seg, float *dst, int n, int b) {
 }
 
 // Workgroup = POST_EPB envs, one ROLE per wave so no wave diverges:
-//   wave 0      the simulated character of the 4 envs   (4 x 16 body lanes)
-//   wave 1      their reference poses at t              -> ref_* state, reward, done
-//   wave 2..    target poses: group k = (wave-2)*4 + g covers env k / S, step k % S
-// Phase 1 writes the pose-derived columns of the 4 observation rows into LDS, phase 2 (all threads) gathers the
-// 4 x 441 heightmap samples into the same rows, phase 3 streams the rows out as aligned float4.
+//   wave 0          the simulated character of the 4 envs   (4 x 16 body lanes)  -> its own observation columns
+//   wave 1          their reference poses at t                                   -> reward, done
+//   wave 2 + p      target steps 2p and 2p + 1 of the 4 envs, one in each half of packed float2 values (p < ceil(S / 2))
+//   last wave       the 4 x 441 heightmap samples (only launched with PARC_POST_HF)
+// Phase 0 (28 lanes of wave 0: per-env and per-query scalars -> LDS) is the only thing the one barrier waits for; behind it the waves
+// never meet again: each collects the columns it produces in an LDS segment of its own and writes them as 16-byte stores (stage_out).
 __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_kernel(parc_char_model_t m, parc_motion_lib_t ml, parc_terrain_t ter,
                                                                      parc_track_cfg_t cfg, parc_env_buffers_t buf,
                                                                      const int64_t *__restrict__ env_ids, int n_total, int what,
