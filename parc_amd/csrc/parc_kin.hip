@@ -1411,6 +1411,34 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 row[Wc + S * Wt + S * B + b] = fsqrt(dot3(f, f)) > cfg.contact_eps ? 1.f : 0.f;
             }
         }
+        if ((what & PARC_POST_REWARD_DONE) && b == 0 && live) {
+            // task terms  ig_parkour_env.py:1346-1393 (logged; they scale the reward only if rel_task_w > 0).  They read the simulated
+            // root and the xy target only - nothing of the reference pose - so the character wave, the first to finish, computes them
+            // instead of the reward wave, whose instruction stream is the longest of the workgroup.
+            const auto &rbuf = *kernarg_late<parc_env_buffers_t>(KARG_OFF_BUF);
+            const auto &rcfg = *kernarg_late<parc_track_cfg_t>(KARG_OFF_CFG);
+            const int N = rbuf.reward_terms_stride > 0 ? rbuf.reward_terms_stride : rbuf.num_envs;
+            float tx = tgt_xy[le][0] - c_pos.x, ty = tgt_xy[le][1] - c_pos.y;
+            float terr = tx * tx + ty * ty;
+            float task_r1 = fexp(-0.075f * terr);
+            float tl = fsqrt(terr);
+            float itl = frcp(tl);
+            float dxn = tl > 0.01f ? tx * itl : 0.f, dyn = tl > 0.01f ? ty * itl : 0.f;
+            float mve = fmaxf(2.0f - (dxn * envd[le][12] + dyn * envd[le][13]), 0.f);
+            float min_vel_r = fexp(-(mve * mve));
+            // heading direction (cos h, sin h) = normalised xy of the rotated x axis
+            float ha = 1.0f - 2.0f * (c_rot.y * c_rot.y + c_rot.z * c_rot.z), hb = 2.0f * (c_rot.w * c_rot.z + c_rot.x * c_rot.y);
+            float hn2 = ha * ha + hb * hb;
+            float hir = __builtin_amdgcn_rsqf(hn2);
+            float chd = hn2 > 0.f ? ha * hir : 1.0f, shd = hn2 > 0.f ? hb * hir : 0.0f;
+            float he = fmaxf(1.0f - (dxn * chd + dyn * shd), 0.f);
+            float task2 = min_vel_r * fexp(-(he * he));
+            float task_r = rcfg.task1_w * task_r1 + rcfg.task2_w * task2;
+            if (terr < rcfg.target_radius * rcfg.target_radius) task_r = 1.0f;
+            rbuf.reward_terms[6 * (size_t)N + e] = task_r1;
+            rbuf.reward_terms[7 * (size_t)N + e] = task2;
+            rbuf.reward_terms[8 * (size_t)N + e] = task_r;
+        }
     }
     // ---- reference wave, part 1 (before the barrier, while the target waves are still busy): reference state out
     // Everything the reference wave does lives in this one branch (its values never meet the other roles' registers), including
@@ -1507,29 +1535,6 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                     rbuf.reward_terms[3 * (size_t)N + e] = root_vel_r;
                     rbuf.reward_terms[4 * (size_t)N + e] = key_r;
                     rbuf.reward_terms[5 * (size_t)N + e] = cp;
-                    {
-                        // task terms  ig_parkour_env.py:1346-1393 (logged; they scale the reward only if rel_task_w > 0)
-                        float tx = tgt_xy[le][0] - c_pos.x, ty = tgt_xy[le][1] - c_pos.y;
-                        float terr = tx * tx + ty * ty;
-                        float task_r1 = fexp(-0.075f * terr);
-                        float tl = fsqrt(terr);
-                        float itl = frcp(tl);
-                        float dxn = tl > 0.01f ? tx * itl : 0.f, dyn = tl > 0.01f ? ty * itl : 0.f;
-                        float mve = fmaxf(2.0f - (dxn * envd[le][12] + dyn * envd[le][13]), 0.f);
-                        float min_vel_r = fexp(-(mve * mve));
-                        // heading direction (cos h, sin h) = normalised xy of the rotated x axis
-                        float ha = 1.0f - 2.0f * (c_rot.y * c_rot.y + c_rot.z * c_rot.z), hb = 2.0f * (c_rot.w * c_rot.z + c_rot.x * c_rot.y);
-                        float hn2 = ha * ha + hb * hb;
-                        float hir = __builtin_amdgcn_rsqf(hn2);
-                        float chd = hn2 > 0.f ? ha * hir : 1.0f, shd = hn2 > 0.f ? hb * hir : 0.0f;
-                        float he = fmaxf(1.0f - (dxn * chd + dyn * shd), 0.f);
-                        float task2 = min_vel_r * fexp(-(he * he));
-                        float task_r = rcfg.task1_w * task_r1 + rcfg.task2_w * task2;
-                        if (terr < rcfg.target_radius * rcfg.target_radius) task_r = 1.0f;
-                        rbuf.reward_terms[6 * (size_t)N + e] = task_r1;
-                        rbuf.reward_terms[7 * (size_t)N + e] = task2;
-                        rbuf.reward_terms[8 * (size_t)N + e] = task_r;
-                    }
                     // done
                     const float tm = qryd[0][le][7];
                     int done = PARC_DONE_NULL;
