@@ -336,10 +336,26 @@ PARC_DEV q4 joint_dof_to_rot(const parc_char_model_t &m, int b, const float *dof
 }
 
 // the same with the joint's constants already at hand (type, first dof, hinge axis)
+// Both joint kinds end in axis_angle_to_quat (exp_map_to_quat of parc_math.h = the steps below, then that call): the lanes of a group
+// differ in kind, so each kind's branch only prepares (axis, angle) and the common tail is issued once instead of once per kind.
 PARC_DEV q4 joint_dof_to_rot(int jt, int d, v3 ax, const float *dof, int stride) {
-    if (jt == PARC_JOINT_HINGE) return axis_angle_to_quat(ax, dof[d * stride]);
-    if (jt == PARC_JOINT_SPHERICAL) return exp_map_to_quat(mk3(dof[d * stride], dof[(d + 1) * stride], dof[(d + 2) * stride]));
-    return mk4(0.f, 0.f, 0.f, 1.f);
+    float an = 0.f;
+    if (jt == PARC_JOINT_HINGE) {
+        an = dof[d * stride];
+    } else if (jt == PARC_JOINT_SPHERICAL) {
+        const v3 em = mk3(dof[d * stride], dof[(d + 1) * stride], dof[(d + 2) * stride]);
+        float a = fsqrt(dot3(em, em));
+        const float ia = frcp(a);
+        ax = v3{em.x * ia, em.y * ia, em.z * ia};
+        if (!(a < 3.1415925f)) a = normalize_angle(a);       // identity below pi
+        if (!(fabsf(a) > 1e-5f)) {
+            ax = mk3(0.f, 0.f, 1.f);
+            a = 0.f;
+        }
+        an = a;
+    }
+    const q4 q = axis_angle_to_quat(ax, an);
+    return (jt == PARC_JOINT_HINGE || jt == PARC_JOINT_SPHERICAL) ? q : mk4(0.f, 0.f, 0.f, 1.f);
 }
 
 // anim/kin_char_model.py:79-100: one joint's quaternion -> dofs
