@@ -419,6 +419,11 @@ def main():
                                              "(valu.frac_of_valu_issue_peak) is saturated - the launch is bound by the dependent chains of its pose waves "
                                              "(6 waves per workgroup, 70 VGPRs) and the drain of its row stores (DESIGN.md section 3, "
                                              "profiles/r03_post_step_attempts.txt)",
+                         "in_the_rollout_step": "us_per_launch is the launch repeated in one hipGraph (the condition of the committed rocprof "
+                                                "summaries); inside the rollout step's graph the same launch takes 17.6 us by rocprofv3 "
+                                                "(0.40 of the HBM peak; every kernel of that graph takes >= 4.5 us, a launch that returns at "
+                                                "entry 4.6 instead of 1.6 us: profiles/r03_post_step_in_rollout.txt); "
+                                                "us_per_launch_event_pairs_in_rollout_loop is that launch between two events, event cost included",
                          "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": kern_graph_us, "us_per_launch_eager_back_to_back": kern_b2b_us,
                          "us_per_launch_event_pairs_in_rollout_loop": kern_us, "launches_event_timed": len(evs), "valu": valu},
             "rollout": ("one hipGraph replay per env step" + (", finished envs reset on the device inside the graph" if any(k[2] for k in agent._graphs)
