@@ -1485,12 +1485,17 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 const v3 sim_pos = ld3(rbuf.rigid_body_state + ((size_t)e * B + (valid ? b : 0)) * 13);
                 const v3 sim_root = shfl16(sim_pos, 0);          // body 0 is the root
                 const v3 sim_f = ld3(rbuf.contact_forces + ((size_t)e * B + (valid ? b : 0)) * 3);
-                if (valid && b > 0) {
+                // rotation differences, one evaluation for the group: lane b > 0 its joint (simulated vs reference), lane 0 - which has no
+                // joint - the ROOT rotation difference that the reward's root term and the termination test need (same function, same inputs
+                // as a second call by lane 0 alone would see)
+                float rot_diff = 0.f;
+                if (valid) {
                     // the simulated character's joint rotation (K1), computed here too: taking it from the character wave would need a
                     // second barrier, and with it every wave of the workgroup would wait for the slowest one
-                    const q4 cj = joint_rot_lds(dofs);
-                    float da = quat_diff_angle(cj, rq);
-                    pose_e = rcfg.joint_err_w[b - 1] * da * da;
+                    q4 cj = c_rot;
+                    if (b > 0) cj = joint_rot_lds(dofs);
+                    rot_diff = quat_diff_angle(cj, rq);                 // (lane 0: rq = r_rot, the reference root rotation)
+                    if (b > 0) pose_e = rcfg.joint_err_w[b - 1] * rot_diff * rot_diff;
                 }
                 #pragma unroll 1
                 for (int d = b; d < D; d += GRP) {
@@ -1530,7 +1535,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 if (b == 0 && live) {
                     v3 dp = r_pos - c_pos;
                     float root_pos_err = dot3(dp, dp);
-                    float rre = quat_diff_angle(c_rot, r_rot);
+                    const float rre = rot_diff;
                     float rre2 = rre * rre;
                     v3 dv = r_vel - ld3(envd[le] + 12), dw = r_avel - ld3(envd[le] + 15);
                     float pose_r = fexp(-0.25f * pose_e);
