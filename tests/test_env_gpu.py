@@ -655,3 +655,25 @@ def test_other_target_step_counts_against_the_oracle(steps):
     obs, r, done, info = env.step(mid + 0.2 * half * torch.randn((n, 28), device=DEV))
     torch.cuda.synchronize()
     assert smoke_impl.oracle_compare(env, clips, tiled, obs, r) == n
+
+
+@pytest.mark.parametrize("n", [3, 250])
+def test_env_counts_that_do_not_fill_the_last_workgroup(n):
+    """The post-step kernel serves 4 envs per workgroup; a launch whose env count is not a multiple of 4 (or smaller than one workgroup)
+    leaves lane groups of the last workgroup without an env.  Every env against the oracle, after steps and after a restart of some."""
+    import smoke_impl
+    from parc_amd import workloads
+    torch.manual_seed(0)
+    env, clips, tiled = workloads.build_env("boxes_64clips", n, DEV, seed=3)
+    obs, info = env.reset()
+    lo, hi = env._action_bound_low, env._action_bound_high
+    mid, half = 0.5 * (hi + lo), 0.5 * (hi - lo)
+    for _ in range(3):
+        obs, r, done, info = env.step(mid + 0.2 * half * torch.randn((n, 28), device=DEV))
+    torch.cuda.synchronize()
+    assert obs.shape == (n, 1312) and torch.isfinite(obs).all() and torch.isfinite(r).all()
+    assert smoke_impl.oracle_compare(env, clips, tiled, obs, r) == n
+    env.reset(torch.arange(0, n, 2, device=DEV))
+    obs, r, done, info = env.step(mid + 0.2 * half * torch.randn((n, 28), device=DEV))
+    torch.cuda.synchronize()
+    assert smoke_impl.oracle_compare(env, clips, tiled, obs, r) == n
