@@ -243,6 +243,8 @@ int parc_motion_lib_build(void *stream, parc_char_model_t model, parc_motion_lib
  * global plan clock, mgdm_env.py:476-480 - not env time + offset), and no end-of-clip termination (DeepMimicEnv.update_done's rule
  * dm_env.py:746-783 does not apply; the sub-env's termination is RefCharEnv.update_done, mgdm_dm_util.py:205-230). */
 #define PARC_POST_PLAN_CLOCK 128
+/* every documented bit; parc_track_post_step returns PARC_EINVAL for any other bit of `what` */
+#define PARC_POST_ALL 255
 /* Two kernels since round 3: bit0 (the reference STATE: ref_* buffers, bit5's character state) is `ref_state_kernel`, enqueued first;
  * bits 1-3 / 6 the fused `track_post_kernel`, whose reward wave samples the reference pose itself.  They write disjoint outputs and
  * read nothing of each other.  A call with bit0 only (a restart's first launch) enqueues the small kernel alone. */
@@ -385,15 +387,6 @@ int parc_relu_bwd_bias_grad(void *stream, int64_t rows, int dim, float *gy, cons
 /* out[c] <- sum_r w[r] * x[r, c] (x [rows, dim] row-major, dim % 4 == 0, 16-byte aligned; workspace as above): the weight gradient of
  * a Linear layer with one output (the value head `_critic_out`, learning/ppo_model.py:14-22), fixed summation order. */
 int parc_weighted_colsum(void *stream, int64_t rows, int dim, const float *x, const float *w, float *out, float *workspace);
-
-/* ---- measurement knobs (exported for tools/bench_kernels.py; not part of the stable ABI, defaults are the product path) ----
- * parc_tune_hf_envs_per_block(1|2|4|8): envs per workgroup of the standalone heightmap kernel;
- * parc_tune_hf_ablation(0..5): timing-only variants of it (outputs wrong for != 0);
- * bits 16/17/18 of `what` in parc_track_post_step drop the target / reference / character waves (timing only). */
-int parc_tune_hf_envs_per_block(int envs_per_block);
-/* 128-thread env groups per workgroup (1|2|4|8; 2 envs per group): fewer, fatter workgroups for the same number of waves */
-int parc_tune_hf_groups(int groups);
-int parc_tune_hf_ablation(int variant);
 
 int parc_abi_version(void);
 

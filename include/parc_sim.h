@@ -61,7 +61,7 @@ int parc_sim_step(void *stream, const parc_sim_model_t *model, parc_terrain_t te
                   const float *action, const float *action_low, const float *action_high, int n_substeps, float h);
 
 /* The same step, followed by IGEnv._update_time (envs/ig_env.py:862-865) inside the launch: timestep_buf[e] += 1 (int32),
- * time_buf[e] = timestep_buf[e] * step_dt.  Body-per-lane kernel only (PARC_EUNSUPPORTED for the reference kernel). */
+ * time_buf[e] = timestep_buf[e] * step_dt.  */
 int parc_sim_step_tick(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,
                        float *dof_state, float *rigid_body_state, float *contact_forces, const float *env_offsets,
                        const float *action, const float *action_low, const float *action_high, int n_substeps, float h,
@@ -76,11 +76,6 @@ int parc_sim_refresh_bodies(void *stream, const parc_sim_model_t *model, int n_e
 /* Same for every env whose mask[e] != 0 (device-side reset, no index list). */
 int parc_sim_refresh_bodies_masked(void *stream, const parc_sim_model_t *model, int n_envs, const int32_t *mask,
                                    const float *root_state, const float *dof_state, float *rigid_body_state, float *contact_forces);
-
-/* measurement knobs (not part of the stable ABI): parc_tune_sim_variant(1 = body-per-lane kernel, default; 0 = one env per
- * lane, the single-source reference core), parc_tune_sim_threads(8|16|32|64) lanes per workgroup of variant 0 */
-int parc_tune_sim_variant(int variant);
-int parc_tune_sim_threads(int threads);
 
 int parc_sim_abi(void);
 

@@ -14,7 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libparc_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["parc_kin.hip", "parc_sim.hip", "parc_sim_ref.hip", "parc_ppo.hip", "parc_terrain.hip"]
+SOURCES = ["parc_kin.hip", "parc_sim.hip", "parc_ppo.hip", "parc_terrain.hip"]
+# The diagnostics library (tools/parc_diag.py; never loaded by this package): the same sources with -DPARC_DIAG_BUILD (timing-ablation bits of
+# parc_track_post_step, the heightmap kernel's measurement knobs) plus the one-env-per-lane reference formulation of the simulator.
+DIAG_LIB_PATH = os.path.join(LIB_DIR, "libparc_hip_diag.so")
+DIAG_SOURCES = SOURCES + ["parc_sim_ref.hip"]
 
 MAX_BODIES = 16
 MAX_DOFS = 64
@@ -97,7 +101,7 @@ class PPOCfgS(ctypes.Structure):
 _lib = None
 
 
-# per-source optimisation level.  parc_sim_ref.hip (the one-env-per-lane reference kernel, not launched by the product) is built at
+# per-source optimisation level.  parc_sim_ref.hip (the one-env-per-lane reference kernel, diagnostics library only) is built at
 # -O2: at -O3 hipcc (ROCm 7.2, gfx950) miscompiles it (results diverge from the -O0/-O1/-O2 builds and from the g++ host build of the
 # same source; GVN scalar PRE on the unrolled 3x3 helpers).  The product's simulator kernels (parc_sim.hip) are correct at
 # every level (profiles/r02_sim_o3_bisect.txt) and are built at whichever measured faster.
@@ -105,6 +109,7 @@ OPT_LEVEL = {"parc_kin.hip": os.environ.get("PARC_KIN_OPT", "-O3 -fno-slp-vector
 
 
 DIGEST_PATH = os.path.join(LIB_DIR, "libparc_hip.digest")
+DIAG_DIGEST_PATH = os.path.join(LIB_DIR, "libparc_hip_diag.digest")
 
 
 def source_digest():
@@ -115,47 +120,52 @@ def source_digest():
     h = hashlib.sha256()
     inc = os.path.join(os.path.dirname(_HERE), "include")
     files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))] + \
-        [os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")]
+        ([os.path.join(inc, f) for f in sorted(os.listdir(inc)) if f.endswith(".h")] if os.path.isdir(inc) else [])
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(repr((SOURCES, sorted(OPT_LEVEL.items()))).encode())
+    h.update(repr((DIAG_SOURCES, sorted(OPT_LEVEL.items()))).encode())
     return h.hexdigest()
 
 
-def _stored_digest():
+def _stored_digest(path=DIGEST_PATH):
     try:
-        with open(DIGEST_PATH) as f:
+        with open(path) as f:
             return f.read().strip()
     except OSError:
         return None
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP sources for gfx950 into parc_amd/lib/libparc_hip.so (hipcc cross-compiles without a GPU)."""
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+def build(force=False, verbose=False, diag=False):
+    """Compile the HIP sources for gfx950 into parc_amd/lib/libparc_hip.so (hipcc cross-compiles without a GPU).
+    diag=True: the diagnostics library libparc_hip_diag.so instead (tools/parc_diag.py is its only user)."""
+    lib_path, digest_path, sources = (DIAG_LIB_PATH, DIAG_DIGEST_PATH, DIAG_SOURCES) if diag else (LIB_PATH, DIGEST_PATH, SOURCES)
     digest = source_digest()
-    if not force and os.path.exists(LIB_PATH) and _stored_digest() == digest:
-        return LIB_PATH
-    obj_dir = os.path.join(LIB_DIR, "obj")
+    if not force and os.path.exists(lib_path) and _stored_digest(digest_path) == digest:
+        return lib_path
+    obj_dir = os.path.join(LIB_DIR, "obj_diag" if diag else "obj")
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    for s in srcs:
+    objs, procs = [], []
+    for s in sources:
         o = os.path.join(obj_dir, s.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950"] + OPT_LEVEL.get(s, "-O3").split() + ["-std=c++17", "-fPIC", "-c", "-o", o, os.path.join(CSRC, s)]
+        cmd = [hipcc, "--offload-arch=gfx950"] + OPT_LEVEL.get(s, "-O3").split() + (["-DPARC_DIAG_BUILD"] if diag else []) + \
+            ["-std=c++17", "-fPIC", "-c", "-o", o, os.path.join(CSRC, s)]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        procs.append((cmd, subprocess.Popen(cmd)))      # the translation units are independent: compile them side by side
         objs.append(o)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    with open(DIGEST_PATH, "w") as f:
+    with open(digest_path, "w") as f:
         f.write(digest + "\n")
-    return LIB_PATH
+    return lib_path
 
 
 def lib():
@@ -164,7 +174,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libparc_hip.so is not built ({}); run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "-- there is no CPU fallback".format(LIB_PATH))
-        if _stored_digest() != source_digest() and not os.environ.get("PARC_ALLOW_STALE_LIB"):
+        if _stored_digest() != source_digest():
             raise RuntimeError("libparc_hip.so was built from other sources than the ones beside it (csrc/, include/): rebuild with "
                                "`python -c 'import __graft_entry__ as g; g.build()'` - calling a stale library would hand it argument "
                                "structs of another layout")

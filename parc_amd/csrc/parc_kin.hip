@@ -194,9 +194,18 @@ __global__ __launch_bounds__(256) void hf_gather_scalar_kernel(int n_envs, const
     out[(size_t)e * out_stride + p] = fminf(fmaxf(v, min_h), max_h);
 }
 
+// Measurement knobs of the standalone heightmap kernel exist only in the diagnostics build (-DPARC_DIAG_BUILD: tools/parc_diag.py builds
+// libparc_hip_diag.so, tools/parc_diag.h declares its extra entry points); the product library has them as constants and
+// exports no setter, so nothing a test or tool does can leave a later product launch on another kernel.
+#ifdef PARC_DIAG_BUILD
 static int g_hf_epb = 2;
-static int g_hf_groups = 1;   // 128-thread env groups per workgroup (1, 2, 4, 8): tuning knob
-static int g_hf_abl = 0;  // diagnostic ablations (timing only, outputs wrong): 1 no gather, 2 no stores
+static int g_hf_groups = 1;   // 128-thread env groups per workgroup (1, 2, 4, 8)
+static int g_hf_abl = 0;      // timing-only ablations (outputs wrong): 1 no gather, 2 no stores, ...
+#define PARC_DIAG(...) __VA_ARGS__
+#else
+static constexpr int g_hf_epb = 2;
+#define PARC_DIAG(...)
+#endif
 
 static int launch_hf(bool from_state, void *stream, int n_envs, const float *ray_xy, int n_points, const float *root,
                      const float *aux, parc_terrain_t ter, float min_h, float max_h, float *out, int64_t out_stride) {
@@ -228,6 +237,7 @@ static int launch_hf(bool from_state, void *stream, int n_envs, const float *ray
     hipLaunchKernelGGL((hf_gather_kernel<FS, EPB>), dim3((n_envs + EPB - 1) / EPB), dim3(HF_THREADS), 0, st, n_envs, ray_xy, \
                        n_points, root, aux, ter, min_h, max_h, out, out_stride, head)
     const int epb = g_hf_epb;
+#ifdef PARC_DIAG_BUILD
 #define HF_LAUNCH_G(AB, G)                                                                                                              \
     hipLaunchKernelGGL((hf_gather_kernel<true, 2, AB, G>), dim3((n_envs + 2 * G - 1) / (2 * G)), dim3(HF_THREADS * G), 0, st, n_envs, ray_xy, \
                        n_points, root, aux, ter, min_h, max_h, out, out_stride, head)
@@ -245,7 +255,9 @@ static int launch_hf(bool from_state, void *stream, int n_envs, const float *ray
     else if (from_state && g_hf_abl == 3) HF_LAUNCH3(true, 2, 3);
     else if (from_state && g_hf_abl == 4) HF_LAUNCH3(true, 2, 4);
     else if (from_state && g_hf_abl == 5) HF_LAUNCH3(true, 2, 5);
-    else if (from_state) {
+    else
+#endif
+    if (from_state) {
         if (epb == 1) HF_LAUNCH(true, 1);
         else if (epb == 4) HF_LAUNCH(true, 4);
         else if (epb == 8) HF_LAUNCH(true, 8);
@@ -261,6 +273,7 @@ static int launch_hf(bool from_state, void *stream, int n_envs, const float *ray
     return PARC_OK;
 }
 
+#ifdef PARC_DIAG_BUILD
 // tuning knob (envs per workgroup of the heightmap kernel: 1, 2, 4 or 8); not part of the stable ABI
 extern "C" int parc_tune_hf_groups(int g) {
     if (g != 1 && g != 2 && g != 4 && g != 8) return PARC_EINVAL;
@@ -277,6 +290,7 @@ extern "C" int parc_tune_hf_envs_per_block(int epb) {
     g_hf_epb = epb;
     return PARC_OK;
 }
+#endif
 
 extern "C" int parc_refresh_ray_obs_hfs(void *stream, int n_envs, const float *ray_xy, int n_points, const float *root_pos_xyz,
                                         const float *heading, parc_terrain_t terrain, float min_h, float max_h, float *out,
@@ -1096,7 +1110,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
     // else to do in front of the barrier) instead of as four (character and reference wave: nine) vector loads in every pose wave: lrot 4 | lt 3, parent | depth, key slot,
     // | joint type, first dof, - | hinge axis 3, -
     __shared__ __attribute__((aligned(16))) float bodyk[GRP][16];
-    if (what & 0x100000) return;                     // (timing diagnostic: the launch alone)
+    PARC_DIAG(if (what & 0x100000) return;)          // (timing diagnostic: the launch alone)
     const int tid = threadIdx.x;
     const int wv = tid >> 6, gg = (tid & 63) >> 4, b = tid & 15;
     const int B = m.num_bodies, J = B - 1, D = m.dof_size, K = cfg.num_key_bodies, S = cfg.num_tar_steps;
@@ -1210,7 +1224,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         gpr = hf_env_params<true>(ghe, buf.root_state, buf.env_offsets, ter, 1.0f / ter.dx, 1.0f / ter.dy);
         glive = hel < n_total && (!masked || buf.env_mask[helc] != 0);
     }
-    if (what & 0x200000) return;                     // (timing diagnostic: launch + phase 0 + heightmap gather, no barrier)
+    PARC_DIAG(if (what & 0x200000) return;)          // (timing diagnostic: launch + phase 0 + heightmap gather, no barrier)
     if (is_ref && gg == 0) {
         const fk_consts k = fk_consts_of(m, b);
         int ks = -1;
@@ -1239,9 +1253,9 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         return k;
     };
     // diagnostic role ablations (timing only): bits 16/17/18 drop the target / reference / character waves
-    if (((what & 0x10000) && is_tar) || ((what & 0x20000) && is_ref) || ((what & 0x40000) && is_char)) return;
+    PARC_DIAG(if (((what & 0x10000) && is_tar) || ((what & 0x20000) && is_ref) || ((what & 0x40000) && is_char)) return;)
     if (is_gat) {
-        if (what & 0x80000) return;                              // (timing diagnostic: no heightmap wave)
+        PARC_DIAG(if (what & 0x80000) return;)                   // (timing diagnostic: no heightmap wave)
         const int P = cfg.num_ray_points;
         const float max_i = (float)(ter.dim_x - 1), max_j = (float)(ter.dim_y - 1);
         // straight into the observation row; the 441 columns are a third of the row's bytes.  The launch is bound by the NUMBER of
@@ -1296,7 +1310,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             jq = slerp(q4p{mk2(xa.x, xb.x), mk2(xa.y, xb.y), mk2(xa.z, xb.z), mk2(xa.w, xb.w)},
                        q4p{mk2(ya.x, yb.x), mk2(ya.y, yb.y), mk2(ya.z, yb.z), mk2(ya.w, yb.w)}, blend);
         }
-        if ((what & 0x400000) && jq.x.x != 123.f) return;       // (timing diagnostic: a target wave up to its blended joint rotations)
+        PARC_DIAG(if ((what & 0x400000) && jq.x.x != 123.f) return;)       // (timing diagnostic: a target wave up to its blended joint rotations)
         // root position: lerp of the two rows, + loop shift, + tile offset (the order of query_root_pos and dm_env.py:604-615)
         v3p p_root;
         {
@@ -1319,7 +1333,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         q4p rot;
         group_fk<false>(fk_consts_lds(), m.max_depth, p_root, jq, jq, pos, rot);
         asm volatile("" ::: "memory");                          // the simulated root pose and heading are only needed from here on
-        if ((what & 0x800000) && pos.x.x != 123.f) return;      // (timing diagnostic: a target wave up to the end of its tree walk)
+        PARC_DIAG(if ((what & 0x800000) && pos.x.x != 123.f) return;)      // (timing diagnostic: a target wave up to the end of its tree walk)
         p_root = shfl16(pos, 0);
         const float4 e0 = reinterpret_cast<const float4 *>(envd[le])[0], e1 = reinterpret_cast<const float4 *>(envd[le])[1],
                      e2 = reinterpret_cast<const float4 *>(envd[le])[2];
@@ -1346,7 +1360,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             ka[0] = kp.x.x, ka[1] = kp.y.x, ka[2] = kp.z.x;
             ka[Wt] = kp.x.y, ka[Wt + 1] = kp.y.y, ka[Wt + 2] = kp.z.y;
         }
-        if ((what & 0x1000000) && seg[b] != 123.f) return;      // (timing diagnostic: a target wave without its stores)
+        PARC_DIAG(if ((what & 0x1000000) && seg[b] != 123.f) return;)      // (timing diagnostic: a target wave without its stores)
         stage_out(seg, row + Wc + sA * Wt, hasB ? 2 * Wt : Wt, b);
         return;
     }
@@ -1671,6 +1685,9 @@ extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_
                                     parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
                                     const float *ray_xy) {
     if (!model_ok(model) || mlib.num_bodies != model.num_bodies || mlib.dof_size != model.dof_size) return PARC_EINVAL;
+#ifndef PARC_DIAG_BUILD
+    if (what & ~PARC_POST_ALL) return PARC_EINVAL;   // only the documented PARC_POST_* bits (the timing-ablation bits exist in the diagnostics build only)
+#endif
     if (cfg.num_tar_steps < 0 || cfg.num_tar_steps > PARC_MAX_TAR_STEPS || cfg.num_key_bodies > PARC_MAX_KEY_BODIES) return PARC_EUNSUPPORTED;
     const int B = model.num_bodies, J = B - 1, D = model.dof_size, K = cfg.num_key_bodies, S = cfg.num_tar_steps;
     const int row_len = (12 + 6 * J + D + 3 * K) + S * (9 + 6 * J + 3 * K) + S * B + B;

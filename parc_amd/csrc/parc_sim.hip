@@ -1,11 +1,11 @@
 // Device entry points of the articulated-body simulator.  The product kernels are the body-per-lane ones below (16 lanes per env, 4 envs
 // per 64-thread workgroup, parc_sim_bpl.h); the one-env-per-lane reference formulation is a separate translation unit
-// (parc_sim_ref.hip, reached through parc_tune_sim_variant(0)).
+// (parc_sim_ref.hip) that is compiled into the diagnostics library only (tools/parc_diag.py, parc_diag_sim_step_env_per_lane).
 #include <hip/hip_runtime.h>
 
 #include "parc_sim_bpl.h"
 #include "parc_sim_core.h"
-#include "parc_sim_internal.h"
+#include "../../include/parc_sim.h"
 
 // body-per-lane step: 16 lanes per env, 4 envs per 64-thread workgroup (parc_sim_bpl.h)
 __global__ __launch_bounds__(64) void sim_step_bpl_kernel(const parc_sim_model_t *__restrict__ model, parc_terrain_t ter, int n_envs,
@@ -64,14 +64,7 @@ __global__ __launch_bounds__(64) void sim_refresh_bpl_kernel(const parc_sim_mode
     store_lane_state<false>(L, b, maxd, x, nullptr, nullptr, rigid_body_state + 13 * (size_t)B * e, contact_forces + 3 * (size_t)B * e);
 }
 
-// 1 = body-per-lane kernel (default), 0 = one env per lane (the single-source reference core)
-static int g_sim_variant = 1;
-static const int model_bodies_hint = PARC_SIM_MAX_BODIES;      // PARC_SIM_MAX_BODIES == lanes per env
-extern "C" int parc_tune_sim_variant(int v) {
-    if (v != 0 && v != 1) return PARC_EINVAL;
-    g_sim_variant = v;
-    return PARC_OK;
-}
+static_assert(PARC_SIM_MAX_BODIES <= BPL_G, "one body per lane: a 16-lane group holds one env");
 
 static int sim_step_impl(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,
                          float *dof_state, float *rigid_body_state, float *contact_forces, const float *env_offsets, const float *action,
@@ -79,16 +72,11 @@ static int sim_step_impl(void *stream, const parc_sim_model_t *model, parc_terra
                          float step_dt) {
     if (!model || n_envs < 0 || n_substeps <= 0 || !(h > 0.f) || !terrain.hf) return PARC_EINVAL;
     if (n_envs == 0) return PARC_OK;
-    if (g_sim_variant == 1 && model_bodies_hint <= BPL_G) {
-        hipLaunchKernelGGL(sim_step_bpl_kernel, dim3((n_envs + BPL_EPB - 1) / BPL_EPB), dim3(64), 0, (hipStream_t)stream, model, terrain, n_envs,
-                           root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low, action_high, n_substeps, h,
-                           timestep, time_buf, step_dt);
-        hipError_t e1 = hipGetLastError();
-        return e1 == hipSuccess ? PARC_OK : (int)e1;
-    }
-    if (timestep) return PARC_EUNSUPPORTED;          // the one-env-per-lane reference kernel does not carry the clock
-    return parc_sim_launch_env_per_lane(stream, model, terrain, n_envs, root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action,
-                                        action_low, action_high, n_substeps, h);
+    hipLaunchKernelGGL(sim_step_bpl_kernel, dim3((n_envs + BPL_EPB - 1) / BPL_EPB), dim3(64), 0, (hipStream_t)stream, model, terrain, n_envs,
+                       root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low, action_high, n_substeps, h,
+                       timestep, time_buf, step_dt);
+    hipError_t e1 = hipGetLastError();
+    return e1 == hipSuccess ? PARC_OK : (int)e1;
 }
 
 extern "C" int parc_sim_step(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,

@@ -120,7 +120,7 @@ struct ContactEval {
 };
 
 // one sample sphere of this lane's body: the same arithmetic as pass1 / report_contacts of the reference core
-__device__ __forceinline__ ContactEval eval_contact(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_off, const Kin &k, int s) {
+__device__ __forceinline__ ContactEval eval_contact(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_off, const Kin &k, int s, float h) {
     ContactEval ce;
     ce.hit = false;
     V3 rb = ld(m.sph_pos[s]);
@@ -134,7 +134,7 @@ __device__ __forceinline__ ContactEval eval_contact(const parc_sim_model_t &m, c
     V3 vpb = k.v.l + cross(k.v.a, ce.rc);
     float vn = dot(vpb, ce.nb);
     float d_eff = depth < m.contact_max_pen ? depth : m.contact_max_pen;
-    ce.cn = vn < 0.f ? m.contact_cn : 0.f;
+    ce.cn = m.contact_cn;         // damper on approach AND on rebound (restitution 0); fn0 <= 0 below = no adhesion
     float fn0 = m.contact_kn * d_eff - ce.cn * vn;
     if (fn0 <= 0.f) return ce;
     V3 vt = vpb - vn * ce.nb;
@@ -143,6 +143,10 @@ __device__ __forceinline__ ContactEval eval_contact(const parc_sim_model_t &m, c
     float ct_cone = m.friction_mu * fn0 * p_rcp(vtn > 1e-4f ? vtn : 1e-4f);
     if (ct_cone < ce.ct) ce.ct = ct_cone;
     ce.F0 = fn0 * ce.nb - ce.ct * vt;
+    // the known part of the contact point's world-velocity change, h w x v_centre (the body frame turns during the step): parc_sim_core.h pass1
+    V3 wv = h * cross(k.v.a, k.v.l + cross(k.v.a, rb));
+    float wvn = dot(wv, ce.nb);
+    ce.F0 = ce.F0 - ((ce.cn + h * m.contact_kn) * wvn) * ce.nb - ce.ct * (wv - wvn * ce.nb);
     ce.hit = true;
     return ce;
 }
@@ -212,7 +216,7 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
     // ---- contacts of this body's sample spheres: implicit spring-damper + regularised friction
     for (unsigned long long mm = valid ? L.sph : 0ull; mm; mm &= mm - 1) {
         const int s = __ffsll((long long)mm) - 1;
-        ContactEval ce = eval_contact(m, ter, env_off, k, s);
+        ContactEval ce = eval_contact(m, ter, env_off, k, s, h);
         if (!ce.hit) continue;
         if (n_hit < BPL_CC_SLOTS) {
             float *o = cc + n_hit * BPL_CC_FLOATS;
@@ -392,7 +396,7 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
             Fb = Fb + F;
         }
         for (unsigned long long mm = overflow; mm; mm &= mm - 1) {      // more simultaneous contacts than slots: re-evaluate
-            ContactEval ce = eval_contact(m, ter, env_off, k, __ffsll((long long)mm) - 1);
+            ContactEval ce = eval_contact(m, ter, env_off, k, __ffsll((long long)mm) - 1, h);
             V3 dv = h * (a.l + cross(a.a, ce.rc));
             float dvn = dot(dv, ce.nb);
             V3 F = ce.F0 - (ce.cn + h * m.contact_kn) * dvn * ce.nb - ce.ct * (dv - dvn * ce.nb);
@@ -405,12 +409,14 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
     // ---- semi-implicit Euler
     const float wmax = m.max_angular_velocity;
     if (b == 0) {
+        // linear velocity in WORLD coordinates, v_w += h R (a_sp + w x v): parc_sim_core.h, substep
+        const V3 vw_new = mul(k.R, x.root_vel.l + h * (a.l + cross(x.root_vel.a, x.root_vel.l)));
         x.root_vel.a = x.root_vel.a + h * a.a;
-        x.root_vel.l = x.root_vel.l + h * a.l;
         float wn = p_sqrt(dot(x.root_vel.a, x.root_vel.a));
         if (wn > wmax) x.root_vel.a = (wmax * p_rcp(wn)) * x.root_vel.a;
-        x.root_pos = x.root_pos + h * mul(k.R, x.root_vel.l);
         x.root_rot = qnormalize(qmul(x.root_rot, exp_to_q(h * x.root_vel.a)));
+        x.root_pos = x.root_pos + h * vw_new;
+        x.root_vel.l = mulT(qmat(x.root_rot), vw_new);
     } else if (L.jt == PARC_JOINT_SPHERICAL) {
         float wn = p_sqrt(dot(x.jw, x.jw));
         if (wn > wmax) x.jw = (wmax * p_rcp(wn)) * x.jw;

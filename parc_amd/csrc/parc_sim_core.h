@@ -541,7 +541,7 @@ PARC_HD void pass1(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_
         V3 nb = mulT(s.R[b], n);
         float vn = dot(vpb, nb);
         float d_eff = depth < m.contact_max_pen ? depth : m.contact_max_pen;
-        float cn = vn < 0.f ? m.contact_cn : 0.f;
+        float cn = m.contact_cn;      // damper on approach AND on rebound (restitution 0, envs/ig_env.py:517,733); fn0 <= 0 below = no adhesion
         float fn0 = m.contact_kn * d_eff - cn * vn;
         if (fn0 <= 0.f) continue;
         V3 vt = vpb - vn * nb;
@@ -550,6 +550,16 @@ PARC_HD void pass1(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_
         float ct_cone = m.friction_mu * fn0 * p_rcp(vtn > 1e-4f ? vtn : 1e-4f);
         if (ct_cone < ct) ct = ct_cone;
         V3 F0 = fn0 * nb - ct * vt;
+        // The impedance Z acts on the change of the contact point's WORLD velocity over the step.  The contact point of a sample sphere is
+        // c - rad n with c the sphere's centre (a material point) and n fixed in the world, so that change is
+        // h R (a_sp.l + alpha x rc + w x v_c), v_c = v + w x rb the centre's velocity: the first two terms are the unknown the impedance
+        // multiplies, the third (the body frame turns by h w during the step) is known and belongs to the explicit force - without it a
+        // spinning body's contact predicts an approach speed -h (w x v_c).n that is not there and leaves the friction cone.
+        {
+            V3 wv = h * cross(s.v[b].a, s.v[b].l + cross(s.v[b].a, rb));
+            float wvn = dot(wv, nb);
+            F0 = F0 - ((cn + h * m.contact_kn) * wvn) * nb - ct * (wv - wvn * nb);
+        }
         // Z = (cn + h kn) n n^T + ct (1 - n n^T), body coordinates
         M3 Z = add(ident(ct), outer(((cn + h * m.contact_kn) - ct) * nb, nb));
         M3 Sr = skew(rc);
@@ -582,7 +592,7 @@ PARC_HD void report_contacts(const parc_sim_model_t &m, const parc_terrain_t &te
         V3 nb = mulT(s.R[b], n);
         float vn = dot(vpb, nb);
         float d_eff = depth < m.contact_max_pen ? depth : m.contact_max_pen;
-        float cn = vn < 0.f ? m.contact_cn : 0.f;
+        float cn = m.contact_cn;      // damper on approach AND on rebound (restitution 0, envs/ig_env.py:517,733); fn0 <= 0 below = no adhesion
         float fn0 = m.contact_kn * d_eff - cn * vn;
         if (fn0 <= 0.f) continue;
         V3 vt = vpb - vn * nb;
@@ -591,7 +601,7 @@ PARC_HD void report_contacts(const parc_sim_model_t &m, const parc_terrain_t &te
         float ct_cone = m.friction_mu * fn0 * p_rcp(vtn > 1e-4f ? vtn : 1e-4f);
         if (ct_cone < ct) ct = ct_cone;
         V3 F0 = fn0 * nb - ct * vt;
-        V3 dv = h * (s.a[b].l + cross(s.a[b].a, rc));
+        V3 dv = h * (s.a[b].l + cross(s.a[b].a, rc) + cross(s.v[b].a, s.v[b].l + cross(s.v[b].a, rb)));   // world-velocity change of the contact point (pass1)
         float dvn = dot(dv, nb);
         V3 F = F0 - (cn + h * m.contact_kn) * dvn * nb - ct * (dv - dvn * nb);
         float fnn = dot(F, nb);
@@ -742,15 +752,19 @@ PARC_HD void substep(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 en
     }
     if (cweight > 0.f) report_contacts(m, ter, env_off, s, h, cweight, x);
     // ---- integrate (semi-implicit Euler): velocities first, then positions with the new velocities
+    // The root's linear velocity advances in WORLD coordinates: v_w += h R (a_sp + w x v) (the classical acceleration of the origin).
+    // Advancing its body coordinates by h a_sp instead turns them by (1 - h [w]), which stretches |v| by 1 + h^2 w^2 / 2 per substep (16 %
+    // per second at 6 rad/s and h = 1/120: linear momentum of a tumbling character was not conserved - round 4, spinning-ball test).
+    const V3 vw_new = mul(s.R[0], x.root_vel.l + h * (s.a[0].l + cross(x.root_vel.a, x.root_vel.l)));
     x.root_vel.a = x.root_vel.a + h * s.a[0].a;
-    x.root_vel.l = x.root_vel.l + h * s.a[0].l;
     const float wmax = m.max_angular_velocity;
     {
         float wn = p_sqrt(dot(x.root_vel.a, x.root_vel.a));
         if (wn > wmax) x.root_vel.a = (wmax * p_rcp(wn)) * x.root_vel.a;
     }
-    x.root_pos = x.root_pos + h * mul(s.R[0], x.root_vel.l);
     x.root_rot = qnormalize(qmul(x.root_rot, exp_to_q(h * x.root_vel.a)));
+    x.root_pos = x.root_pos + h * vw_new;
+    x.root_vel.l = mulT(qmat(x.root_rot), vw_new);         // back to the coordinates of the new body frame
     PARC_LOOP(7)
     for (int i = 1; i < B; ++i) {
         const int jt = m.joint_type[i];

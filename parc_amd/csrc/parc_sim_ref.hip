@@ -1,13 +1,14 @@
 // The one-env-per-lane formulation of the simulator as a device kernel: the single-source reference core (parc_sim_core.h, also built
 // for the host by oracle/sim_host.cpp) with 64 envs per workgroup and its per-body arrays in scratch.  NOT what the product launches
-// (that is sim_step_bpl_kernel in parc_sim.hip); kept because every invariant test runs on both formulations and the device build of
-// this one is compared with its host build.  It lives in its own translation unit because hipcc (ROCm 7.2, gfx950) miscompiles THIS
+// (that is sim_step_bpl_kernel in parc_sim.hip) and NOT in the product library: this file is compiled into the diagnostics library only
+// (tools/parc_diag.py, libparc_hip_diag.so; entry point parc_diag_sim_step_env_per_lane, tools/parc_diag.h), kept because every
+// invariant test runs on both formulations and the device build of this one is compared with its host build.  It lives in its own translation unit because hipcc (ROCm 7.2, gfx950) miscompiles THIS
 // kernel at -O3 (GVN scalar PRE on the fully unrolled 3x3 helpers, profiles/r02_sim_o3_bisect.txt): this file is built at -O2, the
 // product kernels are not held back by it.
 #include <hip/hip_runtime.h>
 
 #include "parc_sim_core.h"
-#include "parc_sim_internal.h"
+#include "../../include/parc_sim.h"
 
 #define SIM_THREADS 64
 
@@ -26,21 +27,17 @@ __global__ __launch_bounds__(SIM_THREADS) void sim_step_kernel(const parc_sim_mo
                        n_sub, h, s);
 }
 
-// envs (= lanes) per workgroup: 4096 envs are only 64 full waves on a 1024-SIMD chip, so partially filled waves on more CUs can win;
-// tuning knob, not part of the stable ABI
-static int g_sim_threads = SIM_THREADS;
-extern "C" int parc_tune_sim_threads(int t) {
-    if (t != 8 && t != 16 && t != 32 && t != 64) return PARC_EINVAL;
-    g_sim_threads = t;
-    return PARC_OK;
-}
-
-int parc_sim_launch_env_per_lane(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,
-                                 float *dof_state, float *rigid_body_state, float *contact_forces, const float *env_offsets,
-                                 const float *action, const float *action_low, const float *action_high, int n_substeps, float h) {
-    const int th = g_sim_threads;
-    hipLaunchKernelGGL(sim_step_kernel, dim3((n_envs + th - 1) / th), dim3(th), 0, (hipStream_t)stream, model, terrain, n_envs, root_state,
-                       dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low, action_high, n_substeps, h);
+// threads = envs (= lanes) per workgroup (8, 16, 32 or 64): 4096 envs are only 64 full waves on a 1024-SIMD chip, so partially filled
+// waves on more CUs can win.  A per-call argument: no process-global state.
+extern "C" int parc_diag_sim_step_env_per_lane(void *stream, const parc_sim_model_t *model, parc_terrain_t terrain, int n_envs, float *root_state,
+                                               float *dof_state, float *rigid_body_state, float *contact_forces, const float *env_offsets,
+                                               const float *action, const float *action_low, const float *action_high, int n_substeps, float h,
+                                               int threads) {
+    if (!model || n_envs < 0 || n_substeps <= 0 || !(h > 0.f) || !terrain.hf) return PARC_EINVAL;
+    if (threads != 8 && threads != 16 && threads != 32 && threads != 64) return PARC_EINVAL;
+    if (n_envs == 0) return PARC_OK;
+    hipLaunchKernelGGL(sim_step_kernel, dim3((n_envs + threads - 1) / threads), dim3(threads), 0, (hipStream_t)stream, model, terrain, n_envs,
+                       root_state, dof_state, rigid_body_state, contact_forces, env_offsets, action, action_low, action_high, n_substeps, h);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }

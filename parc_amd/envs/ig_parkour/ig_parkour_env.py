@@ -502,13 +502,8 @@ class IGParkourEnv(base_env.BaseEnv):
         sim_args = (_hip.stream(), self._sim_model.device_ptr(self._device), c._terrain_struct, self._num_envs, _hip.ptr(c.root_state),
                     _hip.ptr(c.dof_state), _hip.ptr(c.rigid_body_state), _hip.ptr(c.contact_forces), _hip.ptr(c.env_offsets), _hip.ptr(act),
                     _hip.ptr(self._action_bound_low), _hip.ptr(self._action_bound_high), self._sim_steps * self._substeps, self._sim_h)
-        rc = L.parc_sim_step_tick(*sim_args, _hip.ptr(self._timestep_buf), _hip.ptr(self._time_buf), float(self._timestep))
-        if rc == -2:                 # the one-env-per-lane reference kernel (parc_tune_sim_variant(0)) does not carry the clock
-            _hip.check(L.parc_sim_step(*sim_args), "parc_sim_step")
-            self._timestep_buf += 1
-            torch.mul(self._timestep_buf, self._timestep, out=self._time_buf)
-        else:
-            _hip.check(rc, "parc_sim_step_tick")
+        _hip.check(L.parc_sim_step_tick(*sim_args, _hip.ptr(self._timestep_buf), _hip.ptr(self._time_buf), float(self._timestep)),
+                   "parc_sim_step_tick")
         # _update_misc (incl. the xy target resample) / _update_observations / _update_reward / _update_done in one launch
         c.rand_pool.uniform_()          # all uniforms of this step and of the restarts that follow it (tracker_core.rand_pool)
         c.rand_pool_fresh = True

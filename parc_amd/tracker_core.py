@@ -6,14 +6,11 @@ HIP kernels (include/parc_hip.h).  The env class (parc_amd/envs/ig_parkour/ig_pa
 these tensors under the reference's attribute names.
 """
 import numpy as np
-import os
 
 import torch
 
 from . import _hip
 
-
-_POST_DIAG = int(os.environ.get("PARC_POST_DIAG", "0"), 0)      # role-ablation bits of track_post_kernel, timing runs only
 
 class TrackerConfig:
     """Scalars the kernels need, parsed from the env YAML (PARC/tracker_config/dm_env_default.yaml)."""
@@ -251,8 +248,6 @@ class TrackerCore:
         else:
             n, ids = 0, _hip.c_vp(0)
         timed = self.timing_events is not None and env_ids is None and rows is None and (what & _hip.POST_REWARD_DONE)
-        if _POST_DIAG and env_ids is None and rows is None and (what & _hip.POST_REWARD_DONE):
-            what |= _POST_DIAG                       # timing diagnostics of the step's full launch (tools/rollout_post_stats.sh): results are garbage
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()

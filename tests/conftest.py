@@ -7,6 +7,9 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+TOOLS = os.path.join(REPO, "tools")
+if TOOLS not in sys.path:
+    sys.path.append(TOOLS)          # `import parc_diag`: the diagnostics library's loader (tests of the reference simulator kernel)
 
 GOLDEN = os.path.join(REPO, "tests", "golden")
 

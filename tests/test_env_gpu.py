@@ -443,23 +443,13 @@ def test_fused_reset_sampler_distribution_and_bookkeeping():
 
 
 def test_step_clock_rides_in_the_simulator_launch(env):
-    """IGEnv._update_time inside parc_sim_step_tick: timestep += 1, time = timestep * dt (fp32), same values with the torch fallback
-    of the one-env-per-lane kernel."""
-    from parc_amd import _hip
+    """IGEnv._update_time inside parc_sim_step_tick: timestep += 1, time = timestep * dt (fp32)."""
     env.reset()
     a = torch.zeros((96, 28), device=DEV)
     ts0 = env._timestep_buf.clone()
     env.step(a)
     assert torch.equal(env._timestep_buf, ts0 + 1)
     assert torch.equal(env._time_buf, env._timestep_buf.to(torch.float32) * torch.tensor(env._timestep, dtype=torch.float32, device=DEV))
-    _hip.lib().parc_tune_sim_variant(0)
-    try:
-        ts1 = env._timestep_buf.clone()
-        env.step(a)
-        assert torch.equal(env._timestep_buf, ts1 + 1)
-        assert torch.equal(env._time_buf, env._timestep_buf.to(torch.float32) * torch.tensor(env._timestep, dtype=torch.float32, device=DEV))
-    finally:
-        _hip.lib().parc_tune_sim_variant(1)
 
 
 def test_device_recorder_equals_per_step_host_lists(env, tmp_path):
@@ -524,8 +514,7 @@ def test_config4_parkour_8192_envs_with_record_rollout(tmp_path):
         obs, r, done, info = env.step(a)
     torch.cuda.synchronize()
     assert obs.shape == (n, 1312) and torch.isfinite(obs).all() and torch.isfinite(r).all()
-    ids = np.linspace(0, n - 1, 64).astype(np.int64)
-    assert smoke_impl.oracle_compare(env, clips, tiled, obs, r, ids) == 64
+    assert smoke_impl.oracle_compare(env, clips, tiled, obs, r) == n          # every one of the 8192 envs against the oracle
     hfcols = obs[:, 871:]
     assert float(hfcols.min()) >= -3.0 and float(hfcols.max()) <= 3.0 and float(hfcols.std()) > 0.05
     agent._curr_obs, agent._curr_info = env.reset()
@@ -546,9 +535,10 @@ def test_config4_parkour_8192_envs_with_record_rollout(tmp_path):
     assert d["terrain"]["__class__"] == "util.terrain_util.SubTerrain"
 
 
-@pytest.mark.parametrize("workload,num_envs", [("flat_1clip", 1024), ("iter0_1024clips", 4096)])
+@pytest.mark.parametrize("workload,num_envs", [("flat_1clip", 1024), ("boxes_64clips", 4096), ("iter0_1024clips", 4096)])
 def test_baseline_config_workloads_at_full_size(workload, num_envs):
-    """BASELINE.json configs[1] (1024 envs, flat terrain, one clip) and configs[3]'s single-GPU share (4096 envs on the iter-0 stand-in:
+    """BASELINE.json configs[1] (1024 envs, flat terrain, one clip), configs[2] (4096 envs on procgen box heightfields, 64 clips: the
+    configuration the metric is quoted on and bench.py times) and configs[3]'s single-GPU share (4096 envs on the iter-0 stand-in:
     1024 clips, 32 x 32 tiles, a 1504^2 heightfield and ~83 MB of clip rows, i.e. nothing fits in L2) at their full env counts:
     oracle parity of every env of the full launch, finiteness, per-env independence of the fused post-step kernel (a subset
     launch reproduces the rows of the full launch), and one PPO iteration end to end."""
@@ -556,7 +546,9 @@ def test_baseline_config_workloads_at_full_size(workload, num_envs):
     from parc_amd import _hip, workloads
     torch.manual_seed(0)
     env, clips, tiled = workloads.build_env(workload, num_envs, DEV, seed=0)
-    assert env.get_num_envs() == num_envs and len(clips) == {"flat_1clip": 1, "iter0_1024clips": 1024}[workload]
+    assert env.get_num_envs() == num_envs and len(clips) == {"flat_1clip": 1, "boxes_64clips": 64, "iter0_1024clips": 1024}[workload]
+    if workload == "boxes_64clips":
+        assert tiled[0].shape == (144, 144) and float(tiled[0].std()) > 0.3        # 8 x 8 tiles of 18^2 cells, boxes of U[-3, 3] m
     if workload == "iter0_1024clips":
         assert tiled[0].shape == (1504, 1504) and sum(c["frames"].shape[0] for c in clips) * 448 > 80e6
     obs, info = env.reset()

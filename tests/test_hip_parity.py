@@ -338,8 +338,9 @@ def test_full_size_properties(km, mlib):
 
 @pytest.mark.parametrize("variant,n", [(1, 64), (1, 61), (0, 64)])
 def test_sim_device_matches_host_build(km, variant, n):
-    """Both simulator kernels -- body per lane (variant 1, the default: parc_sim_bpl.h) and one env per lane (variant 0, the
-    single-source core) -- against the HOST build of that core (oracle/sim_host.cpp): a few env steps of random actions
+    """Both simulator kernels -- body per lane (variant 1, the product's: parc_sim_bpl.h, through parc_sim_step) and one env per lane
+    (variant 0, the single-source core; diagnostics library only, tools/parc_diag.py) -- against the HOST build of that core
+    (oracle/sim_host.cpp): a few env steps of random actions
     on a bumpy terrain; n = 61 leaves a partially filled last workgroup.  fp32 with different libm / contraction /
     summation order: tolerance 1e-3 after 3 steps (contacts make the dynamics locally stiff)."""
     from parc_amd import _hip
@@ -347,7 +348,6 @@ def test_sim_device_matches_host_build(km, variant, n):
     from oracle.sim_host import HostSim
     rng = np.random.default_rng(2)
     sm = SimModel(km)
-    assert _hip.lib().parc_tune_sim_variant(variant) == 0
     hf = (rng.random((40, 40)) * 0.3).astype(np.float32)
     host = HostSim(sm.struct, n, hf, [-4.0, -4.0], [0.4, 0.4])
     host.root_state[:, 0:2] = rng.random((n, 2)) * 6.0
@@ -362,14 +362,18 @@ def test_sim_device_matches_host_build(km, variant, n):
     d_hf = T(hf)
     ter = _hip.terrain_struct(d_hf, [-4.0, -4.0], [0.4, 0.4])
     L = _hip.lib()
+    if variant == 0:
+        import parc_diag                  # tools/parc_diag.py (tests/conftest.py puts tools/ on the path)
+        step_fn, extra = parc_diag.lib().parc_diag_sim_step_env_per_lane, (64,)
+    else:
+        step_fn, extra = L.parc_sim_step, ()
     for step in range(3):
         act = (rng.standard_normal((n, 28)) * 0.5).astype(np.float32)
         host.step(act, n_sub=4, h=1.0 / 120.0)
         a = T(act)
-        _hip.check(L.parc_sim_step(_hip.stream(), sm.device_ptr(DEV), ter, n, _hip.ptr(rs), _hip.ptr(ds), _hip.ptr(rb), _hip.ptr(cf),
-                                   _hip.ptr(eo), _hip.ptr(a), _hip.ptr(lo), _hip.ptr(hi), 4, 1.0 / 120.0), "parc_sim_step")
+        _hip.check(step_fn(_hip.stream(), sm.device_ptr(DEV), ter, n, _hip.ptr(rs), _hip.ptr(ds), _hip.ptr(rb), _hip.ptr(cf),
+                           _hip.ptr(eo), _hip.ptr(a), _hip.ptr(lo), _hip.ptr(hi), 4, 1.0 / 120.0, *extra), "parc_sim_step")
         torch.cuda.synchronize()
-    L.parc_tune_sim_variant(1)
     assert torch.isfinite(rs).all() and torch.isfinite(ds).all()
     assert float(np.abs(host.contact_forces).max()) > 10.0           # the scene does have contacts
     close(cf, host.contact_forces, atol=2.0, rtol=2e-2)                # N; forces are stiff in the penetration depth

@@ -29,6 +29,41 @@ def test_library_exports_every_declared_symbol():
     assert L.parc_abi_version() == 1
 
 
+def test_product_library_carries_no_diagnostics():
+    """The timing-ablation bits of parc_track_post_step, the heightmap kernel's measurement knobs and the reference simulator kernel
+    live in the diagnostics library only (tools/parc_diag.py, -DPARC_DIAG_BUILD): the product library answers PARC_EINVAL (-1) to any
+    bit of `what` outside PARC_POST_ALL - before any HIP call, so this runs without a GPU - and exports none of those symbols; no
+    environment variable reaches a launch (PARC_POST_DIAG / PARC_ALLOW_STALE_LIB are gone)."""
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    from parc_amd import _hip
+    from parc_amd.anim.kin_char_model import KinCharModel
+    from parc_amd.assets import humanoid_spec
+    L = _hip.lib()
+    km = KinCharModel("cpu")
+    km.load_char_file(humanoid_spec.write_mjcf())
+    ms = _hip.MotionLibS()
+    ms.num_bodies, ms.dof_size = 15, 28
+    full = _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS
+    for bit in (0x100, 0x10000, 0x80000, 0x100000, 0x200000, 0x1000000, 1 << 30):
+        rc = L.parc_track_post_step(None, km.c_struct(), ms, _hip.TerrainS(), _hip.TrackCfgS(), _hip.EnvBuffersS(), None, 0, full | bit, None)
+        assert rc == -1, (hex(bit), rc)
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", _hip.LIB_PATH], text=True)
+    assert "parc_track_post_step" in syms
+    for forbidden in ("parc_tune_", "parc_diag_", "sim_step_kernel"):
+        assert forbidden not in syms.replace("sim_step_bpl_kernel", ""), forbidden
+    dsyms = subprocess.check_output(["nm", "-D", "--defined-only", _hip.DIAG_LIB_PATH], text=True)
+    for needed in ("parc_tune_hf_ablation", "parc_tune_hf_groups", "parc_tune_hf_envs_per_block", "parc_diag_sim_step_env_per_lane"):
+        assert needed in dsyms, needed
+    hdr = open(os.path.join(REPO, "tools", "parc_diag.h")).read()
+    for name in set(re.findall(r"\bint\s+(parc_[a-z0-9_]+)\s*\(", hdr)):
+        assert name in dsyms, name
+    for src in ("parc_amd/tracker_core.py", "parc_amd/_hip.py"):
+        text = open(os.path.join(REPO, src)).read()
+        assert "PARC_POST_DIAG" not in text and "PARC_ALLOW_STALE_LIB" not in text and "environ.get(\"PARC_POST" not in text
+
+
 def test_mjcf_parser_matches_reference_parse():
     from parc_amd.anim.kin_char_model import KinCharModel
     from parc_amd.assets import humanoid_spec

@@ -12,6 +12,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from parc_amd import _hip  # noqa: E402
 from parc_amd.util import geom_util  # noqa: E402
 
+# --plain: the PRODUCT library and only launches of the product's own flags (what profiles/ *_kernel_stats / pmc files are taken from).
+# Anything else (knob sweeps, role ablations) runs on the diagnostics library, tools/parc_diag.py.
+PLAIN = "--plain" in sys.argv                    # one launch variant per process, no sweeps
+if not PLAIN or any(a.startswith("--ablate=") for a in sys.argv):
+    import parc_diag  # noqa: E402
+    parc_diag.install()
+
 
 def time_loop(fn, iters, warmup=20):
     for _ in range(warmup):
@@ -78,11 +85,12 @@ def main():
             def k5n(nn=nn):
                 L.parc_refresh_obs_hfs(_hip.stream(), nn, _hip.ptr(rays), P, _hip.ptr(root_state), _hip.ptr(env_off), ter, -3.0, 3.0, dst, 1312)
             print(json.dumps({"kernel": "hf_gather_kernel", "envs": nn, "us_per_launch_back_to_back": time_loop(k5n, args.iters)}))
-    for epb in (1, 2, 4, 8):
+    for epb in () if PLAIN else (1, 2, 4, 8):
         L.parc_tune_hf_envs_per_block(epb)
         print(json.dumps({"kernel": "hf_gather_kernel", "epb": epb, "envs": n, "us_per_launch_back_to_back": time_loop(k5, args.iters)}))
-    L.parc_tune_hf_envs_per_block(2)
-    for ab in (1, 2, 3, 4, 5, 0):
+    if not PLAIN:
+        L.parc_tune_hf_envs_per_block(2)
+    for ab in () if PLAIN else (1, 2, 3, 4, 5, 0):
         L.parc_tune_hf_ablation(ab)
         print(json.dumps({"kernel": "hf_gather_kernel", "ablation": ab, "us": time_loop(k5, args.iters)}))
     us_loop = time_loop(k5, args.iters)
@@ -101,7 +109,7 @@ def bench_post_step(n, iters, workload="boxes_64clips"):
     # the product step's flags (the reference STATE is published by the step's tail launch, parc_step_tail, since round 3)
     full = _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS
     abl = [int(a.split("=")[1], 0) for a in sys.argv if a.startswith("--ablate=")]
-    if abl:                      # PMC runs of one role ablation: every launch of the process uses it
+    if abl:                      # PMC runs of one role ablation: every launch of the process uses it (diagnostics library)
         full |= abl[0]
     def graph_us_fn(fn, n=200):
         for _ in range(3):
@@ -147,23 +155,26 @@ def bench_post_step(n, iters, workload="boxes_64clips"):
         return best
     us_fused = time_loop(lambda: core.post_step(full), iters)
     us_graph = graph_us(full)
-    us_nohf = graph_us(full & ~_hip.POST_HF)
+    # --plain runs are what the profiler passes wrap: ONE launch variant per process, so that a kernel-stats mean or a counter mean
+    # is the full launch's and not a blend (round 3's files mixed 1123 full with 803 no-heightmap launches)
+    us_nohf = None if PLAIN else graph_us(full & ~_hip.POST_HF)
     # timing diagnostics (bits of `what` the kernel honours for this purpose only): 0x10000 / 0x20000 / 0x40000 drop the target /
     # reference / character waves after the barrier, 0x80000 the heightmap wave, 0x100000 returns at entry, 0x200000 returns in front of the
     # barrier, 0x400000 / 0x800000 end a target wave after its slerp / its tree walk
-    for name, bits in () if "--plain" in sys.argv else (("launch_only", 0x100000), ("up_to_the_barrier", 0x200000), ("none", 0x70000), ("only_char", 0x30000),
+    for name, bits in () if PLAIN else (("launch_only", 0x100000), ("up_to_the_barrier", 0x200000), ("none", 0x70000), ("only_char", 0x30000),
                                                          ("only_ref", 0x50000), ("only_tar", 0x60000), ("no_tar", 0x10000), ("no_ref", 0x20000), ("no_char", 0x40000),
                                                          ("no_heightmap_wave", 0x80000), ("only_tar_no_heightmap_wave", 0xe0000),
                                                          ("only_tar_no_stores", 0xe0000 | 0x1000000), ("all_but_target_stores", 0x1000000), ("only_tar_up_to_slerp", 0xe0000 | 0x400000), ("only_tar_up_to_tree_walk", 0xe0000 | 0x800000),
                                                          ("only_ref_no_heightmap_wave", 0xd0000), ("only_char_no_heightmap_wave", 0xb0000)):
         print(json.dumps({"ablation": name, "us_graph_replay": round(graph_us(full | bits), 2)}))
-    # the step's tail launch: fail-rate EMA alone, and with the reference state co-scheduled
-    fr = torch.full((M,), 0.5, device="cuda:0")
-    us_fr = graph_us_fn(lambda: core.update_fail_rates(fr, 0.01))
-    us_tail = graph_us_fn(lambda: core.step_tail(fr, 0.01))
-    us_state = graph_us_fn(lambda: core.post_step(_hip.POST_REF))
-    print(json.dumps({"kernel": "step tail", "us_fail_rate_kernel_alone": round(us_fr, 2), "us_step_tail_kernel (fail rates + reference state)": round(us_tail, 2),
-                      "us_ref_state_kernel_alone": round(us_state, 2)}))
+    if not PLAIN:
+        # the step's tail launch: fail-rate EMA alone, and with the reference state co-scheduled
+        fr = torch.full((M,), 0.5, device="cuda:0")
+        us_fr = graph_us_fn(lambda: core.update_fail_rates(fr, 0.01))
+        us_tail = graph_us_fn(lambda: core.step_tail(fr, 0.01))
+        us_state = graph_us_fn(lambda: core.post_step(_hip.POST_REF))
+        print(json.dumps({"kernel": "step tail", "us_fail_rate_kernel_alone": round(us_fr, 2), "us_step_tail_kernel (fail rates + reference state)": round(us_tail, 2),
+                          "us_ref_state_kernel_alone": round(us_state, 2)}))
     # algorithmic bytes per env: K5 3544 + K3 7*760 + state 456 + obs cols [0,871) 3484 + bodies 780 + 8 out
     alg = n * (3544 + 7 * 760 + 456 + 3484 + 780 + 8)
     print(json.dumps({"kernel": "track_post_kernel(fused hf)", "workload": workload, "clips": M, "hf_cells": list(hf.shape),

@@ -98,15 +98,17 @@ def run():
         L = ctypes.CDLL(so)
         _hip_sim.declare(L)
         row = {}
+        L.parc_diag_sim_step_env_per_lane.restype = ctypes.c_int
+        L.parc_diag_sim_step_env_per_lane.argtypes = L.parc_sim_step.argtypes + [ctypes.c_int]
         for kern in (0, 1):
-            L.parc_tune_sim_variant(kern)
+            step_fn, extra = (L.parc_diag_sim_step_env_per_lane, (64,)) if kern == 0 else (L.parc_sim_step, ())
             rs, ds = T(rs0), T(ds0)
             rb, cf = torch.zeros((n, 15, 13), device=dev), torch.zeros((n, 15, 3), device=dev)
             worst = 0.0
             for t in range(steps):
                 a = T(acts[t])
-                rc = L.parc_sim_step(_hip.stream(), sm.device_ptr(dev), ter, n, _hip.ptr(rs), _hip.ptr(ds), _hip.ptr(rb), _hip.ptr(cf),
-                                     _hip.ptr(eo), _hip.ptr(a), _hip.ptr(lo), _hip.ptr(hi), 4, 1.0 / 120.0)
+                rc = step_fn(_hip.stream(), sm.device_ptr(dev), ter, n, _hip.ptr(rs), _hip.ptr(ds), _hip.ptr(rb), _hip.ptr(cf),
+                             _hip.ptr(eo), _hip.ptr(a), _hip.ptr(lo), _hip.ptr(hi), 4, 1.0 / 120.0, *extra)
                 assert rc == 0, rc
                 torch.cuda.synchronize()
                 d = max(float(np.abs(rs.cpu().numpy()[:, 0:7] - href[t][0][:, 0:7]).max()),
@@ -167,14 +169,15 @@ def optbisect():
         lines = [ln for ln in res.stderr.splitlines() if ln.startswith("BISECT:")]
         L = ctypes.CDLL(so)
         _hip_sim.declare(L)
-        L.parc_tune_sim_variant(0)
+        L.parc_diag_sim_step_env_per_lane.restype = ctypes.c_int
+        L.parc_diag_sim_step_env_per_lane.argtypes = L.parc_sim_step.argtypes + [ctypes.c_int]
         rs, ds = T(rs0), T(ds0)
         rb, cf = torch.zeros((n, 15, 13), device=dev), torch.zeros((n, 15, 3), device=dev)
         worst = 0.0
         for t in range(steps):
             a = T(acts[t])
-            rc = L.parc_sim_step(_hip.stream(), sm.device_ptr(dev), ter, n, _hip.ptr(rs), _hip.ptr(ds), _hip.ptr(rb), _hip.ptr(cf), _hip.ptr(eo),
-                                 _hip.ptr(a), _hip.ptr(lo), _hip.ptr(hi), 4, 1.0 / 120.0)
+            rc = L.parc_diag_sim_step_env_per_lane(_hip.stream(), sm.device_ptr(dev), ter, n, _hip.ptr(rs), _hip.ptr(ds), _hip.ptr(rb), _hip.ptr(cf),
+                                                   _hip.ptr(eo), _hip.ptr(a), _hip.ptr(lo), _hip.ptr(hi), 4, 1.0 / 120.0, 64)
             assert rc == 0
             torch.cuda.synchronize()
             d = max(float(np.abs(rs.cpu().numpy()[:, 0:7] - href[t][0][:, 0:7]).max()), float(np.abs(ds.cpu().numpy()[..., 0] - href[t][1][..., 0]).max()))

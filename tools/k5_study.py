@@ -51,7 +51,8 @@ def main():
     eo = torch.zeros((n, 3), device=dev)
     obs = torch.zeros((n, 1312), device=dev)
     dst = _hip.c_vp(obs.data_ptr() + 4 * 871)
-    L = _hip.lib()
+    import parc_diag
+    L = parc_diag.lib()          # the knobs exist in the diagnostics library only
 
     def k5():
         L.parc_refresh_obs_hfs(_hip.stream(), n, _hip.ptr(rays), P, _hip.ptr(rs), _hip.ptr(eo), ter, -3.0, 3.0, dst, 1312)

@@ -18,6 +18,11 @@ def per_dispatch(d, counter, pat="track_post"):
 def main():
     fd, wd, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
     f, w = per_dispatch(fd, "FETCH_SIZE"), per_dispatch(wd, "WRITE_SIZE")
+    # one launch variant only: the kernel's stores are the same bytes every launch (round 3's files blended two variants: min 16.6 MB
+    # against a median of 27.4 MB)
+    if w["min_KB"] < 0.9 * w["median_KB"] or w["max_KB"] > 1.1 * w["median_KB"]:
+        sys.exit("pmc_traffic: WRITE_SIZE spreads from %.0f to %.0f KB around a median of %.0f KB: more than one launch variant under the "
+                 "profiler" % (w["min_KB"], w["max_KB"], w["median_KB"]))
     out = {"FETCH_SIZE": f, "WRITE_SIZE": w, "envs": n, "workload": sys.argv[4] if len(sys.argv) > 4 else "boxes_64clips",
            "note": "rocprofv3 --kernel-trace --pmc <counter> (separate passes) -- python3 tools/bench_kernels.py --post --plain --workload=<workload>; "
                    "track_post_kernel; bytes = KB*1024; gfx950 correction (MI355X_MICROARCH.md HBM section): corrected traffic = "

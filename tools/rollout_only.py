@@ -6,6 +6,13 @@ import torch
 from parc_amd import workloads
 from parc_amd.util import mp_util
 
+# --diag=0x...: timing-ablation bits ORed into every full post-step launch of the rollout (diagnostics library; results are garbage)
+_bits = [int(a.split("=")[1], 0) for a in sys.argv[1:] if a.startswith("--diag=")]
+if _bits:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import parc_diag
+    parc_diag.install(_bits[0])
+sys.argv = [a for a in sys.argv if not a.startswith("--diag=")]
 dev = "cuda:0"
 mp_util.init(0, 1, dev)
 torch.manual_seed(0)
