@@ -106,6 +106,10 @@ typedef struct {
     int32_t obs_dim;                             /* 1312 */
     float task1_w, task2_w, target_radius;       /* task reward terms, logged only while rel_task_w == 0 */
     float target_future_min, target_future_max;  /* dm.target_xy_future_time_min/max (PARC_POST_TARGETS) */
+    /* reward variants (ig_parkour_env.py:1284-1285,1323-1339; mgdm_dm_util.py:343-350): track_root_h = 0 drops the height from the
+     * root position error, use_contact_info = 0 drops the contact penalty from the reward.  (track_root = 0 and global_obs are not
+     * built: the host mirror refuses those configurations.) */
+    int32_t track_root_h, use_contact_info;
 } parc_track_cfg_t;
 
 /*
@@ -139,6 +143,11 @@ typedef struct {
     /* PARC_POST_TARGETS: DeepMimicEnv._update_motion_targets (dm_env.py:617-654) inside the launch */
     float *next_target_time;        /* [N]   time at which an env draws its next xy target */
     const float *target_rand;       /* [N,3] uniforms in [0,1): look-ahead time, and a Box-Muller pair for the 0.05 m target noise */
+    /* Per-env values that belong to observation columns OUTSIDE the fused row layout (optional variants of _compute_obs,
+     * ig_parkour_env.py:1212-1224 and ig_char_env.py:618-620; gathered into the handed-out row by parc_assemble_obs):
+     * [N,4] = root height (root_pos z), the xy target localised to the root (rotate_2d_vec(target_xy - root_xy, -heading)), 0.
+     * Written by every PARC_POST_OBS launch when not NULL. */
+    float *obs_aux;
     /* A launch on a ROW RANGE [e0, e0 + n) of larger allocations (a sub-env: every pointer above advanced by e0 rows, num_envs = n)
      * keeps the term-major layout of reward_terms by naming the allocation's row length here; 0 = num_envs. */
     int32_t reward_terms_stride;
@@ -251,6 +260,16 @@ int parc_motion_lib_build(void *stream, parc_char_model_t model, parc_motion_lib
 int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
                          parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
                          const float *ray_xy);
+
+/* Observation rows of the non-default layouts of IGParkourEnv._compute_obs (ig_parkour_env.py:1054-1244): global_root_height_obs
+ * prepends the root height, enable_tar_obs = False / use_contact_info = False leave column blocks out, has_target_xy_obs and the
+ * replan timer append columns behind the heightmap.  out[e, c] = V[e, col_map[c]] where the virtual row V[e] is
+ * [ obs[e, 0..obs_dim) | aux[e, 0..4) | *scalar ] (col_map[c] in [0, obs_dim + 5); aux / scalar may be NULL if unused).
+ * col_map: int32 [out_dim] on the device.  env_ids (int64 device pointer, n_sel entries) restricts the pass to those rows - the rows
+ * a reset touches (ig_env.py:100-121: reset(env_ids) rewrites obs_buf[env_ids] only) -, NULL = all n_envs rows.  One coalesced pass,
+ * no temporaries. */
+int parc_assemble_obs(void *stream, int n_envs, const float *obs, int obs_dim, const float *aux, const float *scalar,
+                      const int32_t *col_map, float *out, int out_dim, const int64_t *env_ids, int n_sel);
 
 /* Reset bookkeeping of DeepMimicEnv._reset_envs / IGEnv._reset_envs (dm_env.py:517-568, ig_env.py:100-121,693-721) for the
  * envs whose mask is set, from per-env candidate samples new_*[N] (drawn for every env, used where masked):

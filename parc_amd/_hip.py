@@ -73,7 +73,7 @@ class TrackCfgS(ctypes.Structure):
                 ("episode_length", c_f), ("contact_eps", c_f), ("min_obs_h", c_f), ("max_obs_h", c_f),
                 ("num_ray_points", c_i32), ("obs_dim", c_i32),
                 ("task1_w", c_f), ("task2_w", c_f), ("target_radius", c_f),
-                ("target_future_min", c_f), ("target_future_max", c_f)]
+                ("target_future_min", c_f), ("target_future_max", c_f), ("track_root_h", c_i32), ("use_contact_info", c_i32)]
 
 
 class EnvBuffersS(ctypes.Structure):
@@ -85,7 +85,7 @@ class EnvBuffersS(ctypes.Structure):
                 ("ref_joint_rot", c_vp), ("ref_dof_vel", c_vp), ("ref_dof_pos", c_vp),
                 ("ref_contacts", c_vp), ("ref_body_pos", c_vp),
                 ("obs", c_vp), ("reward", c_vp), ("reward_terms", c_vp), ("done", c_vp), ("done_kind", c_vp),
-                ("env_mask", c_vp), ("init_noise_xy", c_vp), ("next_target_time", c_vp), ("target_rand", c_vp),
+                ("env_mask", c_vp), ("init_noise_xy", c_vp), ("next_target_time", c_vp), ("target_rand", c_vp), ("obs_aux", c_vp),
                 ("reward_terms_stride", c_i32)]
 
 
@@ -201,6 +201,8 @@ def _declare(L):
     L.parc_calc_motion_frame.argtypes = [c_vp, MotionLibS, c_int, c_vp, c_vp] + [c_vp] * 7
     L.parc_motion_lib_build.argtypes = [c_vp, CharModelS, MotionLibS, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
     L.parc_track_post_step.argtypes = [c_vp, CharModelS, MotionLibS, TerrainS, TrackCfgS, EnvBuffersS, c_vp, c_int, c_int, c_vp]
+    L.parc_assemble_obs.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int]
+    L.parc_assemble_obs.restype = c_int
     L.parc_update_fail_rates.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_vp]
     L.parc_step_tail.argtypes = [c_vp, CharModelS, MotionLibS, EnvBuffersS, c_int, c_int, c_vp, c_f, c_vp]
     L.parc_step_tail.restype = c_int
@@ -261,7 +263,8 @@ EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hf
             "parc_action_head", "parc_points_hf_sdf", "parc_moments_workspace_floats", "parc_moments_accumulate", "parc_reset_sample_apply", "parc_return_tracker_workspace_floats", "parc_scale_by_clipped_norm", "parc_relu_bwd_workspace_floats",
             "parc_relu_bwd_bias_grad", "parc_ppo_loss_packed", "parc_weighted_colsum", "parc_sgd_workspace_floats", "parc_sgd_momentum_step",
             "parc_pose_chain_forward", "parc_pose_chain_backward", "parc_points_hf_sdf_grad", "parc_body_points_world", "parc_body_points_world_grad",
-            "parc_quat_diff_angle", "parc_quat_diff_angle_grad", "parc_temporal_terms", "parc_temporal_terms_grad", "parc_step_tail"]
+            "parc_quat_diff_angle", "parc_quat_diff_angle_grad", "parc_temporal_terms", "parc_temporal_terms_grad", "parc_step_tail",
+            "parc_assemble_obs"]
 
 
 def check(rc, what):

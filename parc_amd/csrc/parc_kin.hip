@@ -1441,6 +1441,16 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 row[Wc + S * Wt + S * B + b] = fsqrt(dot3(f, f)) > cfg.contact_eps ? 1.f : 0.f;
             }
         }
+        if ((what & PARC_POST_OBS) && b == 0 && live) {
+            // values of the optional observation columns (has_target_xy_obs ig_parkour_env.py:1212-1224: the xy target seen from the
+            // root, rotate_2d_vec(target - root_xy, -heading) = the heading-inverse rotation of (dx, dy, 0); global_root_height_obs
+            // ig_char_env.py:618-620: root height) for parc_assemble_obs
+            float *aux = kernarg_late<parc_env_buffers_t>(KARG_OFF_BUF)->obs_aux;
+            if (aux) {
+                const v3 lt = quat_rotate(hinv, mk3(tgt_xy[le][0] - c_pos.x, tgt_xy[le][1] - c_pos.y, 0.f));
+                reinterpret_cast<float4 *>(aux)[e] = make_float4(c_pos.z, lt.x, lt.y, 0.f);
+            }
+        }
         if ((what & PARC_POST_REWARD_DONE) && b == 0 && live) {
             // task terms  ig_parkour_env.py:1346-1393 (logged; they scale the reward only if rel_task_w > 0).  They read the simulated
             // root and the xy target only - nothing of the reference pose - so the character wave, the first to finish, computes them
@@ -1548,6 +1558,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 fall_height = any16(fall_height);
                 if (b == 0 && live) {
                     v3 dp = r_pos - c_pos;
+                    if (!rcfg.track_root_h) dp.z = 0.f;          // mgdm_dm_util.py:349-350
                     float root_pos_err = dot3(dp, dp);
                     const float rre = rot_diff;
                     float rre2 = rre * rre;
@@ -1561,7 +1572,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                     // ig_parkour_env.py:1317-1339,1404
                     float dm = rcfg.reward_w[0] * pose_r + rcfg.reward_w[1] * vel_r + rcfg.reward_w[2] * root_pose_r +
                                rcfg.reward_w[3] * root_vel_r + rcfg.reward_w[4] * key_r;
-                    dm += cp;
+                    if (rcfg.use_contact_info) dm += cp;        // ig_parkour_env.py:1323-1339
                     rbuf.reward[e] = rcfg.rel_deepmimic_w * dm;
                     const int N = rbuf.reward_terms_stride > 0 ? rbuf.reward_terms_stride : rbuf.num_envs;
                     rbuf.reward_terms[0 * (size_t)N + e] = pose_r;
@@ -1714,6 +1725,37 @@ extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_
                            (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, n, what, ray_xy);
         PARC_CHECK_LAUNCH();
     }
+    return PARC_OK;
+}
+
+// =============================================================================================
+// Observation rows of the non-default layouts: a column gather from [obs row | aux | scalar] (parc_hip.h, parc_assemble_obs)
+// =============================================================================================
+__global__ __launch_bounds__(256) void assemble_obs_kernel(const float *__restrict__ obs, int obs_dim, const float *__restrict__ aux,
+                                                           const float *__restrict__ scalar, const int32_t *__restrict__ col_map,
+                                                           float *__restrict__ out, int out_dim, const int64_t *__restrict__ env_ids) {
+    const int e = env_ids ? (int)env_ids[blockIdx.y] : (int)blockIdx.y;
+    const float sc = scalar ? scalar[0] : 0.f;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < out_dim; c += gridDim.x * blockDim.x) {
+        const int k = col_map[c];
+        float v;
+        if (k < obs_dim) v = obs[(size_t)e * obs_dim + k];
+        else if (k < obs_dim + 4) v = aux[4 * (size_t)e + (k - obs_dim)];
+        else v = sc;
+        out[(size_t)e * out_dim + c] = v;
+    }
+}
+
+extern "C" int parc_assemble_obs(void *stream, int n_envs, const float *obs, int obs_dim, const float *aux, const float *scalar,
+                                 const int32_t *col_map, float *out, int out_dim, const int64_t *env_ids, int n_sel) {
+    if (n_envs < 0 || obs_dim <= 0 || out_dim <= 0 || !obs || !col_map || !out || (env_ids && n_sel < 0)) return PARC_EINVAL;
+    const int rows = env_ids ? n_sel : n_envs;
+    if (rows == 0) return PARC_OK;
+    if (rows > 65535) return PARC_EUNSUPPORTED;          // grid.y
+    const int bx = (out_dim + 255) / 256;
+    hipLaunchKernelGGL(assemble_obs_kernel, dim3(bx > 2 ? 2 : bx, rows), dim3(256), 0, (hipStream_t)stream, obs, obs_dim, aux, scalar, col_map,
+                       out, out_dim, env_ids);
+    PARC_CHECK_LAUNCH();
     return PARC_OK;
 }
 

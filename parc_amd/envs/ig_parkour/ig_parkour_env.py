@@ -184,10 +184,13 @@ class IGParkourEnv(base_env.BaseEnv):
         self._reward_buf, self._done_buf = c.reward, c.done
         self._timestep_buf, self._time_buf = c.timestep_buf, c.time_buf
         self._ep_num_buf = torch.zeros(N, device=self._device, dtype=torch.int64)
-        # the kernels write rows of cfg.obs_dim; with the replan-timer column the env hands out a buffer one column wider that is
-        # refreshed from them (a strided copy per step: such an env is stepped eagerly anyway)
-        self._obs_buf = c.obs if not self._enable_replan_timer_obs else torch.zeros((N, self._cfg.obs_dim + 1), dtype=torch.float32,
-                                                                                    device=self._device)
+        # The kernels write the fused row of cfg.obs_dim columns.  In the tracker's default configuration that IS the handed-out row;
+        # a configuration with other segments (has_target_xy_obs, global_root_height_obs, enable_tar_obs / use_contact_info off, the
+        # replan timer of a generator sub-env: ig_parkour_env.py:1163-1239) hands out a buffer of its own that one gather launch
+        # (parc_assemble_obs) fills from the fused rows, the per-env extras and the plan clock.
+        self._obs_shapes, cols = self._cfg.obs_layout(self._enable_replan_timer_obs)
+        self._obs_cols = None if cols is None else torch.tensor(cols, dtype=torch.int32, device=self._device)
+        self._obs_buf = c.obs if cols is None else torch.zeros((N, len(cols)), dtype=torch.float32, device=self._device)
         self._ray_hfs = c.ray_hfs
         self._target_xy, self._next_target_xy_time = c.target_xy, c.next_target_xy_time
         self._info = dict()
@@ -207,17 +210,18 @@ class IGParkourEnv(base_env.BaseEnv):
         return Box(low=-np.inf, high=np.inf, shape=[int(self._obs_buf.shape[1])], dtype=np.float32)
 
     def _publish_obs(self, env_ids=None):
-        """rows the kernels just wrote -> the handed-out buffer, plan clock in the last column (only with the replan-timer column)"""
-        if not self._enable_replan_timer_obs:
+        """rows the kernels just wrote -> the handed-out buffer (only for a configuration whose row is not the fused row)"""
+        if self._obs_cols is None:
             return
-        D = self._cfg.obs_dim
-        t = self._mgdm_env.get_mgdm_time_buf()
-        if env_ids is None:
-            self._obs_buf[:, :D] = self._core.obs
-            self._obs_buf[:, D] = t
-        elif len(env_ids) > 0:
-            self._obs_buf[env_ids, :D] = self._core.obs[env_ids]
-            self._obs_buf[env_ids, D] = t
+        t = self._mgdm_env.get_mgdm_time_buf() if self._enable_replan_timer_obs else None
+        self._core.assemble_obs(self._obs_cols, self._obs_buf, scalar=t, env_ids=env_ids)
+
+    def _finish_reward(self):
+        """rel_task_w > 0: the task term multiplies the tracking reward (ig_parkour_env.py:1399-1404; the kernel left deepmimic_r in
+        the reward buffer and total_task_r in its term row, TrackerConfig)"""
+        if self._cfg.rel_task_w > 0:
+            c = self._core
+            torch.mul(c.reward, c.reward_terms[8], out=c.reward)
 
     def has_dm_envs(self):
         return self._num_dm_envs > 0
@@ -446,6 +450,7 @@ class IGParkourEnv(base_env.BaseEnv):
             c.post_step(_hip.POST_OBS | _hip.POST_HF | _hip.POST_MASKED | _hip.POST_TARGETS, reset_rand=True, rows=rows)
             if mixed:
                 return self._reset_done_mgdm_rows()
+            self._publish_obs()
             self._update_info()
             return self._obs_buf, self._info
         assert not mixed, "generator rows restart on the device only in the training configuration (supports_device_reset)"
@@ -469,6 +474,7 @@ class IGParkourEnv(base_env.BaseEnv):
                                                     _hip.ptr(c.contact_forces)), "parc_sim_refresh_bodies_masked")
         c.target_rand.uniform_()
         c.post_step(_hip.POST_OBS | _hip.POST_HF | _hip.POST_MASKED | _hip.POST_TARGETS)
+        self._publish_obs()
         self._update_info()
         return self._obs_buf, self._info
 
@@ -510,6 +516,8 @@ class IGParkourEnv(base_env.BaseEnv):
         # (the reference STATE - ref_* buffers - rides in the fail-rate launch below: nothing in the fused launch reads it)
         c.post_step(_hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS)
         c.step_tail(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight)
+        self._finish_reward()
+        self._publish_obs()
         if self._never_done:
             self._done_buf[:] = base_env.DoneFlags.NULL.value
         self._update_info(step=True)
@@ -547,6 +555,7 @@ class IGParkourEnv(base_env.BaseEnv):
             c.step_tail(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight, rows=(0, n_dm))     # fail rates + reference state
         mg._post(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF)
         mg.update_done_extra(fixed_shape=True)
+        self._finish_reward()
         self._publish_obs()
         if self._never_done:
             self._done_buf[:] = base_env.DoneFlags.NULL.value
@@ -610,19 +619,8 @@ class IGParkourEnv(base_env.BaseEnv):
     def _compute_obs(self, env_ids=None, ret_obs_shapes=False):
         """Observation rows for env_ids (all if None); with ret_obs_shapes the ordered segment table the agent uses to
         build the normaliser's index set (ig_parkour_env.py:1163-1239, learning/dm_ppo_agent.py:91-109)."""
-        cfg = self._cfg
-        B = cfg.num_bodies
-        S = len(cfg.tar_obs_steps)
         if ret_obs_shapes:
-            shapes = OrderedDict()
-            shapes["char_obs"] = {"use_normalizer": True, "shape": torch.Size([cfg.char_obs_dim])}
-            shapes["tar_obs"] = {"use_normalizer": True, "shape": torch.Size([S, cfg.tar_obs_dim])}
-            shapes["tar_contacts"] = {"use_normalizer": False, "shape": torch.Size([S, B])}
-            shapes["char_contacts"] = {"use_normalizer": False, "shape": torch.Size([B])}
-            shapes["hf"] = {"use_normalizer": False, "shape": torch.Size([self._ray_xy_points.shape[0]])}
-            if self._enable_replan_timer_obs:
-                shapes["replan_t"] = {"use_normalizer": False, "shape": torch.Size([1])}
-            return shapes
+            return OrderedDict((k, dict(v)) for k, v in self._obs_shapes.items())
         if self.has_mgdm_envs():
             ids = self._all_env_ids if env_ids is None else env_ids.to(torch.long)
             n_dm = self._num_dm_envs
@@ -632,6 +630,7 @@ class IGParkourEnv(base_env.BaseEnv):
             self._publish_obs(env_ids)
         else:
             self._core.post_step(_hip.POST_OBS | _hip.POST_HF, env_ids)
+            self._publish_obs(env_ids)
         return self._obs_buf if env_ids is None else self._obs_buf[env_ids]
 
     # ------------------------------------------------------------------ motion recording (ig_parkour_env.py:850-995,1594-1620)
@@ -658,10 +657,6 @@ class IGParkourEnv(base_env.BaseEnv):
     # Python lists on every step (a loop over all envs with device reads); here the states are scattered into device buffers
     # [steps, env, ...] with a per-env write row, and the host only touches the envs that finish (one small transfer per step).
     def build_agent_states_dict(self, name_suffix="", record_obs=False):
-        if self.has_mgdm_envs():
-            # the recorder ends a clip at its dataset motion's end (parc_4_phys_record runs all rows on dataset clips); the reference
-            # reaches this with generator rows from its viewer only (ig_parkour_env.py:329-332)
-            raise NotImplementedError("motion recording covers envs whose rows all follow dataset clips (fraction_dm_envs: 1.0)")
         obs_shapes = self._compute_obs(ret_obs_shapes=True) if record_obs else None
         self._dm_agent_motion = []
         for _ in range(self._num_envs):
@@ -679,12 +674,17 @@ class IGParkourEnv(base_env.BaseEnv):
         N, dev = self._num_envs, self._device
         # rows: the longest clip at the control rate + the frame written at reset + slack; row `cap` is a dump row for envs that
         # are not recording (so the scatter needs no compaction)
-        cap = int(math.ceil(float(self._dm_env._motion_lib._motion_lengths.max().item()) * self._control_freq)) + 8
+        # (a dataset row's recording ends with its clip.  A generator row records until it FAILS, across time-outs and replans, like the
+        # reference's lists (ig_parkour_env.py:957-995): its buffers start at one episode and double whenever the number of steps
+        # written since this call - a host counter, no read-back - reaches the capacity)
+        cap = 8 + (int(math.ceil(float(self._dm_env._motion_lib._motion_lengths.max().item()) * self._control_freq)) if self.has_dm_envs()
+                   else int(math.ceil(float(self._episode_length) * self._control_freq)))
         if getattr(self, "_rec_cap", -1) != cap or self._rec_has_obs != record_obs:
             self._rec_frames = torch.empty((cap + 1, N, 34), dtype=torch.float32, device=dev)
             self._rec_contacts = torch.empty((cap + 1, N, self._char_contact_forces.shape[1]), dtype=torch.float32, device=dev)
             self._rec_obs = torch.empty((cap + 1, N, self._obs_buf.shape[1]), dtype=torch.float32, device=dev) if record_obs else None
             self._rec_cap, self._rec_has_obs = cap, record_obs
+        self._rec_steps = 0
         self._rec_len = torch.zeros(N, dtype=torch.long, device=dev)
         self._rec_arange = torch.arange(N, device=dev)
         self._writing_dev = torch.ones(N, dtype=torch.bool, device=dev)
@@ -708,6 +708,9 @@ class IGParkourEnv(base_env.BaseEnv):
         if self._writing_dirty:
             self._writing_dev = torch.tensor(self._writing_env_state, dtype=torch.bool, device=self._device)
             self._writing_dirty = False
+        if self.has_mgdm_envs() and self._rec_steps >= self._rec_cap:
+            self._grow_recorder()
+        self._rec_steps += 1
         frames, contacts = self._get_char_state_all()
         w = self._writing_dev
         row = torch.where(w & (self._rec_len < self._rec_cap), self._rec_len, torch.full_like(self._rec_len, self._rec_cap))
@@ -721,12 +724,17 @@ class IGParkourEnv(base_env.BaseEnv):
         self._writing_dev = w & ~fin
         n_fin, n_writing = torch.stack([fin.sum(), self._writing_dev.sum()]).tolist()      # the step's one host read
         if n_fin > 0:
-            dm = self._dm_env
+            dm, n_dm = self._dm_env, self._num_dm_envs
             ids = fin.nonzero().flatten()
-            mlen = dm._motion_lib._motion_lengths[dm._motion_ids[ids]].tolist()
-            mtime = dm._get_motion_times()[ids].tolist()
+            dm_ids = ids[ids < n_dm]
+            if len(dm_ids) > 0:
+                mlen = dm._motion_lib._motion_lengths[dm._motion_ids[dm_ids]].tolist()
+                mtime = dm._get_motion_times()[dm_ids].tolist()
             for k, e in enumerate(ids.tolist()):
                 self._writing_env_state[e] = False
+                if e >= n_dm:                  # a generator row: whatever it recorded, under the default name (ig_parkour_env.py:993-994)
+                    self.save_agent_states_to_file(e)
+                    continue
                 name = dm.get_env_motion_name(e)
                 if not self._bypass_record_fail and mtime[k] < mlen[k] - self._timestep * 2.0:
                     print("env", e, "failed to track motion", name)
@@ -735,16 +743,31 @@ class IGParkourEnv(base_env.BaseEnv):
                 self.save_agent_states_to_file(e, name + self._save_motion_name_suffix)
         self.set_write_agent_states_flag(n_writing > 0)
 
+    def _grow_recorder(self):
+        """double the recorder's rows (generator rows record until they fail); the dump row moves to the new end"""
+        old, new = self._rec_cap, 2 * self._rec_cap
+
+        def grow(buf):
+            if buf is None:
+                return None
+            out = torch.empty((new + 1,) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+            out[:old] = buf[:old]
+            return out
+        self._rec_frames, self._rec_contacts, self._rec_obs = grow(self._rec_frames), grow(self._rec_contacts), grow(self._rec_obs)
+        self._rec_cap = new
+
     def save_agent_states_to_file(self, env_id, output_motion_name=None):
         rec = self._dm_agent_motion[env_id]
         T = min(int(self._rec_len[env_id].item()), self._rec_cap)
         frames = self._rec_frames[:T, env_id].cpu().numpy().astype(np.float32)
-        frames[:, 0:2] += self._env_offsets[env_id, 0:2].cpu().numpy()
+        is_dm = env_id < self._num_dm_envs
+        if is_dm:                              # dataset rows: env -> global xy; generator rows stay as they are (ig_parkour_env.py:905-916)
+            frames[:, 0:2] += self._env_offsets[env_id, 0:2].cpu().numpy()
         out = dict(rec)
         out["contacts"] = self._rec_contacts[:T, env_id].cpu().numpy().astype(np.float32)
         if self._record_obs:
             out["obs"] = self._rec_obs[:T, env_id].cpu().numpy().astype(np.float32)
-        ter = self._dm_env._terrain
+        ter = self._dm_env._terrain if is_dm else self._mgdm_env._terrain
         pad = round(1.0 // ter.dxdy[0].item()) * ter.dxdy[0].item()
         sliced, frames = terrain_util.slice_terrain_around_motion(frames, ter, padding=pad)
         out["terrain"] = sliced.numpy_copy()

@@ -19,25 +19,22 @@ class TrackerConfig:
         km = kin_char_model
         B, D = km.get_num_joints(), km.get_dof_size()
         J = B - 1
+        # Variants of IGParkourEnv._compute_obs / _update_reward (ig_parkour_env.py:1054-1244,1275-1404) beyond the tracker's defaults:
+        #   has_target_xy_obs, global_root_height_obs, enable_tar_obs = False, use_contact_info = False  -> column layout (obs_layout)
+        #   track_root_h = False, use_contact_info = False, rel_task_w > 0                             -> reward (kernel flags / one multiply)
+        # Not built: global_obs (the whole row in world axes) and track_root = False (reward / termination in heading-local axes).
         unsupported = []
         if env_config.get("global_obs", False):
             unsupported.append("global_obs=True")
-        if env_config.get("global_root_height_obs", False):
-            unsupported.append("global_root_height_obs=True")
-        if not env_config.get("enable_tar_obs", True):
-            unsupported.append("enable_tar_obs=False")
-        if not env_config.get("use_contact_info", True):
-            unsupported.append("use_contact_info=False")
-        if env_config.get("has_target_xy_obs", False):
-            unsupported.append("has_target_xy_obs=True")
-        if not env_config.get("track_root_h", True):
-            unsupported.append("track_root_h=False")
         if not env_config.get("track_root", True):
             unsupported.append("track_root=False")
-        if env_config.get("rel_task_w", 0.0) > 0:
-            unsupported.append("rel_task_w>0")
         if unsupported:
-            raise NotImplementedError("tracker kernels cover the default tracker configuration; unsupported: " + ", ".join(unsupported))
+            raise NotImplementedError("tracker kernels do not cover: " + ", ".join(unsupported))
+        self.has_target_xy_obs = bool(env_config.get("has_target_xy_obs", False))
+        self.global_root_height_obs = bool(env_config.get("global_root_height_obs", False))
+        self.enable_tar_obs = bool(env_config.get("enable_tar_obs", True))
+        self.use_contact_info = bool(env_config.get("use_contact_info", True))
+        self.rel_task_w = float(env_config.get("rel_task_w", 0.0))
 
         self.timestep = 1.0 / env_config["control_freq"]
         steps = list(env_config.get("tar_obs_steps", [1]))
@@ -72,7 +69,11 @@ class TrackerConfig:
         w = w / w.sum()             # ig_parkour_env.py:122-132
         for i in range(5):
             s.reward_w[i] = float(w[i])
-        s.rel_deepmimic_w = float(env_config["rel_deepmimic_w"])
+        # rel_task_w > 0: reward = deepmimic_r * task_r, without rel_deepmimic_w (ig_parkour_env.py:1399-1404); the kernel then writes
+        # deepmimic_r and the env multiplies by the task term the same launch produced
+        s.rel_deepmimic_w = float(env_config["rel_deepmimic_w"]) if self.rel_task_w <= 0 else 1.0
+        s.track_root_h = int(bool(env_config.get("track_root_h", True)))
+        s.use_contact_info = int(self.use_contact_info)
         ptd = env_config["pose_termination_dist"]
         for i in range(J):
             s.pose_termination_dist[i] = float(ptd[i])
@@ -106,6 +107,46 @@ class TrackerConfig:
         self.contact_body_ids = cb
         self.tar_obs_steps = steps
         self.num_bodies, self.dof_size = B, D
+        self.num_ray_points = int(num_ray_points)
+
+    def obs_layout(self, replan_timer=False):
+        """(shapes, col_map): the segment table of IGParkourEnv._compute_obs(ret_obs_shapes=True) (ig_parkour_env.py:1163-1239) for this
+        configuration, and for each column of the handed-out row its source in the virtual row [ fused row (obs_dim) | aux: root
+        height, local target x, y, 0 | plan clock ] that parc_assemble_obs gathers from - None when the handed-out row IS the fused
+        row (the tracker's default configuration: no gather, the kernels' buffer is handed out)."""
+        from collections import OrderedDict
+        B, S, P = self.num_bodies, len(self.tar_obs_steps), self.num_ray_points
+        Wc, Wt, D0 = self.char_obs_dim, self.tar_obs_dim, self.obs_dim
+        shapes, cols = OrderedDict(), []
+        char_cols = list(range(0, Wc))
+        if self.global_root_height_obs:                # ig_char_env.py:618-620: root height in front of the character block
+            char_cols = [D0 + 0] + char_cols
+        shapes["char_obs"] = {"use_normalizer": True, "shape": torch.Size([len(char_cols)])}
+        cols += char_cols
+        o = Wc
+        if self.enable_tar_obs:
+            shapes["tar_obs"] = {"use_normalizer": True, "shape": torch.Size([S, Wt])}
+            cols += list(range(o, o + S * Wt))
+        o += S * Wt
+        if self.use_contact_info and self.enable_tar_obs:
+            shapes["tar_contacts"] = {"use_normalizer": False, "shape": torch.Size([S, B])}
+            cols += list(range(o, o + S * B))
+        o += S * B
+        if self.use_contact_info:
+            shapes["char_contacts"] = {"use_normalizer": False, "shape": torch.Size([B])}
+            cols += list(range(o, o + B))
+        o += B
+        shapes["hf"] = {"use_normalizer": False, "shape": torch.Size([P])}
+        cols += list(range(o, o + P))
+        assert o + P == D0
+        if self.has_target_xy_obs:                     # ig_parkour_env.py:1212-1224
+            shapes["target_xy"] = {"use_normalizer": True, "shape": torch.Size([2])}
+            cols += [D0 + 1, D0 + 2]
+        if replan_timer:                               # ig_parkour_env.py:1226-1232
+            shapes["replan_t"] = {"use_normalizer": False, "shape": torch.Size([1])}
+            cols += [D0 + 4]
+        native = cols == list(range(D0))
+        return shapes, (None if native else cols)
 
 
 class TrackerCore:
@@ -144,6 +185,9 @@ class TrackerCore:
         self.ref_contacts = z((N, B), **f32)
         self.ref_body_pos = z((N, B, 3), **f32)
         self.obs = z((N, cfg.obs_dim), **f32)
+        # values of the optional observation columns (root height, localised xy target; parc_env_buffers_t.obs_aux), allocated only
+        # for configurations whose handed-out row has them
+        self.obs_aux = z((N, 4), **f32) if (cfg.has_target_xy_obs or cfg.global_root_height_obs) else None
         # row 0 = total reward, rows 1..9 = the logged terms: one [10, N] block so the return tracker adds it in one op
         self.reward_all = z((10, N), **f32)
         self.reward = self.reward_all[0]
@@ -197,7 +241,7 @@ class TrackerCore:
                               motion_time_offsets=1, motion_xy_offset=2, time_buf=1, target_xy=2, ref_root_pos=3, ref_root_rot=4, ref_root_vel=3,
                               ref_root_ang_vel=3, ref_joint_rot=4 * (B - 1), ref_dof_vel=D, ref_dof_pos=D, ref_contacts=B, ref_body_pos=3 * B,
                               obs=self.cfg.obs_dim, reward=1, reward_terms=1, done=1, done_kind=1, env_mask=1, init_noise_xy=2,
-                              next_target_time=1, target_rand=3)          # in 4-byte words (motion_ids: int64 = 2 words)
+                              next_target_time=1, target_rand=3, obs_aux=4)          # in 4-byte words (motion_ids: int64 = 2 words)
                 for name, words in rowlen.items():
                     base = getattr(s, name)
                     if base:
@@ -220,7 +264,7 @@ class TrackerCore:
                 p(self.ref_root_pos), p(self.ref_root_rot), p(self.ref_root_vel), p(self.ref_root_ang_vel),
                 p(self.ref_joint_rot), p(self.ref_dof_vel), p(self.ref_dof_pos), p(self.ref_contacts), p(self.ref_body_pos),
                 p(self.obs), p(self.reward), p(self.reward_terms), p(self.done), p(self.done_kind),
-                p(self.reset_mask), p(self.init_noise_xy), p(self.next_target_xy_time), p(self.target_rand), 0)
+                p(self.reset_mask), p(self.init_noise_xy), p(self.next_target_xy_time), p(self.target_rand), p(self.obs_aux), 0)
         return self._buf_struct
 
     # ---- K5 (IGParkourEnv._refresh_obs_hfs)
@@ -257,6 +301,16 @@ class TrackerCore:
         if timed:
             ev1.record()
             self.timing_events.append((ev0, ev1))
+
+    def assemble_obs(self, col_map, out, scalar=None, env_ids=None):
+        """rows of a non-default observation layout (TrackerConfig.obs_layout) gathered from the fused rows, obs_aux and one scalar"""
+        if env_ids is not None:
+            env_ids = env_ids.to(torch.int64).contiguous()
+            if env_ids.numel() == 0:
+                return
+        _hip.check(_hip.lib().parc_assemble_obs(_hip.stream(), self.N, _hip.ptr(self.obs), self.cfg.obs_dim, _hip.ptr(self.obs_aux),
+                                                _hip.ptr(scalar), _hip.ptr(col_map), _hip.ptr(out), int(out.shape[1]),
+                                                _hip.ptr(env_ids), 0 if env_ids is None else int(env_ids.numel())), "parc_assemble_obs")
 
     def step_tail(self, fail_rates, ema_w, publish_ref_state=True, rows=None):
         """fail-rate EMA of the step + (optionally) the per-step publication of the reference state, co-scheduled in one launch;

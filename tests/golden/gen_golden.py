@@ -1031,7 +1031,8 @@ def gen_recorded_files():
 
 
 STAGES = ["core", "voxel-mesh", "dataset-yaml", "procgen", "terrain-geometry", "done-branches", "ppo-loss", "normalizer", "trackers",
-          "action-head", "recorded-files", "motion-opt", "mgdm", "motion-edit", "sim-config", "stage-scripts", "experience-buffer"]
+          "action-head", "recorded-files", "motion-opt", "mgdm", "motion-edit", "sim-config", "stage-scripts", "experience-buffer",
+          "obs-variants"]
 
 
 def _icosa_points(radius):
@@ -1637,6 +1638,101 @@ def gen_experience_buffer():
 
 
 
+def gen_obs_variants():
+    """G26: the non-default variants of IGParkourEnv._compute_obs / _update_reward (ig_parkour_env.py:1054-1244,1275-1404) - the
+    reference's OWN methods, called unbound on an object that carries the G6 state under the reference's attribute names (its
+    constructor needs Isaac Gym; these two methods do not) - and the two env configurations the reference ships
+    (data/envs/ig_parkour_env.yaml: the motion-generator env with has_target_xy_obs; data/terrains/dm_env_civilization.yaml), parsed,
+    with the observation segment table each one produces."""
+    import json
+    import yaml
+    import envs.ig_parkour.ig_parkour_env as ipe
+    z = np.load(os.path.join(HERE, "g6_step.npz"))
+    km = load_char()
+    n = z["obs"].shape[0]
+    rng = np.random.default_rng(26)
+    target_xy = t(z["char_root_pos"][:, 0:2] + rng.standard_normal((n, 2)).astype(np.float32) * 3.0)
+    target_xy[0] = t(z["char_root_pos"][0, 0:2]) + 0.3                 # inside the target radius: task reward saturates
+    target_xy[1] = t(z["char_root_pos"][1, 0:2])                       # on the target: direction undefined -> zeros
+    plan_clock = torch.tensor(0.2333, dtype=torch.float32)
+
+    class DM:
+        def compute_tar_obs(self, steps, env_ids):
+            assert env_ids is None
+            return t(z["tar_root_pos"]), t(z["tar_root_rot"]), t(z["tar_joint_rot"]), t(z["tar_key_pos"]), t(z["tar_contacts"])
+
+        def get_mgdm_time_buf(self):
+            return plan_clock.reshape(1)
+
+    def make(cfg):
+        e = object.__new__(ipe.IGParkourEnv)
+        e._device, e._num_envs, e._visualize, e._report_tracking_error = "cpu", n, False, False
+        e._kin_char_model = km
+        for k in ("char_root_pos", "char_root_rot", "char_root_vel", "char_root_ang_vel", "char_dof_pos", "char_dof_vel", "char_rigid_body_pos"):
+            setattr(e, "_" + k, t(z[k]).clone())
+        e._char_contact_forces = t(z["contact_forces"])
+        for k in ("ref_root_pos", "ref_root_rot", "ref_root_vel", "ref_root_ang_vel", "ref_joint_rot", "ref_dof_vel", "ref_contacts", "ref_body_pos"):
+            setattr(e, "_" + k, t(z[k]).clone())
+        e._ray_hfs = t(z["ray_hfs"])
+        e._target_xy = target_xy.clone()
+        e._key_body_ids = t(z["key_body_ids"], torch.int64)
+        e._tar_obs_steps = t(z["tar_obs_steps"], torch.int)
+        e._joint_err_w, e._dof_err_w = t(z["joint_err_w"]), t(z["dof_err_w"])
+        w = np.array([cfg["pose_w"], cfg["vel_w"], cfg["root_pos_w"], cfg["root_vel_w"], cfg["key_pos_w"]])
+        tot = w.sum()
+        e._pose_w, e._vel_w, e._root_pos_w, e._root_vel_w, e._key_pos_w = [float(v / tot) for v in w]
+        e._contact_weights = t(cfg["contact_weights"])
+        e._global_obs, e._use_heightmap = bool(cfg["global_obs"]), True
+        e._global_root_height_obs, e._enable_tar_obs = bool(cfg["global_root_height_obs"]), bool(cfg.get("enable_tar_obs", True))
+        e._use_contact_info, e._has_target_xy_obs = bool(cfg["use_contact_info"]), bool(cfg["has_target_xy_obs"])
+        e._track_root, e._track_root_h = bool(cfg["track_root"]), bool(cfg["track_root_h"])
+        e._task1_w, e._task2_w, e._target_radius = cfg["task1_w"], cfg["task2_w"], cfg["target_radius"]
+        e._rel_deepmimic_w, e._rel_task_w = cfg["rel_deepmimic_w"], cfg["rel_task_w"]
+        mg = bool(cfg.get("_mgdm", False))
+        e._num_dm_envs, e._num_mgdm_envs = (0, n) if mg else (n, 0)
+        e._enable_replan_timer_obs = bool(cfg.get("enable_replan_timer_obs", False)) and mg
+        e._dm_env = e._mgdm_env = DM()
+        e._reward_buf = torch.zeros(n)
+        e._info = dict()
+        return e
+
+    base = dict(pose_w=0.5, vel_w=0.1, root_pos_w=0.15, root_vel_w=0.1, key_pos_w=0.15, contact_weights=[5.0] * 15, global_obs=False,
+                global_root_height_obs=False, enable_tar_obs=True, use_contact_info=True, has_target_xy_obs=False, track_root=True,
+                track_root_h=True, task1_w=0.7, task2_w=0.3, target_radius=1.0, rel_deepmimic_w=1.0, rel_task_w=0.0)
+    variants = {"default": {}, "target_xy": {"has_target_xy_obs": True}, "root_height": {"global_root_height_obs": True},
+                "no_tar_obs": {"enable_tar_obs": False}, "no_contact_info": {"use_contact_info": False},
+                "no_root_h_tracking": {"track_root_h": False}, "task_product": {"rel_task_w": 0.5, "rel_deepmimic_w": 0.7},
+                "everything": {"has_target_xy_obs": True, "global_root_height_obs": True, "track_root_h": False, "rel_task_w": 1.0},
+                "mgdm_shipped": {"has_target_xy_obs": True, "enable_replan_timer_obs": True, "_mgdm": True}}
+    arrs = {"target_xy": target_xy, "plan_clock": plan_clock}
+    tables = {}
+    import contextlib
+    import io
+    for tag, over in variants.items():
+        cfg = dict(base, **over)
+        e = make(cfg)
+        with contextlib.redirect_stdout(io.StringIO()):                # (_compute_obs prints its segment table)
+            shapes = ipe.IGParkourEnv._compute_obs(e, ret_obs_shapes=True)
+        obs = ipe.IGParkourEnv._compute_obs(e)
+        ipe.IGParkourEnv._update_reward(e)
+        arrs[tag + "_obs"] = obs
+        arrs[tag + "_reward"] = e._reward_buf.clone()
+        for k, v in e._info["rewards"].items():
+            arrs[tag + "_r_" + k] = v
+        tables[tag] = {"config": {k: v for k, v in over.items()},
+                       "obs_shapes": [[k, bool(v["use_normalizer"]), [int(d) for d in v["shape"]]] for k, v in shapes.items()],
+                       "obs_dim": int(obs.shape[1])}
+    assert np.array_equal(npy(arrs["default_obs"]), z["obs"]) and np.allclose(npy(arrs["default_reward"]), z["reward"], atol=1e-7)
+    save("g26_obs_variants", **arrs)
+    shipped = {}
+    for name in ("data/envs/ig_parkour_env.yaml", "data/terrains/dm_env_civilization.yaml"):
+        with open(os.path.join(REF, name)) as f:
+            shipped[name] = yaml.safe_load(f)
+    with open(os.path.join(OUT, "g26_obs_variants.json"), "w") as f:
+        json.dump({"variants": tables, "shipped_configs": shipped}, f, indent=1, sort_keys=True)
+    print("wrote g26_obs_variants.json", {k: v["obs_dim"] for k, v in tables.items()})
+
+
 def gen_core():
     rng = np.random.default_rng(0)
     torch.manual_seed(0)
@@ -1658,7 +1754,8 @@ def main():
     run = {"core": gen_core, "voxel-mesh": lambda: gen_voxel_mesh(np.random.default_rng(10)), "dataset-yaml": gen_dataset_yaml,
            "procgen": gen_procgen, "terrain-geometry": gen_terrain_geometry, "done-branches": gen_done_branches, "ppo-loss": gen_ppo_loss,
            "normalizer": gen_normalizer, "trackers": gen_trackers, "action-head": gen_action_head, "recorded-files": gen_recorded_files,
-           "motion-opt": gen_motion_opt, "mgdm": gen_mgdm, "motion-edit": gen_motion_edit, "sim-config": gen_sim_config, "stage-scripts": gen_stage_scripts, "experience-buffer": gen_experience_buffer}
+           "motion-opt": gen_motion_opt, "mgdm": gen_mgdm, "motion-edit": gen_motion_edit, "sim-config": gen_sim_config, "stage-scripts": gen_stage_scripts, "experience-buffer": gen_experience_buffer,
+           "obs-variants": gen_obs_variants}
     picked = [s_ for s_ in STAGES if "--only-" + s_ in sys.argv]
     if "--check" in sys.argv:
         # regenerate everything into a scratch directory and compare with the committed fixtures array by array

@@ -499,7 +499,7 @@ def test_device_recorder_equals_per_step_host_lists(env, tmp_path):
 
 def test_config4_parkour_8192_envs_with_record_rollout(tmp_path):
     """BASELINE.json configs[4] at its per-GPU size: 8192 envs on the parkour terrains (stairs / curvy paths / boxes from the reference's
-    generators), training rollout with oracle parity on a slice, then the parc_4_phys_record loop (deterministic policy, device
+    generators), training rollout with oracle parity of every env, then the parc_4_phys_record loop (deterministic policy, device
     recorder on all 8192 envs, finished clips written in the reference's motion format)."""
     import smoke_impl
     from parc_amd import workloads

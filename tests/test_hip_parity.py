@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C-ABI of libparc_hip.so) against the CPU oracle on the same seeded
 inputs and against the golden vectors the reference's Python produced.  fp32; tolerances as in
 test_oracle_golden.py (device libm vs glibc/torch differ by a few ulp in sin/cos/atan2/acos)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -143,12 +145,12 @@ def test_g5_heightmap_gather(name, oracle):
     assert torch.equal(obs2[:7, 871:], obs[:7, 871:]) and torch.all(obs2[7:] == -99.0)
 
 
-def _core_from_golden(km, mlib, name="g6_step"):
+def _core_from_golden(km, mlib, name="g6_step", **env_over):
     from parc_amd.tracker_core import TrackerConfig, TrackerCore
     from parc_amd.util.terrain_util import SubTerrain
     from parc_amd.envs.ig_parkour.default_config import default_env_config
     z = golden(name)
-    cfg = TrackerConfig(default_env_config()["env"], km, 441)
+    cfg = TrackerConfig(dict(default_env_config()["env"], **env_over), km, 441)
     n = z["motion_ids"].shape[0]
     core = TrackerCore(n, DEV, km, mlib, cfg, T(z["rays"]))
     core.set_terrain(SubTerrain.from_arrays(z["hf"], z["min_point"], z["dxdy"], device=DEV))
@@ -201,6 +203,61 @@ def test_g6_fused_post_step(km, mlib, oracle, ref_char, ref_mlib):
                                z["char_root_rot"], z["char_root_vel"], z["char_root_ang_vel"], z["char_dof_pos"], z["char_dof_vel"],
                                z["contact_forces"], z["ray_hfs"])
     close(obs[:, :871], o_obs[:, :871], atol=3e-5)
+
+
+@pytest.mark.parametrize("tag", ["target_xy", "root_height", "no_tar_obs", "no_contact_info", "no_root_h_tracking", "task_product",
+                                 "everything", "mgdm_shipped"])
+def test_g26_observation_and_reward_variants(km, mlib, tag):
+    """Fixture G26 = the reference's own IGParkourEnv._compute_obs / _update_reward (ig_parkour_env.py:1054-1244,1275-1404) run on the
+    G6 state under the non-default switches: has_target_xy_obs (the configuration data/envs/ig_parkour_env.yaml ships),
+    global_root_height_obs, enable_tar_obs / use_contact_info off, track_root_h off, rel_task_w > 0 (multiplicative task reward), and
+    the shipped motion-generator layout with the replan timer behind the target columns.  Device: the fused launch + obs_aux, the row
+    gather parc_assemble_obs, the reward flags of parc_track_cfg_t, the one multiply of rel_task_w."""
+    import json
+    from parc_amd import _hip
+    g = golden("g26_obs_variants")
+    table = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g26_obs_variants.json")))["variants"][tag]
+    over = {k: v for k, v in table["config"].items() if not k.startswith("_") and k != "enable_replan_timer_obs"}
+    core, z = _core_from_golden(km, mlib, **over)
+    replan = tag == "mgdm_shipped"
+    core.target_xy[:] = T(g["target_xy"])
+    core.next_target_xy_time[:] = 1e9                      # no resample: the fixture's targets stay
+    shapes, cols = core.cfg.obs_layout(replan)
+    assert [[k, v["use_normalizer"], list(v["shape"])] for k, v in shapes.items()] == table["obs_shapes"]
+    core.post_step(_hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS)
+    if core.cfg.rel_task_w > 0:
+        torch.mul(core.reward, core.reward_terms[8], out=core.reward)       # IGParkourEnv._finish_reward
+    want = g[tag + "_obs"]
+    if cols is None:
+        out = core.obs
+    else:
+        assert len(cols) == table["obs_dim"] == want.shape[1]
+        out = torch.full((core.N, len(cols)), -7.0, device=DEV)
+        clock = T(g["plan_clock"]).reshape(1)
+        core.assemble_obs(T(cols, torch.int32), out, scalar=clock if replan else None)
+        # a subset call rewrites exactly those rows
+        out2 = out.clone()
+        ids = torch.tensor([3, 17, 40], device=DEV)
+        out2[ids] = 0.0
+        core.assemble_obs(T(cols, torch.int32), out2, scalar=clock if replan else None, env_ids=ids)
+        assert torch.equal(out, out2)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    P = 441
+    names = [r[0] for r in table["obs_shapes"]]
+    widths = [int(np.prod(r[2])) for r in table["obs_shapes"]]
+    o = 0
+    for name, w in zip(names, widths):
+        if name == "hf":
+            _hf_check(torch.tensor(got[:, o:o + w]), want[:, o:o + w], z["hf_boundary"])
+        else:
+            close(got[:, o:o + w], want[:, o:o + w], atol=3e-5)
+        o += w
+    assert o == got.shape[1]
+    close(core.reward, g[tag + "_reward"], atol=2e-6)
+    for i, k in enumerate(("pose_r", "vel_r", "root_pos_r", "root_vel_r", "key_pos_r", "contact_penalty", "task_r1", "task_r2", "total_task_r")):
+        if tag + "_r_" + k in g.files:
+            close(core.reward_terms[i], g[tag + "_r_" + k], atol=2e-6)
 
 
 def test_g6_fused_heightmap_equals_standalone(km, mlib):

@@ -64,6 +64,53 @@ def test_product_library_carries_no_diagnostics():
         assert "PARC_POST_DIAG" not in text and "PARC_ALLOW_STALE_LIB" not in text and "environ.get(\"PARC_POST" not in text
 
 
+def test_g26_observation_layouts_and_the_shipped_configs():
+    """The segment table IGParkourEnv._compute_obs(ret_obs_shapes=True) prints (fixture G26: the reference's own method, one entry per
+    configuration variant) against TrackerConfig.obs_layout, with the gather map checked on a numbered row; and the two env
+    configurations the reference SHIPS - data/envs/ig_parkour_env.yaml (motion-generator env, has_target_xy_obs, replan timer) and
+    data/terrains/dm_env_civilization.yaml - parsed by the reference's yaml and accepted as they are."""
+    from parc_amd.anim.kin_char_model import KinCharModel
+    from parc_amd.assets import humanoid_spec
+    from parc_amd.envs.ig_parkour.default_config import default_env_config
+    from parc_amd.tracker_core import TrackerConfig
+    g = json.load(open(os.path.join(REPO, "tests", "golden", "g26_obs_variants.json")))
+    km = KinCharModel("cpu")
+    km.load_char_file(humanoid_spec.write_mjcf())
+    for tag, table in g["variants"].items():
+        over = {k: v for k, v in table["config"].items() if not k.startswith("_") and k != "enable_replan_timer_obs"}
+        cfg = TrackerConfig(dict(default_env_config()["env"], **over), km, 441)
+        shapes, cols = cfg.obs_layout(tag == "mgdm_shipped")
+        assert [[k, v["use_normalizer"], list(v["shape"])] for k, v in shapes.items()] == table["obs_shapes"], tag
+        width = sum(int(np.prod(r[2])) for r in table["obs_shapes"])
+        assert width == table["obs_dim"] and (cols is None) == (tag in ("default", "no_root_h_tracking", "task_product"))
+        if cols is not None:
+            assert len(cols) == width and max(cols) < cfg.obs_dim + 5
+            virt = np.arange(cfg.obs_dim + 5)              # a numbered virtual row: [fused row | root_h, tx, ty, 0 | clock]
+            row = virt[np.array(cols)]
+            seg = dict(zip([r[0] for r in table["obs_shapes"]], np.split(row, np.cumsum([int(np.prod(r[2])) for r in table["obs_shapes"]])[:-1])))
+            assert list(seg["hf"]) == list(range(871, 1312))
+            if "target_xy" in seg:
+                assert list(seg["target_xy"]) == [1313, 1314]
+            if "replan_t" in seg:
+                assert list(seg["replan_t"]) == [1316]
+            if over.get("global_root_height_obs"):
+                assert list(seg["char_obs"]) == [1312] + list(range(136))
+    for name, tree in g["shipped_configs"].items():
+        env = tree["env"]
+        cfg = TrackerConfig(env, km, 441)
+        mg = float(env["fraction_dm_envs"]) < 1.0
+        shapes, cols = cfg.obs_layout(bool(env.get("enable_replan_timer_obs", False)) and mg)
+        if "ig_parkour_env" in name:
+            assert cfg.has_target_xy_obs and list(shapes) == ["char_obs", "tar_obs", "tar_contacts", "char_contacts", "hf", "target_xy", "replan_t"]
+            assert len(cols) == 1315 == g["variants"]["mgdm_shipped"]["obs_dim"]
+        else:
+            assert cols is None and cfg.obs_dim == 1312
+    with pytest.raises(NotImplementedError):
+        TrackerConfig(dict(default_env_config()["env"], global_obs=True), km, 441)
+    with pytest.raises(NotImplementedError):
+        TrackerConfig(dict(default_env_config()["env"], track_root=False), km, 441)
+
+
 def test_mjcf_parser_matches_reference_parse():
     from parc_amd.anim.kin_char_model import KinCharModel
     from parc_amd.assets import humanoid_spec

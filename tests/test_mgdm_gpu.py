@@ -350,3 +350,113 @@ def test_generator_rows_inside_the_captured_rollout_step(fraction):
     assert (env._ep_num_buf >= ep0).all() and (env._ep_num_buf[n_dm:] > ep0[n_dm:]).any()
     rt = eb.get_data("replan_timer")
     assert float(rt.max()) <= 0.2 + 2.0 / 30.0 + 1e-6 and float(rt.min()) >= 1.0 / 30.0 - 1e-6
+
+
+def test_the_reference_shipped_generator_env_config_builds_and_steps():
+    """data/envs/ig_parkour_env.yaml - the one sample env configuration the reference ships for the motion-generator env
+    (fraction_dm_envs 0.0, has_target_xy_obs, enable_replan_timer_obs) - as the reference's yaml parses it (fixture G26 holds the tree),
+    handed to IGParkourEnv unchanged but for the two things that do not exist here: the character file path (this package's generated
+    copy of the same MJCF) and the diffusion model (mgdm.model_path -> the stand-in planner as mgdm.generator).  The observation row has
+    the reference's segment table for that configuration (G26 'mgdm_shipped': 1315 columns), the two target columns are
+    rotate_2d_vec(target_xy - root_xy, -heading) (ig_parkour_env.py:1215-1218) of the env's own state and the last column is the plan
+    clock; the agent builds its normaliser index set from the table and trains one iteration on it."""
+    import json
+    import os
+    from parc_amd import workloads
+    from parc_amd.assets import humanoid_spec
+    from parc_amd.envs.ig_parkour.ig_parkour_env import IGParkourEnv
+    from parc_amd.util import torch_util
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g26_obs_variants.json")))
+    tree = g["shipped_configs"]["data/envs/ig_parkour_env.yaml"]
+    assert tree["env"]["has_target_xy_obs"] is True and tree["env"]["fraction_dm_envs"] == 0.0
+    tree["env"]["char_file"] = humanoid_spec.write_mjcf()
+    tree["env"]["mgdm"]["generator"] = WalkGenerator()
+    N = 32
+    torch.manual_seed(1)
+    env = IGParkourEnv(tree, N, DEV, False)
+    assert not env.has_dm_envs() and env.has_mgdm_envs()
+    table = g["variants"]["mgdm_shipped"]
+    shapes = env._compute_obs(ret_obs_shapes=True)
+    assert [[k, v["use_normalizer"], list(v["shape"])] for k, v in shapes.items()] == table["obs_shapes"]
+    obs, info = env.reset()
+    assert obs.shape == (N, 1315) == (N, table["obs_dim"]) == (N, env.get_obs_space().shape[0])
+    low, high = env._action_bound_low, env._action_bound_high
+    for _ in range(5):
+        obs, r, done, info = env.step(torch.minimum(torch.maximum(env._ref_dof_pos.clone(), low), high))
+        assert torch.isfinite(obs).all() and torch.isfinite(r).all()
+        assert torch.equal(obs[:, :1312], env._core.obs)
+        heading = torch_util.calc_heading(env._char_root_rot)
+        want = torch_util.rotate_2d_vec(env._target_xy - env._char_root_pos[:, 0:2], -heading)
+        assert (obs[:, 1312:1314] - want).abs().max() < 3e-5 and want.abs().max() > 0.1
+        assert (obs[:, 1314] == env.get_mgdm_env()._mgdm_time_buf[0]).all()
+        env.reset((done != 0).nonzero().flatten())
+    agent = workloads.build_agent(env, DEV, steps_per_iter=4, update_epochs=1, batch_size=2)
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    tinfo = agent._train_iter()
+    assert np.isfinite(tinfo["critic_loss"].item())
+
+
+def test_recording_with_generator_rows(tmp_path):
+    """IGParkourEnv.write_agent_states on an env with both kinds of rows (ig_parkour_env.py:957-995 records whatever rows exist): a
+    generator row records from the call until it FAILS - across time-outs, resets and replans - and is then written under the default
+    name with a slice of the GENERATOR's terrain and its frames unshifted; a dataset row ends with its clip as before.  Checked against
+    the reference's own scheme kept on the host (one list per env, appended every step), with the recorder's buffers forced to grow."""
+    from parc_amd import workloads
+    from parc_amd.envs import base_env
+    from parc_amd.util import safe_pickle
+    N = 32
+    mg_cfg = {"plan_length": 0.5, "ddim_stride": 50, "max_replans": 3, "cfg_scale": 0.7, "target_dist_max": 4.0, "target_dist_min": 1.0,
+              "target_dur_max": 2.0, "target_dur_min": 1.0, "target_heading_scale": 0.5, "generator": WalkGenerator(),
+              "heightmap": {"horizontal_scale": 0.4, "sq_m_per_env": 0.5, "safety_region": 3.0, "num_segments": 6, "platform_heights": [0.0]}}
+    env, _, _ = workloads.build_env("boxes_64clips", N, DEV, seed=5, env_overrides={"fraction_dm_envs": 0.5, "mgdm": mg_cfg,
+                                                                                     "enable_replan_timer_obs": True, "has_target_xy_obs": True})
+    n_dm = env._num_dm_envs
+    env._output_motion_dir = str(tmp_path)
+    env._bypass_record_fail = True
+    obs, info = env.reset()
+    assert obs.shape == (N, 1315)
+    env.build_agent_states_dict("_rec", record_obs=True)
+    env._rec_cap = 4                                   # the allocation has more rows; the next steps force _grow_recorder twice
+    env.write_agent_states()                           # the frame at reset, like DMPPOAgent.record_motions (dm_ppo_agent.py:435-436)
+    lists = [{"frames": [], "contacts": [], "obs": [], "on": True} for _ in range(N)]
+
+    def host_append():
+        fr, co = env._get_char_state_all()
+        for e in range(N):
+            if lists[e]["on"]:
+                lists[e]["frames"].append(fr[e].cpu().numpy())
+                lists[e]["contacts"].append(co[e].cpu().numpy())
+                lists[e]["obs"].append(env._obs_buf[e].cpu().numpy())
+    host_append()
+    torch.manual_seed(3)
+    low, high = env._action_bound_low, env._action_bound_high
+    written = set()
+    for it in range(60):
+        a = low + (high - low) * torch.rand((N, 28), device=DEV)          # flailing: everybody falls within a second or two
+        obs, r, done, info = env.step(a)                                   # (step() records, the flag being set)
+        host_append()
+        for e in (done == base_env.DoneFlags.FAIL.value).nonzero().flatten().tolist():
+            if lists[e]["on"]:
+                lists[e]["on"] = False
+                written.add(e)
+        env.reset((done != 0).nonzero().flatten())
+        if not env.is_writing_agent_states():
+            break
+    assert env._rec_cap >= 16                                              # grew from 4
+    gen_rows = sorted(e for e in written if e >= n_dm)
+    assert len(gen_rows) >= 4, gen_rows
+    for e in gen_rows:
+        d = safe_pickle.load_motion_file_safe(str(tmp_path / ("dm_motion_" + str(e).zfill(3) + ".pkl")))
+        T_ = len(lists[e]["frames"])
+        assert d["frames"].shape == (T_, 34) and d["contacts"].shape == (T_, 15) and d["obs"].shape == (T_, 1315)
+        assert list(d["obs_shapes"])[-2:] == ["target_xy", "replan_t"]
+        np.testing.assert_array_equal(d["contacts"], np.stack(lists[e]["contacts"]))
+        np.testing.assert_array_equal(d["obs"], np.stack(lists[e]["obs"]))
+        want = np.stack(lists[e]["frames"])
+        np.testing.assert_array_equal(d["frames"][:, 2:], want[:, 2:])      # everything but xy is untouched
+        # xy: slice_terrain_around_motion re-bases the clip on the sliced terrain; differences between frames are preserved
+        np.testing.assert_allclose(np.diff(d["frames"][:, 0:2], axis=0), np.diff(want[:, 0:2], axis=0), atol=2e-6)
+        assert d["terrain"]["__class__"] == "util.terrain_util.SubTerrain"
+    if any(e < n_dm for e in written):                                     # dataset rows still end up under their clip's name + suffix
+        assert len(list(tmp_path.glob("*_rec.pkl"))) >= 1
