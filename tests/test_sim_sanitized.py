@@ -22,7 +22,7 @@ def test_simulator_sources_are_clean_under_asan_and_ubsan():
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1:clear_shadow_mmap_threshold=1000000000", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
                OMP_NUM_THREADS="4")
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO, "tests", "test_sim_invariants.py"), "-x", "-q", "-p", "no:cacheprovider",
-                          "-k", "not unwritten_work_memory"], capture_output=True, text=True, env=env, cwd=REPO, timeout=600)
+                          "-m", "not gpu", "-k", "not unwritten_work_memory"], capture_output=True, text=True, env=env, cwd=REPO, timeout=600)
     tail = (res.stdout + res.stderr)[-4000:]
     assert res.returncode == 0, tail
     assert "runtime error" not in res.stdout + res.stderr and "AddressSanitizer" not in res.stdout + res.stderr, tail
