@@ -124,7 +124,7 @@ def launch_ranks(args):
     return 0
 
 
-def launch_check(rank, world, backend):
+def launch_check(rank, world, backend, scaling="weak"):
     """The launcher's plumbing without the workload: rendezvous, barrier, MAX over ranks of a timer, one line on rank 0."""
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -140,8 +140,12 @@ def launch_check(rank, world, backend):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         torch.distributed.all_reduce(ranks)
     if rank == 0:
+        from parc_amd.envs.ig_parkour.default_config import default_agent_config
+        from parc_amd.learning.dm_ppo_agent import DMPPOAgent
+        T, B = DMPPOAgent.rollout_shape(dict(default_agent_config(), mp_scale_rollout=(scaling == "reference")), world)
         print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": int(ranks.item()), "max_rank_seconds": tt.item(),
-                          "backend": torch.distributed.get_backend() if world > 1 else None}))
+                          "backend": torch.distributed.get_backend() if world > 1 else None,
+                          "scaling": "weak" if scaling == "weak" else "strong", "rollout_steps_per_rank": T, "minibatch_envs_multiple": B}))
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -156,6 +160,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grad-allreduce", default="minibatch", choices=["minibatch", "epoch"],
                     help="minibatch = the reference's cadence (default); epoch = one parameter exchange per PPO epoch (north-star)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "reference"],
+                    help="weak (default): every rank runs the one-GPU workload (T = 32 steps, minibatches of 4 x envs rows) - per-GPU work fixed; "
+                         "reference: the reference's own rule (base_agent.py:179-180, ppo_agent.py:27-29): T = ceil(32 / P), minibatch = "
+                         "ceil(4 / P) x envs rows per rank - what parc_3_tracker.py --num_workers P runs unchanged, total work fixed")
     ap.add_argument("--launch-check", action="store_true",
                     help="only start the ranks, rendezvous, barrier and MAX-reduce a timer (no GPU work, no metric): checks the launcher")
     args = ap.parse_args()
@@ -170,7 +178,7 @@ def main():
             args.gpus, world, args.gpus))
     backend = os.environ.get("PARC_DIST_BACKEND", "nccl")
     if args.launch_check:
-        return launch_check(rank, world, backend)
+        return launch_check(rank, world, backend, args.scaling)
     n_dev = torch.cuda.device_count()
     if n_dev < world and backend == "nccl":
         sys.exit("bench.py: --gpus {} needs {} visible GPUs, found {}".format(args.gpus, world, n_dev))
@@ -186,7 +194,7 @@ def main():
     np.random.seed(41 * rank)
 
     env, clips, tiled = workloads.build_env(args.workload, args.envs, dev, seed=0)
-    agent = workloads.build_agent(env, dev, mp_scale_rollout=False)
+    agent = workloads.build_agent(env, dev, mp_scale_rollout=(args.scaling == "reference"))
     agent._optimizer._cadence = args.grad_allreduce
     N, T = env.get_num_envs(), agent._steps_per_iter
     agent._curr_obs, agent._curr_info = env.reset()
@@ -232,12 +240,16 @@ def main():
     # Inside the timed region it runs as a node of the captured rollout graph, where a single node cannot be bracketed
     # with events; so (a) one extra EAGER rollout right after the region with an event pair around every launch, in the
     # loop's real context, and (b) 200 back-to-back launches (the figure the roofline uses).
-    env._core.timing_events = []
-    orig_rollout(T)
+    env._core.timing_events, env._core.timing_overhead = [], []
+    workloads.eager_rollout_like_the_graph(agent, T)
     torch.cuda.synchronize()
-    evs = env._core.timing_events
-    env._core.timing_events = None
-    kern_us = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3 if evs else float("nan")
+    evs, evs0 = env._core.timing_events, env._core.timing_overhead
+    env._core.timing_events = env._core.timing_overhead = None
+    kern_pair_us = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3 if evs else float("nan")
+    pair_cost_us = float(np.mean([a.elapsed_time(b) for a, b in evs0])) * 1e3 if evs0 else 0.0
+    # THE roofline figure: the launch where the product issues it - behind the simulator step of a rollout step, its clip rows and
+    # destination lines evicted by the policy GEMMs in between - event pair minus what an empty event pair costs in the same place
+    kern_us = kern_pair_us - pair_cost_us
     # the product step's flags (the reference STATE is published by the step's tail launch, parc_step_tail, since round 3)
     full = _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS
     for _ in range(10):
@@ -250,10 +262,8 @@ def main():
     e.record()
     torch.cuda.synchronize()
     kern_b2b_us = s.elapsed_time(e) * 1e3 / 200
-    # the product launches this kernel as a node of the rollout hipGraph, so its launch duration is also taken that way: 200
-    # launches captured in one graph, replayed, bracketed by events on the replay stream.  This is the figure the roofline
-    # uses (it is the one rocprofv3's per-kernel duration agrees with); the eager back-to-back loop above adds ~1.5 us of
-    # host dispatch gap per launch and is reported next to it.
+    # standalone: 200 launches captured in one hipGraph, replayed, bracketed by events on the replay stream (warm caches, nothing
+    # else on the chip; what profiles/rNN_post_step_*_kernel_stats.csv measures) - reported as frac_standalone, NOT the roofline figure
     kern_graph_us = kern_b2b_us
     try:
         g = torch.cuda.CUDAGraph()
@@ -271,12 +281,13 @@ def main():
     except Exception:
         pass
     alg_bytes = N * POST_STEP_BYTES_PER_ENV
-    achieved = alg_bytes / (kern_graph_us * 1e-6) / 1e9
+    achieved = alg_bytes / (kern_us * 1e-6) / 1e9
+    achieved_standalone = alg_bytes / (kern_graph_us * 1e-6) / 1e9
     # HBM traffic per launch and the VALU instruction count come from the PMC passes of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE in
     # separate passes, gfx950-corrected; SQ_INSTS_VALU), committed under profiles/: counters cannot be read from inside this process, so
     # these two are PROFILE CONSTANTS valid for exactly this workload and env count (null otherwise), and are labelled as such.
     def committed_profile(workload, what):
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             for name in ("{}_post_step_{}_{}.json".format(rnd, workload, what), "{}_post_step_{}.json".format(rnd, what)):
                 pth = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(pth) and (workload in name or workload == "boxes_64clips"):
@@ -298,7 +309,7 @@ def main():
             valu = {"wave_instructions_per_launch": n_valu, "source": ssrc + " (committed profile, not measured in this run)",
                     "lane_ops_per_algorithmic_byte": n_valu * 64.0 / alg_bytes,
                     "ridge_lane_ops_per_byte": 1024 * 16 * 2.4e9 / (HBM_PEAK_GBPS * 1e9), "issue_bound_us": issue_us,
-                    "frac_of_valu_issue_peak": issue_us / kern_graph_us}
+                    "frac_of_valu_issue_peak": issue_us / kern_us, "frac_of_valu_issue_peak_standalone": issue_us / kern_graph_us}
 
     def time_launches(fn, iters):
         """us per launch: `iters` launches captured in one hipGraph and replayed between two events (kernel time without the host's
@@ -399,7 +410,8 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            # weak: per-GPU work fixed; --scaling reference: the reference's rule, total samples per iteration fixed = "strong"
+            "scaling": "weak" if args.scaling == "weak" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -407,25 +419,30 @@ def main():
                        if args.workload == "boxes_64clips" else args.workload,
                        "envs_per_gpu": N, "env_steps_per_bench_step": N * T, "rollout_steps": T, "update_epochs": agent._update_epochs,
                        "minibatch": agent._batch_size * N, "sim_substeps": env._sim_steps * env._substeps, "parallelism": "dp{}".format(world),
+                       "scaling_rule": ("per-rank work fixed (T = 32, minibatch = 4 x envs): weak scaling" if args.scaling == "weak" else
+                                        "the reference's rule: T = ceil(32 / P) = {}, minibatch = ceil(4 / P) x envs = {} rows per rank "
+                                        "(base_agent.py:179-180, ppo_agent.py:27-29)".format(T, agent._batch_size * N)),
                        "grad_allreduce": "per minibatch (reference cadence)" if args.grad_allreduce == "minibatch"
                        else "per PPO epoch (parameter + momentum averaging)"},
             "roofline": {"kernel": "track_post_kernel (fused K5 heightmap gather + K3 K2 K4 K6-K10)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "achieved_is": "ALGORITHMIC bytes per launch (SURVEY.md 8d: 13 592 B/env) / measured launch time; the clip database "
-                                        "and heightfield of this workload sit in L2, so the HBM-side traffic is lower",
-                         "traffic_source": (traffic_src + " (committed profile, not measured in this run)") if traffic else None,
-                         "frac_measured_traffic": (traffic / (kern_graph_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         "achieved_is": "ALGORITHMIC bytes per launch (SURVEY.md 8d: 13 592 B/env) / us_per_launch = the launch IN THE ROLLOUT "
+                                        "STEP, where the product issues it (behind the simulator launch; its clip rows and destination lines "
+                                        "were evicted by the policy GEMMs since the previous step): {} HIP-event pairs around it in the step's "
+                                        "launch sequence issued eagerly, minus the cost of an empty event pair recorded right behind each "
+                                        "(profiles/r04_rollout_kernel_stats.csv is rocprofv3's figure for the same launches)".format(len(evs)),
+                         "us_per_launch": kern_us, "us_event_pair": kern_pair_us, "us_empty_event_pair": pair_cost_us,
+                         "launches_event_timed": len(evs), "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac_standalone": achieved_standalone / HBM_PEAK_GBPS, "us_per_launch_standalone": kern_graph_us,
+                         "standalone_is": "200 identical launches replayed in one hipGraph: warm caches, nothing else on the chip "
+                                          "(profiles/r04_post_step_boxes_64clips_kernel_stats.csv)",
+                         "us_per_launch_eager_back_to_back": kern_b2b_us,
+                         "traffic_source": (traffic_src + " (committed profile of the standalone launch, not measured in this run)") if traffic else None,
+                         "frac_measured_traffic": (traffic / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                          "binding_roofline": "HBM by SURVEY's classification; measured: neither HBM (frac_measured_traffic) nor vector issue "
                                              "(valu.frac_of_valu_issue_peak) is saturated - the launch is bound by the dependent chains of its pose waves "
-                                             "(6 waves per workgroup, 70 VGPRs) and the drain of its row stores (DESIGN.md section 3, "
-                                             "profiles/r03_post_step_attempts.txt)",
-                         "in_the_rollout_step": "us_per_launch is the launch repeated in one hipGraph (the condition of the committed rocprof "
-                                                "summaries); inside the rollout step's graph the same launch takes 17.6 us by rocprofv3 "
-                                                "(0.40 of the HBM peak; every kernel of that graph takes >= 4.5 us, a launch that returns at "
-                                                "entry 4.6 instead of 1.6 us: profiles/r03_post_step_in_rollout.txt); "
-                                                "us_per_launch_event_pairs_in_rollout_loop is that launch between two events, event cost included",
-                         "algorithmic_bytes_per_launch": alg_bytes, "us_per_launch": kern_graph_us, "us_per_launch_eager_back_to_back": kern_b2b_us,
-                         "us_per_launch_event_pairs_in_rollout_loop": kern_us, "launches_event_timed": len(evs), "valu": valu},
+                                             "(6 waves per workgroup, 70 VGPRs) and the drain of its row stores (DESIGN.md section 3)",
+                         "valu": valu},
             "rollout": ("one hipGraph replay per env step" + (", finished envs reset on the device inside the graph" if any(k[2] for k in agent._graphs)
                                                                else " + eager reset of finished envs")) if agent._graphs else "eager",
             "kernels": extra,

@@ -93,18 +93,23 @@ class DMPPOAgent(torch.nn.Module):
             self._test_tracking_error_tracker = TrackingErrorTracker(self.get_num_envs(), self._device)
 
     # ------------------------------------------------------------------ config (base_agent.py:170-182, ppo_agent.py:21-51)
+    @staticmethod
+    def rollout_shape(config, num_procs):
+        """(steps_per_iter, batch_size) of one rank.  The reference divides the rollout length and the minibatch by the world size
+        (base_agent.py:179-180, ppo_agent.py:27-29: ceil(32 / P) steps, ceil(4 / P) x num_envs rows per minibatch) so that the samples
+        per iteration and the number of optimizer steps stay what they are on one GPU; "mp_scale_rollout: false" keeps the per-rank
+        work fixed instead (weak scaling)."""
+        P = int(num_procs) if config.get("mp_scale_rollout", True) else 1
+        return int(np.ceil(config["steps_per_iter"] / P)), int(np.ceil(config["batch_size"] / P))
+
     def _load_params(self, config):
-        # the reference divides the rollout length and the minibatch by the world size (base_agent.py:179-180,
-        # ppo_agent.py:27-29) so samples/iteration stay constant; "mp_scale_rollout: false" keeps per-rank work fixed
-        P = mp_util.get_num_procs() if config.get("mp_scale_rollout", True) else 1
         self._discount = config["discount"]
         self._iters_per_output = config["iters_per_output"]
         self._iters_per_checkpoint = config["iters_per_checkpoint"]
         self._normalizer_samples = config.get("normalizer_samples", np.inf)
         self._test_episodes = config["test_episodes"]
-        self._steps_per_iter = int(np.ceil(config["steps_per_iter"] / P))
+        self._steps_per_iter, self._batch_size = self.rollout_shape(config, mp_util.get_num_procs())
         self._update_epochs = config["update_epochs"]
-        self._batch_size = int(np.ceil(config["batch_size"] / P))
         self._td_lambda = config["td_lambda"]
         self._ppo_clip_ratio = config["ppo_clip_ratio"]
         self._norm_adv_clip = config["norm_adv_clip"]

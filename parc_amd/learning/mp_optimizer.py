@@ -249,16 +249,42 @@ class MPOptimizer:
     def get_steps(self):
         return self._steps
 
+    def _flat_view_of_params(self):
+        """(flat tensor holding every parameter, scatter-back function or None): the flat parameter buffer itself where the parameters
+        are views of it (flat SGD), a packed copy otherwise"""
+        if self._flat_sgd:
+            return self._flat_param, None
+        flat = torch.cat([p.detach().reshape(-1) for p in self._param_list])
+
+        def scatter(src):
+            off = 0
+            with torch.no_grad():
+                for p in self._param_list:
+                    p.copy_(src[off:off + p.numel()].view_as(p))
+                    off += p.numel()
+        return flat, scatter
+
     def sync(self):
+        """rank 0's parameters to every rank: ONE broadcast of the flat buffer (the reference sends one tensor per parameter,
+        mp_optimizer.py:69-74: 16 collectives for the two MLPs)"""
+        if not mp_util.enable_mp():
+            return
         with torch.no_grad():
-            for p in self._param_list:
-                p.copy_(mp_util.broadcast(p))
+            flat, scatter = self._flat_view_of_params()
+            torch.distributed.broadcast(flat, src=mp_util.ROOT_PROC_RANK)      # in place on the flat parameter buffer
+            if scatter is not None:
+                scatter(flat)
 
     def _check_synced(self):
-        synced = True
-        for p in self._param_list:
-            if not torch.equal(p, mp_util.broadcast(p)):
-                synced = False
+        """do all ranks hold rank 0's parameters, bit for bit?  One broadcast of a flat copy + one 4-byte MIN-reduce
+        (mp_optimizer.py:76-90 of the reference: one broadcast per parameter)"""
+        if not mp_util.enable_mp():
+            return True
+        with torch.no_grad():
+            flat, _ = self._flat_view_of_params()
+            ref = flat.clone()
+            torch.distributed.broadcast(ref, src=mp_util.ROOT_PROC_RANK)
+            synced = torch.equal(flat, ref)
         buf = torch.tensor([int(synced)], dtype=torch.int, device=self._param_list[0].device)
         mp_util.reduce_inplace_min(buf)
         return buf.item() != 0

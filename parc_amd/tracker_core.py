@@ -217,6 +217,7 @@ class TrackerCore:
         self._buf_struct = None
         self._buf_struct_reset = None
         self.timing_events = None      # bench.py: list of (start, end) torch.cuda.Event pairs around full post-step launches
+        self.timing_overhead = None    # bench.py: list of empty (start, end) pairs recorded right behind them
 
     def set_terrain(self, terrain):
         self.terrain = terrain
@@ -301,6 +302,11 @@ class TrackerCore:
         if timed:
             ev1.record()
             self.timing_events.append((ev0, ev1))
+            if self.timing_overhead is not None:      # an EMPTY pair right behind it: what two event records cost by themselves
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record()
+                eb.record()
+                self.timing_overhead.append((ea, eb))
 
     def assemble_obs(self, col_map, out, scalar=None, env_ids=None):
         """rows of a non-default observation layout (TrackerConfig.obs_layout) gathered from the fused rows, obs_aux and one scalar"""

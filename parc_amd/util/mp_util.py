@@ -66,8 +66,8 @@ def init(rank, num_procs, device, master_port=None):
     global_mp_device = device
     global_num_procs = num_procs
     assert num_procs > 0
-    if str(device).startswith("cuda") and torch.cuda.is_available():
-        torch.cuda.set_device(device)            # RCCL binds a communicator to the current device
+    if str(device).startswith("cuda") and torch.cuda.is_available() and torch.device(device).index is not None:
+        torch.cuda.set_device(device)            # RCCL binds a communicator to the current device (a bare "cuda" keeps the current one)
     if num_procs > 1 and not torch.distributed.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if master_port is not None:

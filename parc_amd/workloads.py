@@ -91,3 +91,30 @@ def build_core(name, num_envs, device, seed=0):
     core.dof_state.view(n, 28, 2)[..., 0] = core.ref_dof_pos
     core.rigid_body_state.view(n, 15, 13)[..., 0:3] = core.ref_body_pos
     return core, clips, tiled
+
+
+def eager_rollout_like_the_graph(agent, num_steps):
+    """Measurement helper (bench.py, tools/rollout_only.py --eager): the launches the captured rollout step consists of - same
+    kernels, same order, same device-side restart of finished envs, device-scalar write row - issued eagerly, so that a single launch can
+    be bracketed by events or read from a profiler trace (kernel nodes of a replayed hipGraph can be neither: events captured into a
+    graph are not re-recorded by a replay, and rocprofv3 inflates the duration of every graph node by ~3 us)."""
+    env, eb = agent._env, agent._exp_buffer
+    snapshots = getattr(env, "_info_snapshots", None)
+    if snapshots is not None:
+        env._info_snapshots = False
+    eb.set_device_head(agent._head_t)
+    agent._in_graph_step = True
+    try:
+        device_reset = hasattr(env, "reset_done") and env.supports_device_reset()
+        for _ in range(num_steps):
+            agent._head_t.fill_(eb._buffer_head)
+            agent._exp_prob_t.fill_(agent._get_exp_prob())
+            done = agent._train_step_body(device_reset)
+            if not device_reset:
+                agent._curr_obs, agent._curr_info = agent._reset_done_envs(done)
+            eb.inc()
+    finally:
+        eb.set_device_head(None)
+        agent._in_graph_step = False
+        if snapshots is not None:
+            env._info_snapshots = snapshots

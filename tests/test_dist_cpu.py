@@ -36,6 +36,41 @@ def _worker(rank, world, port, out):
     loss = torch.mean(torch.square(model(x) - y))
     opt.step(loss, model=model, max_norm=1000.0)
     assert opt._check_synced()
+    # sync() / _check_synced() are ONE broadcast of a flat buffer each, whatever the number of parameters (4 here, 16 in the agent)
+    calls = []
+    real_bc = torch.distributed.broadcast
+    torch.distributed.broadcast = lambda t, src, *a, **k: (calls.append(int(t.numel())), real_bc(t, src, *a, **k))[1]
+    try:
+        n_all = sum(p.numel() for p in model.parameters())
+        opt.sync()
+        assert calls == [n_all], calls
+        assert opt._check_synced() and calls == [n_all, n_all]
+        if rank == 1:                               # a desynchronised rank is detected, and sync() repairs it
+            with torch.no_grad():
+                list(model.parameters())[2].add_(1e-3)
+        assert not opt._check_synced()
+        opt.sync()
+        assert opt._check_synced()
+    finally:
+        torch.distributed.broadcast = real_bc
+    # the reference's scaling rule at world 2 (base_agent.py:179-180, ppo_agent.py:27-29; bench.py --scaling reference): half the
+    # rollout, half the minibatch per rank - the same number of optimizer steps per epoch, each one an exchange of the flat gradient
+    from parc_amd.envs.ig_parkour.default_config import default_agent_config
+    from parc_amd.learning.dm_ppo_agent import DMPPOAgent
+    T_, B_ = DMPPOAgent.rollout_shape(default_agent_config(), world)
+    assert (T_, B_) == (16, 2) and DMPPOAgent.rollout_shape(dict(default_agent_config(), mp_scale_rollout=False), world) == (32, 4)
+    assert DMPPOAgent.rollout_shape(default_agent_config(), 8) == (4, 1) and DMPPOAgent.rollout_shape(default_agent_config(), 1) == (32, 4)
+    torch.manual_seed(500)
+    m5 = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2))
+    o5 = mp_optimizer.MPOptimizer({"type": "SGD", "learning_rate": 0.05, "allreduce_buckets": 3}, list(m5.parameters()))
+    n_env = 3                                       # rows per env-step of this rank; a minibatch = B_ * n_env rows of its T_ * n_env samples
+    torch.manual_seed(600 + rank)
+    xs = torch.randn(T_ * n_env, 6)
+    steps = 0
+    for lo in range(0, T_ * n_env, B_ * n_env):
+        o5.step(torch.mean(torch.square(m5(xs[lo:lo + B_ * n_env]) - 0.5)))
+        steps += 1
+    assert steps == 32 // 4 and o5.get_steps() == steps and o5._check_synced()      # as many optimizer steps per epoch as on one GPU
     nrm = normalizer.Normalizer((3,), device="cpu", non_norm_indices=torch.tensor([2]))
     nrm.record(torch.full((5, 3), float(rank + 1)))
     nrm.update()
@@ -152,6 +187,12 @@ def test_bench_launcher_starts_the_ranks_itself():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["ranks_seen"] == 2
+    assert line["scaling"] == "weak" and line["rollout_steps_per_rank"] == 32 and line["minibatch_envs_multiple"] == 4
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--launch-check", "--scaling", "reference"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["scaling"] == "strong" and line["rollout_steps_per_rank"] == 16 and line["minibatch_envs_multiple"] == 2
     env.pop("PARC_DIST_BACKEND")
     if not torch.cuda.is_available():
         bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8"], capture_output=True, text=True, env=env, timeout=300)

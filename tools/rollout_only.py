@@ -18,13 +18,17 @@ mp_util.init(0, 1, dev)
 torch.manual_seed(0)
 env, _, _ = workloads.build_env("boxes_64clips", 4096, dev, seed=0)
 agent = workloads.build_agent(env, dev, mp_scale_rollout=False)
+rollout = agent._rollout_train
+if "--eager" in sys.argv:            # the same launches without the hipGraph (rocprofv3's per-kernel durations are only trustworthy for
+    sys.argv.remove("--eager")      # eager launches: it adds ~3 us to every kernel node of a replayed graph, profiles/r04_rocprof_graph_node_inflation.txt)
+    rollout = lambda k: workloads.eager_rollout_like_the_graph(agent, k)
 agent._curr_obs, agent._curr_info = env.reset()
 agent._init_train()
-agent._rollout_train(8)          # warm-up + graph capture
+rollout(8)          # warm-up + graph capture
 torch.cuda.synchronize()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 t0 = time.time()
-agent._rollout_train(n)
+rollout(n)
 torch.cuda.synchronize()
 dt = time.time() - t0
 print("rollout steps/s %.1f  ms/step %.3f  env-steps/s %.0f" % (n / dt, dt / n * 1e3, n * 4096 / dt))
