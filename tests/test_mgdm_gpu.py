@@ -352,11 +352,12 @@ def test_generator_rows_inside_the_captured_rollout_step(fraction):
     assert float(rt.max()) <= 0.2 + 2.0 / 30.0 + 1e-6 and float(rt.min()) >= 1.0 / 30.0 - 1e-6
 
 
-def test_the_reference_shipped_generator_env_config_builds_and_steps():
+def test_the_reference_shipped_generator_env_config_builds_and_steps(tmp_path):
     """data/envs/ig_parkour_env.yaml - the one sample env configuration the reference ships for the motion-generator env
     (fraction_dm_envs 0.0, has_target_xy_obs, enable_replan_timer_obs) - as the reference's yaml parses it (fixture G26 holds the tree),
-    handed to IGParkourEnv unchanged but for the two things that do not exist here: the character file path (this package's generated
-    copy of the same MJCF) and the diffusion model (mgdm.model_path -> the stand-in planner as mgdm.generator).  The observation row has
+    handed to IGParkourEnv unchanged but for what does not exist here: the character file path (this package's generated copy of the
+    same MJCF), the diffusion model (mgdm.model_path -> the stand-in planner as mgdm.generator) and the authors' output locations
+    (../Data/terrains/..., output/_motions/... -> the test's scratch directory).  The observation row has
     the reference's segment table for that configuration (G26 'mgdm_shipped': 1315 columns), the two target columns are
     rotate_2d_vec(target_xy - root_xy, -heading) (ig_parkour_env.py:1215-1218) of the env's own state and the last column is the plan
     clock; the agent builds its normaliser index set from the table and trains one iteration on it."""
@@ -371,6 +372,9 @@ def test_the_reference_shipped_generator_env_config_builds_and_steps():
     assert tree["env"]["has_target_xy_obs"] is True and tree["env"]["fraction_dm_envs"] == 0.0
     tree["env"]["char_file"] = humanoid_spec.write_mjcf()
     tree["env"]["mgdm"]["generator"] = WalkGenerator()
+    tree["env"]["mgdm"]["terrain_save_path"] = str(tmp_path / "mgdm_terrain.pkl")
+    tree["env"]["dm"]["terrain_save_path"] = str(tmp_path / "dm_terrain.pkl")
+    tree["env"]["output_motion_dir"] = str(tmp_path / "recorded")
     N = 32
     torch.manual_seed(1)
     env = IGParkourEnv(tree, N, DEV, False)
