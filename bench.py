@@ -240,16 +240,17 @@ def main():
     # Inside the timed region it runs as a node of the captured rollout graph, where a single node cannot be bracketed
     # with events; so (a) one extra EAGER rollout right after the region with an event pair around every launch, in the
     # loop's real context, and (b) 200 back-to-back launches (the figure the roofline uses).
-    env._core.timing_events, env._core.timing_overhead = [], []
+    env._core.timing_events = []
     workloads.eager_rollout_like_the_graph(agent, T)
     torch.cuda.synchronize()
-    evs, evs0 = env._core.timing_events, env._core.timing_overhead
-    env._core.timing_events = env._core.timing_overhead = None
-    kern_pair_us = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e3 if evs else float("nan")
-    pair_cost_us = float(np.mean([a.elapsed_time(b) for a, b in evs0])) * 1e3 if evs0 else 0.0
+    pairs = env._core.timing_events
+    env._core.timing_events = None
     # THE roofline figure: the launch where the product issues it - behind the simulator step of a rollout step, its clip rows and
-    # destination lines evicted by the policy GEMMs in between - event pair minus what an empty event pair costs in the same place
-    kern_us = kern_pair_us - pair_cost_us
+    # destination lines evicted by the policy GEMMs in between -, by a pair of events bound to the dispatch itself (hipExtLaunchKernel:
+    # the kernel's own begin / end time stamps, the ones rocprofv3 reports; an event pair recorded AROUND a launch reads ~5 us more)
+    in_rollout = [pr.elapsed_us() for pr in pairs]
+    kern_us = float(np.mean(in_rollout)) if in_rollout else float("nan")
+    evs = pairs
     # the product step's flags (the reference STATE is published by the step's tail launch, parc_step_tail, since round 3)
     full = _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS
     for _ in range(10):
@@ -428,10 +429,12 @@ def main():
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "achieved_is": "ALGORITHMIC bytes per launch (SURVEY.md 8d: 13 592 B/env) / us_per_launch = the launch IN THE ROLLOUT "
                                         "STEP, where the product issues it (behind the simulator launch; its clip rows and destination lines "
-                                        "were evicted by the policy GEMMs since the previous step): {} HIP-event pairs around it in the step's "
-                                        "launch sequence issued eagerly, minus the cost of an empty event pair recorded right behind each "
-                                        "(profiles/r04_rollout_kernel_stats.csv is rocprofv3's figure for the same launches)".format(len(evs)),
-                         "us_per_launch": kern_us, "us_event_pair": kern_pair_us, "us_empty_event_pair": pair_cost_us,
+                                        "were evicted by the policy GEMMs since the previous step): mean over the {} launches of one rollout, the "
+                                        "step's launch sequence issued eagerly, each timed by a HIP event pair bound to its own dispatch "
+                                        "(hipExtLaunchKernel through parc_track_post_step_timed = the dispatch's begin / end time stamps; "
+                                        "profiles/r04_rollout_kernel_stats.csv is rocprofv3's figure for the same launches)".format(len(evs)),
+                         "us_per_launch": kern_us, "us_per_launch_min": float(np.min(in_rollout)) if in_rollout else None,
+                         "us_per_launch_max": float(np.max(in_rollout)) if in_rollout else None,
                          "launches_event_timed": len(evs), "algorithmic_bytes_per_launch": alg_bytes,
                          "frac_standalone": achieved_standalone / HBM_PEAK_GBPS, "us_per_launch_standalone": kern_graph_us,
                          "standalone_is": "200 identical launches replayed in one hipGraph: warm caches, nothing else on the chip "

@@ -261,6 +261,14 @@ int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_
                          parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
                          const float *ray_xy);
 
+/* The same call with two hipEvent_t (created by the caller with timing enabled) bound to the fused kernel's dispatch
+ * (hipExtLaunchKernel): after the stream has passed it, hipEventElapsedTime(start, stop) is the duration of that one launch by the
+ * dispatch's own time stamps.  Results are identical to parc_track_post_step; bench.py uses it to time the launch where the rollout
+ * step issues it (an event pair recorded AROUND a launch adds ~5 us of event handling on this runtime).  Not capturable in a graph. */
+int parc_track_post_step_timed(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
+                               parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
+                               const float *ray_xy, void *start_event, void *stop_event);
+
 /* Observation rows of the non-default layouts of IGParkourEnv._compute_obs (ig_parkour_env.py:1054-1244): global_root_height_obs
  * prepends the root height, enable_tar_obs = False / use_contact_info = False leave column blocks out, has_target_xy_obs and the
  * replan timer append columns behind the heightmap.  out[e, c] = V[e, col_map[c]] where the virtual row V[e] is
@@ -343,7 +351,15 @@ typedef struct {
     int32_t row_bytes;
     int32_t convert;
 } parc_record_field_t;
-int parc_record_step(void *stream, int n_envs, const int64_t *head, int n_fields, const parc_record_field_t *fields);
+int parc_record_step(void *stream, int n_envs, int64_t *head, int n_fields, const parc_record_field_t *fields, int advance_mod,
+                     int32_t *ticket);
+/* advance_mod > 0: after the copies, *head <- (*head + 1) % advance_mod - ExperienceBuffer.inc (experience_buffer.py:41-44) on the
+ * device, by the launch's last workgroup (ticket: one int32, zero before the first call, left zero); 0: *head is only read. */
+
+/* The random numbers of one rollout step in one launch (counter-based Philox4x32-10 keyed by `seed`): n_uniform floats in [0, 1) and
+ * n_normal floats ~ N(0, 1).  state: two uint64 on the device - [0] the step counter, advanced by the launch; [1] a ticket, zero
+ * between launches.  Same (seed, counter) -> same numbers on every run. */
+int parc_rng_step(void *stream, uint64_t seed, uint64_t *state, float *uniform_out, int64_t n_uniform, float *normal_out, int64_t n_normal);
 
 /* ---- K21 episodic return tracker: DMPPOReturnTracker.update  learning/dm_ppo_return_tracker.py:6-99 in one launch.
  * rewards [K, reward_stride] (row k = term k, first n_envs entries), done [N] i32; state: return_buf [K,N], ep_len [N] i64,
@@ -371,7 +387,8 @@ int parc_normalize_clamp(void *stream, int64_t rows, int dim, const float *x, co
 
 /* ---- K22: Normalizer.record  learning/normalizer.py:28-34: acc[0,:] += sum over rows of x, acc[1,:] += sum over rows of x*x
  * in one pass with a fixed summation order.  x [rows, dim] row-major, acc [2, dim], dim a multiple of 4, 16-byte aligned;
- * workspace: parc_moments_workspace_floats(rows, dim) floats of scratch (caller-owned). */
+ * workspace: parc_moments_workspace_floats(rows, dim) floats of scratch (caller-owned) whose FIRST 64 floats are zero before the first
+ * call (tickets of the second stage, which runs inside the same launch; the call leaves them zero). */
 int64_t parc_moments_workspace_floats(int64_t rows, int dim);
 int parc_moments_accumulate(void *stream, int64_t rows, int dim, const float *x, float *acc, float *workspace);
 

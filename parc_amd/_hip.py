@@ -104,8 +104,9 @@ _lib = None
 # per-source optimisation level.  parc_sim_ref.hip (the one-env-per-lane reference kernel, diagnostics library only) is built at
 # -O2: at -O3 hipcc (ROCm 7.2, gfx950) miscompiles it (results diverge from the -O0/-O1/-O2 builds and from the g++ host build of the
 # same source; GVN scalar PRE on the unrolled 3x3 helpers).  The product's simulator kernels (parc_sim.hip) are correct at
-# every level (profiles/r02_sim_o3_bisect.txt) and are built at whichever measured faster.
-OPT_LEVEL = {"parc_kin.hip": os.environ.get("PARC_KIN_OPT", "-O3 -fno-slp-vectorize"), "parc_sim.hip": os.environ.get("PARC_SIM_OPT", "-O3"), "parc_sim_ref.hip": "-O2"}
+# every level (profiles/r02_sim_o3_bisect.txt) and are built at whichever measured faster: -O3 WITHOUT the SLP vectoriser since round 4
+# (its v_pk_* pairs come with a third more register moves: 114.9 -> 100.8 us per 4096-env step, profiles/r04_sim_step_variants.txt).
+OPT_LEVEL = {"parc_kin.hip": os.environ.get("PARC_KIN_OPT", "-O3 -fno-slp-vectorize"), "parc_sim.hip": os.environ.get("PARC_SIM_OPT", "-O3 -fno-slp-vectorize"), "parc_sim_ref.hip": "-O2"}
 
 
 DIGEST_PATH = os.path.join(LIB_DIR, "libparc_hip.digest")
@@ -201,6 +202,8 @@ def _declare(L):
     L.parc_calc_motion_frame.argtypes = [c_vp, MotionLibS, c_int, c_vp, c_vp] + [c_vp] * 7
     L.parc_motion_lib_build.argtypes = [c_vp, CharModelS, MotionLibS, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
     L.parc_track_post_step.argtypes = [c_vp, CharModelS, MotionLibS, TerrainS, TrackCfgS, EnvBuffersS, c_vp, c_int, c_int, c_vp]
+    L.parc_track_post_step_timed.argtypes = L.parc_track_post_step.argtypes + [c_vp, c_vp]
+    L.parc_track_post_step_timed.restype = c_int
     L.parc_assemble_obs.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int]
     L.parc_assemble_obs.restype = c_int
     L.parc_update_fail_rates.argtypes = [c_vp, c_int, c_int, c_vp, c_vp, c_f, c_vp]
@@ -242,8 +245,10 @@ def _declare(L):
     L.parc_return_tracker_workspace_floats.argtypes = [c_int]
     L.parc_return_tracker_workspace_floats.restype = c_i64
     L.parc_return_tracker_update.restype = c_int
-    L.parc_record_step.argtypes = [c_vp, c_int, c_vp, c_int, c_vp]
+    L.parc_record_step.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp]
     L.parc_record_step.restype = c_int
+    L.parc_rng_step.argtypes = [c_vp, ctypes.c_uint64, c_vp, c_vp, c_i64, c_vp, c_i64]
+    L.parc_rng_step.restype = c_int
     L.parc_reset_apply.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int] + [c_vp] * 9
     L.parc_reset_apply.restype = c_int
     L.parc_reset_sample_apply.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_f, c_vp, c_vp, c_int, c_f] + [c_vp] * 11
@@ -264,7 +269,7 @@ EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hf
             "parc_relu_bwd_bias_grad", "parc_ppo_loss_packed", "parc_weighted_colsum", "parc_sgd_workspace_floats", "parc_sgd_momentum_step",
             "parc_pose_chain_forward", "parc_pose_chain_backward", "parc_points_hf_sdf_grad", "parc_body_points_world", "parc_body_points_world_grad",
             "parc_quat_diff_angle", "parc_quat_diff_angle_grad", "parc_temporal_terms", "parc_temporal_terms_grad", "parc_step_tail",
-            "parc_assemble_obs"]
+            "parc_assemble_obs", "parc_track_post_step_timed", "parc_rng_step"]
 
 
 def check(rc, what):
@@ -289,3 +294,32 @@ def terrain_struct(hf, min_point, dxdy):
     assert hf.dtype == torch.float32 and hf.is_contiguous() and hf.dim() == 2
     return TerrainS(ptr(hf), int(hf.shape[0]), int(hf.shape[1]), float(min_point[0]), float(min_point[1]),
                     float(dxdy[0]), float(dxdy[1]))
+
+
+class HipEventPair:
+    """Two raw hipEvent_t for parc_track_post_step_timed (torch creates its event handles lazily, at the first record)."""
+    _rt = None
+
+    def __init__(self):
+        if HipEventPair._rt is None:
+            HipEventPair._rt = ctypes.CDLL("libamdhip64.so")
+        self.start, self.stop = c_vp(), c_vp()
+        for ev in (self.start, self.stop):
+            rc = HipEventPair._rt.hipEventCreate(ctypes.byref(ev))
+            if rc != 0:
+                raise RuntimeError("hipEventCreate -> %d" % rc)
+
+    def elapsed_us(self):
+        ms = ctypes.c_float()
+        rc = HipEventPair._rt.hipEventElapsedTime(ctypes.byref(ms), self.start, self.stop)
+        if rc != 0:
+            raise RuntimeError("hipEventElapsedTime -> %d" % rc)
+        return ms.value * 1e3
+
+    def __del__(self):
+        try:
+            for ev in (self.start, self.stop):
+                if ev:
+                    HipEventPair._rt.hipEventDestroy(ev)
+        except Exception:       # noqa: BLE001  (interpreter shutdown)
+            pass

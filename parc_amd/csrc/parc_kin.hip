@@ -2,6 +2,7 @@
 // written for gfx950 (MI355X): 64-lane wavefronts, 16-lane body groups, LDS-staged observation rows.
 // C-ABI in include/parc_hip.h.  Reference citations are relative to the reference root.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/parc_hip.h"
@@ -1692,9 +1693,9 @@ __global__ __launch_bounds__(REF_STATE_THREADS) void ref_state_kernel(parc_char_
     ref_state_group(m, ml, buf, env_ids, n_total, what, (int)(blockIdx.x * (REF_STATE_THREADS / GRP) + (threadIdx.x >> 4)), threadIdx.x & 15);
 }
 
-extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
-                                    parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
-                                    const float *ray_xy) {
+static int track_post_step_impl(void *stream, const parc_char_model_t &model, const parc_motion_lib_t &mlib, const parc_terrain_t &terrain,
+                                const parc_track_cfg_t &cfg, const parc_env_buffers_t &buf, const int64_t *env_ids, int n_sel, int what,
+                                const float *ray_xy, hipEvent_t start_event, hipEvent_t stop_event) {
     if (!model_ok(model) || mlib.num_bodies != model.num_bodies || mlib.dof_size != model.dof_size) return PARC_EINVAL;
 #ifndef PARC_DIAG_BUILD
     if (what & ~PARC_POST_ALL) return PARC_EINVAL;   // only the documented PARC_POST_* bits (the timing-ablation bits exist in the diagnostics build only)
@@ -1721,11 +1722,31 @@ extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_
         PARC_CHECK_LAUNCH();
     }
     if (what & (PARC_POST_OBS | PARC_POST_REWARD_DONE)) {
-        hipLaunchKernelGGL(track_post_kernel, dim3((n + POST_EPB - 1) / POST_EPB), dim3(64 * (2 + (cfg.num_tar_steps > 0 ? (cfg.num_tar_steps + 1) / 2 : 0) + (((what & PARC_POST_OBS) && (what & PARC_POST_HF)) ? 1 : 0))), 0,
-                           (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, n, what, ray_xy);
+        const dim3 grid((n + POST_EPB - 1) / POST_EPB);
+        const dim3 block(64 * (2 + (cfg.num_tar_steps > 0 ? (cfg.num_tar_steps + 1) / 2 : 0) + (((what & PARC_POST_OBS) && (what & PARC_POST_HF)) ? 1 : 0)));
+        if (start_event || stop_event)
+            // the same launch with a pair of events bound to THIS dispatch: they carry the kernel's own begin / end time stamps (what a
+            // profiler reads from the dispatch), not the time between two separate event records around it
+            hipExtLaunchKernelGGL(track_post_kernel, grid, block, 0, (hipStream_t)stream, start_event, stop_event, 0, model, mlib, terrain, cfg, buf,
+                                  env_ids, n, what, ray_xy);
+        else
+            hipLaunchKernelGGL(track_post_kernel, grid, block, 0, (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, n, what, ray_xy);
         PARC_CHECK_LAUNCH();
     }
     return PARC_OK;
+}
+
+extern "C" int parc_track_post_step(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
+                                    parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
+                                    const float *ray_xy) {
+    return track_post_step_impl(stream, model, mlib, terrain, cfg, buf, env_ids, n_sel, what, ray_xy, nullptr, nullptr);
+}
+
+extern "C" int parc_track_post_step_timed(void *stream, parc_char_model_t model, parc_motion_lib_t mlib, parc_terrain_t terrain,
+                                          parc_track_cfg_t cfg, parc_env_buffers_t buf, const int64_t *env_ids, int n_sel, int what,
+                                          const float *ray_xy, void *start_event, void *stop_event) {
+    if (!start_event || !stop_event) return PARC_EINVAL;
+    return track_post_step_impl(stream, model, mlib, terrain, cfg, buf, env_ids, n_sel, what, ray_xy, (hipEvent_t)start_event, (hipEvent_t)stop_event);
 }
 
 // =============================================================================================
@@ -1803,35 +1824,60 @@ extern "C" int parc_reset_apply(void *stream, int n_envs, const int32_t *mask, c
 // kernel 2 (one thread per env) inverts them by bisection and does the bookkeeping of reset_apply_kernel.
 // =============================================================================================
 __global__ __launch_bounds__(256) void reset_cdf_kernel(int M, const float *__restrict__ weights, const float *__restrict__ fail_rates, float min_w,
-                                                        float *cdf) {
-    __shared__ float part[256];
+                                                        float *cdf);
+
+#define RESET_CDF_LDS 4096          // clips whose cumulative weights a workgroup builds for itself in LDS (16 KB); more: reset_cdf_kernel first
+
+// cumulative weights into `out` (LDS or global), by the 256 threads of one workgroup: thread t sums its chunk, the chunk sums are
+// scanned, every thread writes its chunk's running sums - the same steps, hence the same fp32 sums, in every workgroup that runs it
+PARC_DEV void build_reset_cdf(int M, const float *__restrict__ weights, const float *__restrict__ fail_rates, float min_w, float *out, float *part) {
     const int chunk = (M + 255) / 256;
     const int i0 = min((int)threadIdx.x * chunk, M), i1 = min(i0 + chunk, M);
     float s = 0.f;
     for (int i = i0; i < i1; ++i) s += (fail_rates ? fmaxf(fail_rates[i], min_w) : 1.0f) * weights[i];
     part[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float run = 0.f;
-        for (int t = 0; t < 256; ++t) {
-            const float v = part[t];
-            part[t] = run;
-            run += v;
-        }
+    // inclusive scan of the 256 chunk sums by all threads (log steps; one thread walking them cost as much as the launch this saves)
+    for (int off = 1; off < 256; off <<= 1) {
+        float v = part[threadIdx.x];
+        if ((int)threadIdx.x >= off) v += part[threadIdx.x - off];
+        __syncthreads();
+        part[threadIdx.x] = v;
+        __syncthreads();
     }
-    __syncthreads();
-    float run = part[threadIdx.x];
+    float run = part[threadIdx.x] - s;           // sum of the chunks in front of this thread's
     for (int i = i0; i < i1; ++i) {
         run += (fail_rates ? fmaxf(fail_rates[i], min_w) : 1.0f) * weights[i];
-        cdf[i] = run;
+        out[i] = run;
     }
+    __syncthreads();
 }
 
+__global__ __launch_bounds__(256) void reset_cdf_kernel(int M, const float *__restrict__ weights, const float *__restrict__ fail_rates, float min_w,
+                                                        float *cdf) {
+    __shared__ float part[256];
+    build_reset_cdf(M, weights, fail_rates, min_w, cdf, part);
+}
+
+template <bool CDF_IN_LDS>
 __global__ __launch_bounds__(256) void reset_sample_apply_kernel(int n, const int32_t *__restrict__ done_in, int32_t *mask, const float *__restrict__ u,
-                                                                 int M, const float *__restrict__ cdf, const float *__restrict__ lengths,
+                                                                 int M, const float *__restrict__ cdf_global, const float *__restrict__ weights,
+                                                                 const float *__restrict__ fail_rates, float min_w,
+                                                                 const float *__restrict__ lengths,
                                                                  const float *__restrict__ offs, int R, float noise_scale, int64_t *mid, int64_t *tid,
                                                                  float *toff, float *xyoff, int32_t *timestep, float *time_buf, int32_t *done,
                                                                  float *next_target_time, int64_t *ep_num, float *init_noise_xy) {
+    __shared__ float s_cdf[CDF_IN_LDS ? RESET_CDF_LDS : 1];
+    __shared__ float s_part[256];
+    const float *cdf = cdf_global;
+    if (CDF_IN_LDS) {
+        // every workgroup builds the table for itself (M <= 4096 entries: a few hundred flops) instead of a one-workgroup launch in
+        // front of this one; workgroup 0 also publishes it (tests read it back)
+        build_reset_cdf(M, weights, fail_rates, min_w, s_cdf, s_part);
+        if (blockIdx.x == 0 && cdf_global)
+            for (int i = threadIdx.x; i < M; i += 256) const_cast<float *>(cdf_global)[i] = s_cdf[i];
+        cdf = s_cdf;
+    }
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const int finished = done_in[e] != PARC_DONE_NULL;
@@ -1870,10 +1916,18 @@ extern "C" int parc_reset_sample_apply(void *stream, int n_envs, const int32_t *
         !cdf_workspace || !init_noise_xy)
         return PARC_EINVAL;
     if (n_envs == 0) return PARC_OK;
-    hipLaunchKernelGGL(reset_cdf_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_motions, motion_weights, fail_rates, min_weight, cdf_workspace);
-    hipLaunchKernelGGL(reset_sample_apply_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_envs, done_flags, mask, uniforms,
-                       n_motions, cdf_workspace, motion_lengths, motion_offsets, terrains_per_motion, noise_scale, motion_ids, motion_terrain_ids,
-                       motion_time_offsets, motion_xy_offset, timestep_buf, time_buf, done, next_target_time, ep_num, init_noise_xy);
+    if (n_motions <= RESET_CDF_LDS) {
+        hipLaunchKernelGGL(reset_sample_apply_kernel<true>, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_envs, done_flags, mask,
+                           uniforms, n_motions, cdf_workspace, motion_weights, fail_rates, min_weight, motion_lengths, motion_offsets,
+                           terrains_per_motion, noise_scale, motion_ids, motion_terrain_ids, motion_time_offsets, motion_xy_offset, timestep_buf,
+                           time_buf, done, next_target_time, ep_num, init_noise_xy);
+    } else {
+        hipLaunchKernelGGL(reset_cdf_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n_motions, motion_weights, fail_rates, min_weight, cdf_workspace);
+        hipLaunchKernelGGL(reset_sample_apply_kernel<false>, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_envs, done_flags, mask,
+                           uniforms, n_motions, cdf_workspace, motion_weights, fail_rates, min_weight, motion_lengths, motion_offsets,
+                           terrains_per_motion, noise_scale, motion_ids, motion_terrain_ids, motion_time_offsets, motion_xy_offset, timestep_buf,
+                           time_buf, done, next_target_time, ep_num, init_noise_xy);
+    }
     PARC_CHECK_LAUNCH();
     return PARC_OK;
 }

@@ -292,7 +292,7 @@ struct record_fields_t {
     parc_record_field_t f[PARC_RECORD_MAX_FIELDS];
 };
 
-__global__ __launch_bounds__(256) void record_step_kernel(int n_envs, const int64_t *__restrict__ head, record_fields_t fields) {
+__global__ __launch_bounds__(256) void record_step_kernel(int n_envs, int64_t *head, record_fields_t fields, int advance_mod, int32_t *ticket) {
     const parc_record_field_t f = fields.f[blockIdx.y];
     const size_t total = (size_t)n_envs * (size_t)f.row_bytes;            // bytes of one time row
     const size_t h = (size_t)head[0];
@@ -301,19 +301,33 @@ __global__ __launch_bounds__(256) void record_step_kernel(int n_envs, const int6
         const int64_t *s = (const int64_t *)f.src;
         int32_t *d = (int32_t *)f.dst + h * (total / 8);
         for (size_t i = tid; i < total / 8; i += nthr) d[i] = (int32_t)s[i];
-        return;
-    }
-    char *d = (char *)f.dst + h * total;
-    const char *s = (const char *)f.src;
-    if (((total | (uintptr_t)d | (uintptr_t)s) & 15) == 0) {
-        for (size_t i = tid; i < total / 16; i += nthr) ((uint4 *)d)[i] = ((const uint4 *)s)[i];
     } else {
-        for (size_t i = tid; i < total / 4; i += nthr) ((uint32_t *)d)[i] = ((const uint32_t *)s)[i];
+        char *d = (char *)f.dst + h * total;
+        const char *s = (const char *)f.src;
+        if (((total | (uintptr_t)d | (uintptr_t)s) & 15) == 0) {
+            for (size_t i = tid; i < total / 16; i += nthr) ((uint4 *)d)[i] = ((const uint4 *)s)[i];
+        } else {
+            for (size_t i = tid; i < total / 4; i += nthr) ((uint32_t *)d)[i] = ((const uint32_t *)s)[i];
+        }
+    }
+    if (advance_mod > 0) {
+        // ExperienceBuffer.inc (experience_buffer.py:41-44) on the device: the LAST workgroup to finish moves the write row on; every
+        // workgroup read `head` when it started, i.e. before it took its ticket, so nobody sees the new value
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int last = (int)(gridDim.x * gridDim.y) - 1;
+            if (atomicAdd(ticket, 1) == last) {
+                head[0] = (int64_t)((h + 1) % (size_t)advance_mod);
+                *ticket = 0;
+            }
+        }
     }
 }
 
-extern "C" int parc_record_step(void *stream, int n_envs, const int64_t *head, int n_fields, const parc_record_field_t *fields) {
-    if (n_envs <= 0 || n_fields <= 0 || n_fields > PARC_RECORD_MAX_FIELDS || !head || !fields) return PARC_EINVAL;
+extern "C" int parc_record_step(void *stream, int n_envs, int64_t *head, int n_fields, const parc_record_field_t *fields, int advance_mod,
+                                int32_t *ticket) {
+    if (n_envs <= 0 || n_fields <= 0 || n_fields > PARC_RECORD_MAX_FIELDS || !head || !fields || advance_mod < 0 || (advance_mod > 0 && !ticket))
+        return PARC_EINVAL;
     record_fields_t args;
     int max_row = 0;
     for (int i = 0; i < n_fields; ++i) {
@@ -325,7 +339,78 @@ extern "C" int parc_record_step(void *stream, int n_envs, const int64_t *head, i
     size_t units = ((size_t)n_envs * (size_t)max_row + 15) / 16;
     unsigned gx = (unsigned)((units + 255) / 256);
     if (gx > 2048u) gx = 2048u;                                          // grid-stride beyond that
-    hipLaunchKernelGGL(record_step_kernel, dim3(gx, (unsigned)n_fields), dim3(256), 0, (hipStream_t)stream, n_envs, head, args);
+    hipLaunchKernelGGL(record_step_kernel, dim3(gx, (unsigned)n_fields), dim3(256), 0, (hipStream_t)stream, n_envs, head, args, advance_mod, ticket);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}
+
+// =============================================================================================
+// The random numbers of one rollout step in ONE launch: Philox4x32-10 (Salmon et al. 2011; the generator torch's device RNG is built
+// on), keyed by the seed, counter = (thread, 0, step counter lo, hi).  n_uniform floats in [0, 1) (24 random bits, like torch's
+// uniform_) - the env's pool: xy-target resample, restart sampling - and n_normal floats ~ N(0, 1) (Box-Muller on pairs) - the
+// policy's action noise.  state[0] = step counter, advanced by the launch's last workgroup; state[1] = its ticket (zero between launches).
+// Replaces two torch generator launches per step, which inside a replayed hipGraph also cost two fills of the generator's
+// seed / offset cells per replay.
+// =============================================================================================
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void rng_step_kernel(uint64_t seed, uint64_t *state, float *__restrict__ uniform_out, int64_t n_uniform,
+                                                       float *__restrict__ normal_out, int64_t n_normal) {
+    const uint64_t step = state[0];
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // one Philox block = 4 outputs
+    const int64_t qu = (n_uniform + 3) / 4, qn = (n_normal + 3) / 4;
+    if (q < qu + qn) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        if (q < qu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (4 * q + k < n_uniform) uniform_out[4 * q + k] = (float)(r[k] >> 8) * (1.0f / 16777216.0f);
+        } else {
+            const int64_t b = 4 * (q - qu);
+            float z[4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float u1 = ((float)(r[2 * k] >> 8) + 1.0f) * (1.0f / 16777216.0f);       // (0, 1]
+                const float u2 = (float)(r[2 * k + 1] >> 8) * (1.0f / 16777216.0f);
+                const float rad = sqrtf(-2.0f * __logf(u1));
+                float sn, cs;
+                __sincosf(6.283185307179586f * u2, &sn, &cs);
+                z[2 * k] = rad * cs;
+                z[2 * k + 1] = rad * sn;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (b + k < n_normal) normal_out[b + k] = z[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long *ticket = reinterpret_cast<unsigned long long *>(state + 1);
+        if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1ull) {
+            state[0] = step + 1;
+            *ticket = 0ull;
+        }
+    }
+}
+
+extern "C" int parc_rng_step(void *stream, uint64_t seed, uint64_t *state, float *uniform_out, int64_t n_uniform, float *normal_out,
+                             int64_t n_normal) {
+    if (!state || n_uniform < 0 || n_normal < 0 || (n_uniform > 0 && !uniform_out) || (n_normal > 0 && !normal_out)) return PARC_EINVAL;
+    const int64_t quads = (n_uniform + 3) / 4 + (n_normal + 3) / 4;
+    if (quads == 0) return PARC_OK;
+    hipLaunchKernelGGL(rng_step_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, state, uniform_out, n_uniform,
+                       normal_out, n_normal);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }
@@ -559,8 +644,10 @@ extern "C" int parc_normalize_clamp(void *stream, int64_t rows, int dim, const f
 // the result does not depend on scheduling.
 // =============================================================================================
 #define MOM_ROWS 64
-__global__ __launch_bounds__(256) void moments_partial_kernel(int rows, int dim4, const float4 *__restrict__ x, float4 *__restrict__ partial) {
+__global__ __launch_bounds__(256) void moments_kernel(int rows, int dim4, int chunks, const float4 *__restrict__ x, float4 *partial, float4 *acc,
+                                                      int32_t *tickets) {
     __shared__ float4 red[2][4][64];
+    __shared__ int s_last;
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * MOM_ROWS, r1 = min(r0 + MOM_ROWS, rows);
@@ -581,37 +668,45 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(int rows, int dim4
         o.x = (a.x + b.x) + (d.x + e.x); o.y = (a.y + b.y) + (d.y + e.y); o.z = (a.z + b.z) + (d.z + e.z); o.w = (a.w + b.w) + (d.w + e.w);
         partial[((size_t)blockIdx.y * 2 + rg) * dim4 + c] = o;
     }
+    // stage 2 in the same launch: the LAST row chunk of this column block to finish (ticket per column block) adds the chunks' partial
+    // rows in chunk order - the order does not depend on which workgroup that is - and folds them into the accumulator
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&tickets[blockIdx.x], 1) == chunks - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (rg < 2 && c < dim4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 16
+        for (int k = 0; k < chunks; ++k) {          // (unrolled: the loads of 16 chunks are in flight together; the adds stay in chunk order)
+            const float4 v = partial[((size_t)k * 2 + rg) * dim4 + c];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        float4 a = acc[(size_t)rg * dim4 + c];
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        acc[(size_t)rg * dim4 + c] = a;
+    }
+    if (threadIdx.x == 0) tickets[blockIdx.x] = 0;
 }
 
-__global__ __launch_bounds__(256) void moments_final_kernel(int chunks, int dim4, const float4 *__restrict__ partial, float4 *acc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over [2, dim4]
-    if (i >= 2 * dim4) return;
-    const int which = i / dim4, c = i - which * dim4;
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 16
-    for (int k = 0; k < chunks; ++k) {          // (unrolled: the loads of 16 chunks are in flight together; the adds stay in chunk order)
-        const float4 v = partial[((size_t)k * 2 + which) * dim4 + c];
-        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-    }
-    float4 a = acc[i];
-    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-    acc[i] = a;
-}
+#define MOM_TICKET_FLOATS 64        // the column blocks' tickets, in front of the partial rows (dim <= 16384)
 
 extern "C" int64_t parc_moments_workspace_floats(int64_t rows, int dim) {
     if (rows < 0 || dim <= 0) return -1;
-    return ((rows + MOM_ROWS - 1) / MOM_ROWS) * 2 * (int64_t)dim;
+    return ((rows + MOM_ROWS - 1) / MOM_ROWS) * 2 * (int64_t)dim + MOM_TICKET_FLOATS;
 }
 
+// workspace: parc_moments_workspace_floats(rows, dim) floats whose FIRST 64 are zero before the first call (the kernel leaves them zero)
 extern "C" int parc_moments_accumulate(void *stream, int64_t rows, int dim, const float *x, float *acc, float *workspace) {
     if (rows < 0 || dim <= 0 || (dim & 3) || (((uintptr_t)x | (uintptr_t)acc | (uintptr_t)workspace) & 15)) return PARC_EINVAL;
     if (rows == 0) return PARC_OK;
     if (rows > (int64_t)MOM_ROWS * 65535) return PARC_EUNSUPPORTED;
     const int dim4 = dim / 4, chunks = (int)((rows + MOM_ROWS - 1) / MOM_ROWS);
-    hipLaunchKernelGGL(moments_partial_kernel, dim3((dim4 + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, (int)rows, dim4, (const float4 *)x,
-                       (float4 *)workspace);
-    hipLaunchKernelGGL(moments_final_kernel, dim3((2 * dim4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, chunks, dim4,
-                       (const float4 *)workspace, (float4 *)acc);
+    if ((dim4 + 63) / 64 > MOM_TICKET_FLOATS) return PARC_EUNSUPPORTED;
+    int32_t *tickets = reinterpret_cast<int32_t *>(workspace);          // the FIRST 64 floats: the same cells whatever the row count
+    hipLaunchKernelGGL(moments_kernel, dim3((dim4 + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, (int)rows, dim4, chunks, (const float4 *)x,
+                       (float4 *)(workspace + MOM_TICKET_FLOATS), (float4 *)acc, tickets);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }

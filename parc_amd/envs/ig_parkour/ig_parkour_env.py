@@ -216,6 +216,35 @@ class IGParkourEnv(base_env.BaseEnv):
         t = self._mgdm_env.get_mgdm_time_buf() if self._enable_replan_timer_obs else None
         self._core.assemble_obs(self._obs_cols, self._obs_buf, scalar=t, env_ids=env_ids)
 
+    _rng_instances = 0
+
+    def step_randoms(self, action_dim):
+        """Every random number of one rollout step in ONE launch (parc_rng_step, counter-based Philox keyed by torch's seed at the first
+        call): returns the N(0, 1) action noise [N, action_dim] of the policy and refills the env's uniform pool (xy-target resample,
+        restart sampling) that the step() which follows consumes - instead of two launches of torch's generator, which inside a replayed
+        hipGraph also cost two fills of its seed / offset cells per replay."""
+        c = self._core
+        if getattr(self, "_rng_state", None) is None:
+            IGParkourEnv._rng_instances += 1
+            self._rng_seed = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * IGParkourEnv._rng_instances) & 0xFFFFFFFFFFFFFFFF
+            self._rng_state = torch.zeros(2, dtype=torch.int64, device=self._device)
+            self._action_noise = None
+        if self._action_noise is None or self._action_noise.shape[1] != action_dim:
+            self._action_noise = torch.empty((self._num_envs, action_dim), dtype=torch.float32, device=self._device)
+        _hip.check(_hip.lib().parc_rng_step(_hip.stream(), self._rng_seed, _hip.ptr(self._rng_state), _hip.ptr(c.rand_pool), c.rand_pool.numel(),
+                                            _hip.ptr(self._action_noise), self._action_noise.numel()), "parc_rng_step")
+        c.rand_pool_prefilled = True
+        return self._action_noise
+
+    def _draw_step_uniforms(self):
+        """the uniform pool of this step: already drawn together with the policy's noise (step_randoms), or one torch launch"""
+        c = self._core
+        if getattr(c, "rand_pool_prefilled", False):
+            c.rand_pool_prefilled = False
+        else:
+            c.rand_pool.uniform_()
+        c.rand_pool_fresh = True
+
     def _finish_reward(self):
         """rel_task_w > 0: the task term multiplies the tracking reward (ig_parkour_env.py:1399-1404; the kernel left deepmimic_r in
         the reward buffer and total_task_r in its term row, TrackerConfig)"""
@@ -282,8 +311,21 @@ class IGParkourEnv(base_env.BaseEnv):
         mg = self._mgdm_env
         if mg is not None:         # (a replan may rebuild the plans' clip library with another shape: its table pointers are launch arguments)
             ml = mg._motion_lib
-            out += ("mgdm", mg._demo_mode, None if ml is None else ml._rows.data_ptr(), mg._dont_auto_update_targets)
+            # the plans' clip library enters the launches as pointers AND shapes: a library rebuilt at the same address with other
+            # dimensions must not replay a graph captured for the old one
+            out += ("mgdm", mg._demo_mode, None if ml is None else (ml._rows.data_ptr(), tuple(ml._rows.shape), ml.num_motions()),
+                    mg._dont_auto_update_targets)
         return out
+
+    def host_step_state(self):
+        """what a step changes on the HOST (the generator sub-env's fp32 plan clock and its replan flag): snapshot / restore around a
+        hipGraph capture that fails - the capture runs the step's host code once, the eager step that follows runs it again"""
+        mg = self._mgdm_env
+        return None if mg is None else (mg._plan_time_host, mg._replan_flag)
+
+    def restore_host_step_state(self, state):
+        if state is not None:
+            self._mgdm_env._plan_time_host, self._mgdm_env._replan_flag = state
 
     def set_rand_reset(self, val=None):
         val = (not self._rand_reset) if val is None else val
@@ -511,8 +553,7 @@ class IGParkourEnv(base_env.BaseEnv):
         _hip.check(L.parc_sim_step_tick(*sim_args, _hip.ptr(self._timestep_buf), _hip.ptr(self._time_buf), float(self._timestep)),
                    "parc_sim_step_tick")
         # _update_misc (incl. the xy target resample) / _update_observations / _update_reward / _update_done in one launch
-        c.rand_pool.uniform_()          # all uniforms of this step and of the restarts that follow it (tracker_core.rand_pool)
-        c.rand_pool_fresh = True
+        self._draw_step_uniforms()      # all uniforms of this step and of the restarts that follow it (tracker_core.rand_pool)
         # (the reference STATE - ref_* buffers - rides in the fail-rate launch below: nothing in the fused launch reads it)
         c.post_step(_hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS)
         c.step_tail(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight)
@@ -549,8 +590,7 @@ class IGParkourEnv(base_env.BaseEnv):
         mg.update_time(self._timestep)
         mg.update_misc(fixed_shape=True)
         if n_dm > 0:
-            c.rand_pool.uniform_()
-            c.rand_pool_fresh = True
+            self._draw_step_uniforms()
             c.post_step(_hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS, rows=(0, n_dm))
             c.step_tail(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight, rows=(0, n_dm))     # fail rates + reference state
         mg._post(_hip.POST_REF | _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF)

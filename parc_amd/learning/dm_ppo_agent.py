@@ -6,7 +6,8 @@ learning/dm_ppo_agent.py DMPPOAgent -- as one class with the same method names, 
 (ppo_agent.py:212-330) and checkpoint keys.  What changes is where the work runs:
   * TD(lambda) and the advantage normalisation are HIP kernels (parc_amd/learning/rl_util.py) instead of a Python loop;
   * the minibatch sampler gathers only the six buffers the loss reads;
-  * the large-critic-loss guard and the NaN trap are evaluated on the device (no ``.item()`` per minibatch);
+  * the large-critic-loss guard is evaluated on the device and the NaN trap reads one stack of losses per update epoch (no ``.item()``
+    per minibatch; the offending minibatch is dumped and training stops, like ppo_agent.py:242-252);
   * gradients live in one flat buffer that RCCL all-reduces in place (learning/mp_optimizer.py).
 """
 import enum
@@ -75,7 +76,6 @@ class DMPPOAgent(torch.nn.Module):
         self._mode = AgentMode.TRAIN
         self._curr_obs = None
         self._curr_info = None
-        self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self._device)
         self._ppo_cfg = None
         if str(self._device).startswith("cuda") and config.get("tuned_gemms", True):
             enable_tuned_gemms()
@@ -87,6 +87,8 @@ class DMPPOAgent(torch.nn.Module):
         self._graph_warm = 0
         self._exp_prob_t = torch.ones([1, 1], dtype=torch.float32, device=self._device)
         self._head_t = torch.zeros([1], dtype=torch.int64, device=self._device)
+        self._head_dev, self._exp_prob_dev = 0, 1.0      # what those two device cells hold (host mirror)
+        self._compute_times = []                         # (row, seconds) of the steps of this rollout, written in one go at its end
         self._replan_time_rows, self._replan_time_src = None, None
         self._ones_mask = None
         if getattr(self._env, "_report_tracking_error", False):
@@ -214,6 +216,7 @@ class DMPPOAgent(torch.nn.Module):
         captured step nothing is written here: _train_step_graph fills the scalar eagerly before every replay."""
         if not getattr(self, "_in_graph_step", False):
             self._exp_prob_t.fill_(exp_prob)
+            self._exp_prob_dev = exp_prob
 
     def _need_normalizer_update(self):
         return self._sample_count < self._normalizer_samples
@@ -257,7 +260,9 @@ class DMPPOAgent(torch.nn.Module):
             else:
                 self._set_exp_prob(exp_prob)
                 mask = torch.bernoulli(self._exp_prob_t.expand(n, 1)).squeeze(-1).contiguous()
-            noise = torch.randn_like(mean)
+            # the env draws the step's random numbers in one launch of its own counter-based generator (action noise + its uniform
+            # pool: IGParkourEnv.step_randoms); torch's generator otherwise
+            noise = self._env.step_randoms(A) if (hasattr(self._env, "step_randoms") and n == self._env.get_num_envs()) else torch.randn_like(mean)
         else:
             mask = torch.zeros(n, dtype=torch.float32, device=mean.device)
             noise = mean                   # unused where the mask is 0
@@ -305,7 +310,7 @@ class DMPPOAgent(torch.nn.Module):
                 if self._replan_time_src is not rt:   # (a tracker env hands out one persistent zero: expand it once, not per step)
                     self._replan_time_src, self._replan_time_rows = rt, rt.expand(self.get_num_envs()).contiguous()
                 items += [("replan_timer", self._replan_time_rows), ("replan_counter", self._env.get_replan_counter())]
-            eb.record_group(items)
+            eb.record_group(items, advance=True)       # the step's last write into the buffer: the device's write row moves on
             return
         eb.record("next_obs", next_obs)
         eb.record("reward", r)
@@ -353,8 +358,14 @@ class DMPPOAgent(torch.nn.Module):
         exp_prob = self._get_exp_prob()
         sig = self._env.host_step_signature() if hasattr(self._env, "host_step_signature") else ()
         key = (self._need_normalizer_update(), exp_prob >= 1.0, device_reset) + tuple(sig)
-        self._head_t.fill_(eb._buffer_head)
-        self._exp_prob_t.fill_(exp_prob)             # read by the captured Bernoulli draw: the value of THIS step, not of the capture
+        # the write row and the exploration probability live on the device; the host only re-writes them when they differ from what
+        # the device holds (the captured step moves the row on itself: ExperienceBuffer.record_group(advance=True)) - no fill per step
+        if self._head_dev != eb._buffer_head:
+            self._head_t.fill_(eb._buffer_head)
+            self._head_dev = eb._buffer_head
+        if self._exp_prob_dev != exp_prob:
+            self._exp_prob_t.fill_(exp_prob)         # read by the captured Bernoulli draw: the value of THIS step, not of the capture
+            self._exp_prob_dev = exp_prob
         g = self._graphs.get(key)
         if g is None:
             if self._graph_warm < 2:                 # library handles / workspaces are created by eager steps first
@@ -366,6 +377,7 @@ class DMPPOAgent(torch.nn.Module):
             if snapshots is not None:
                 self._env._info_snapshots = False
             count0 = self._obs_norm._new_count
+            host0 = self._env.host_step_state() if hasattr(self._env, "host_step_state") else None
             captured = False
             try:
                 torch.cuda.synchronize()
@@ -388,6 +400,8 @@ class DMPPOAgent(torch.nn.Module):
             self._obs_norm._new_count = count0       # capture enqueues nothing; the replay below is this step
             if not captured:
                 torch.cuda.synchronize()
+                if hasattr(self._env, "restore_host_step_state"):
+                    self._env.restore_host_step_state(host0)     # the failed capture ran the step's host code; the eager step runs it again
                 done = self._train_step_body(False)
                 self._graph_fallback_reset = True
                 return done
@@ -397,12 +411,23 @@ class DMPPOAgent(torch.nn.Module):
             fresh = False
         g, done = self._graphs[key]
         g.replay()
+        self._head_dev = (self._head_dev + 1) % eb._buffer_length      # the replayed step moved the device's write row on
         if not fresh and hasattr(self._env, "host_step_replayed"):
             self._env.host_step_replayed()           # what the step changes on the host (the device part is the graph)
         if key[0]:
             self._obs_norm._new_count += self.get_num_envs()
-        eb.get_data("compute_time")[eb._buffer_head].fill_(time.time() - self._env._start_compute_time)
+        self._compute_times.append((eb._buffer_head, time.time() - self._env._start_compute_time))
         return done
+
+    def _flush_compute_times(self):
+        """info["compute_time"] of the rollout's graph-replayed steps into the experience buffer: one small copy per rollout instead of
+        one fill per step"""
+        if self._compute_times:
+            rows = torch.tensor([r for r, _ in self._compute_times], dtype=torch.long, device=self._device)
+            vals = torch.tensor([v for _, v in self._compute_times], dtype=torch.float32, device=self._device)
+            buf = self._exp_buffer.get_data("compute_time")
+            buf[rows] = vals.unsqueeze(1).expand(-1, buf.shape[1])
+            self._compute_times = []
 
     def _rollout_train(self, num_steps):
         for _ in range(num_steps):
@@ -418,6 +443,7 @@ class DMPPOAgent(torch.nn.Module):
             if not dev_reset:
                 self._curr_obs, self._curr_info = self._reset_done_envs(done)
             self._exp_buffer.inc()
+        self._flush_compute_times()
 
     def _rollout_test(self, num_episodes):
         self._test_return_tracker.reset()
@@ -552,7 +578,6 @@ class DMPPOAgent(torch.nn.Module):
         # "LARGE CRITIC LOSS" guard (ppo_agent.py:225-238): stop the actor gradient when the critic is off, on device
         actor_term = torch.where(critic_loss.detach() > 20.0, actor_loss.detach(), actor_loss)
         loss = actor_term + self._critic_loss_weight * critic_loss
-        self._nan_flag |= torch.isnan(loss.detach()).to(torch.int32)      # NaN trap, checked once per iteration
         info["loss"] = loss
         return info
 
@@ -575,7 +600,6 @@ class DMPPOAgent(torch.nn.Module):
             slots["action_entropy"] = 6
         if self._action_reg_weight != 0:
             slots["action_reg_loss"] = 7
-        self._nan_flag |= torch.isnan(out[0]).to(torch.int32)      # NaN trap, checked once per iteration
         return {"loss": loss, "_packed": out, "_slots": slots}
 
     def _explicit_update_ok(self):
@@ -601,11 +625,27 @@ class DMPPOAgent(torch.nn.Module):
             self._optimizer.step_explicit(write, model=self._model, max_norm=self._max_grad_norm)
         else:
             self._optimizer.step_explicit(write)
-        # logged scalars: one add of the packed vector per minibatch; a NaN loss stays NaN in the sum, which _train_iter checks once
-        if "_packed" in acc:
-            acc["_packed"] += out
-        else:
-            acc["_packed"] = out.clone()
+        # logged scalars: the packed vector of this minibatch; _update_model stacks an epoch's vectors (one launch per epoch, and the
+        # NaN trap reads that stack)
+        acc.append(out)
+
+    def _nan_trap(self, loss_rows, batches, epoch):
+        """The reference stops at the first minibatch whose critic or actor loss is NaN and dumps that batch (ppo_agent.py:242-252).
+        Here the losses of an epoch's minibatches are looked at together - ONE host read per epoch instead of one per minibatch -: at
+        the first NaN row the minibatch that produced it is written to output/debug_batch.pkl and training stops; at most the rest
+        of that epoch (<= 7 optimizer steps) ran on it."""
+        bad = torch.isnan(loss_rows).any(dim=1).tolist()
+        if not any(bad):
+            return
+        k = bad.index(True)
+        import pickle
+        batch_file = os.path.join("output", "debug_batch.pkl")
+        os.makedirs("output", exist_ok=True)
+        with open(batch_file, "wb") as f:
+            pickle.dump({name: v.detach().cpu() for name, v in batches[k].items()}, f)
+        Logger.print("NAN LOSS in minibatch {} of update epoch {}: wrote debug batch file to {}".format(k, epoch, batch_file))
+        raise FloatingPointError("NaN loss in minibatch {} of update epoch {} (batch dumped to {}; the reference prints, dumps and exits "
+                                 "at this point)".format(k, epoch, batch_file))
 
     def _update_model(self):
         self.train()
@@ -621,17 +661,26 @@ class DMPPOAgent(torch.nn.Module):
                 if w != 0:
                     slots[name] = i
             keys = ["norm_obs", "loss_rec"] if self._exp_buffer.has_buffer("loss_rec") else _LOSS_KEYS
-            for _ in range(self._update_epochs):
+            total = None
+            for epoch in range(self._update_epochs):
+                outs, batches = [], []
                 for _ in range(num_batches):
-                    self._minibatch_step_explicit(self._exp_buffer.sample(batch_size, keys=keys), acc)
+                    batches.append(self._exp_buffer.sample(batch_size, keys=keys))
+                    self._minibatch_step_explicit(batches[-1], outs)
+                stack = torch.stack(outs)                               # [minibatches, 16]: loss, critic loss, actor loss, ...
+                self._nan_trap(stack[:, 0:3], batches, epoch)
+                total = stack.sum(dim=0) if total is None else total + stack.sum(dim=0)
+                del batches
                 self._optimizer.end_epoch()
-            packed = acc["_packed"] / (self._update_epochs * num_batches)
-            self._nan_flag |= torch.isnan(packed[0:3]).any().to(torch.int32)
+            packed = total / (self._update_epochs * num_batches)
             return {k: packed[i] for k, i in slots.items()}
-        for _ in range(self._update_epochs):
+        for epoch in range(self._update_epochs):
+            losses, batches = [], []
             for _ in range(num_batches):
                 batch = self._exp_buffer.sample(batch_size, keys=_LOSS_KEYS)
                 info = self._compute_loss(batch)
+                losses.append(info["loss"].detach())
+                batches.append(batch)
                 if self._clip_grad_norm:
                     self._optimizer.step(info["loss"], model=self._model, max_norm=self._max_grad_norm)
                 else:
@@ -644,6 +693,8 @@ class DMPPOAgent(torch.nn.Module):
                     for k, v in info.items():
                         v = v.detach()
                         acc[k] = acc[k] + v if k in acc else v.clone()
+            self._nan_trap(torch.stack(losses).reshape(-1, 1), batches, epoch)
+            del batches
             self._optimizer.end_epoch()          # exchange point of the per-epoch cadence (optimizer: grad_allreduce "epoch")
         steps = self._update_epochs * num_batches
         if "_packed" in acc:
@@ -658,8 +709,6 @@ class DMPPOAgent(torch.nn.Module):
         self._rollout_train(self._steps_per_iter)
         data_info = self._build_train_data()
         train_info = self._update_model()
-        if self._nan_flag.item() != 0:
-            raise FloatingPointError("NaN loss during the PPO update (reference behaviour: dump batch and exit)")
         if self._need_normalizer_update():
             self._obs_norm.update()
         info = {**train_info, **data_info}

@@ -216,8 +216,7 @@ class TrackerCore:
         self._terrain_struct = None
         self._buf_struct = None
         self._buf_struct_reset = None
-        self.timing_events = None      # bench.py: list of (start, end) torch.cuda.Event pairs around full post-step launches
-        self.timing_overhead = None    # bench.py: list of empty (start, end) pairs recorded right behind them
+        self.timing_events = None      # bench.py: list of _hip.HipEventPair bound to the full post-step launches of a rollout
 
     def set_terrain(self, terrain):
         self.terrain = terrain
@@ -294,19 +293,16 @@ class TrackerCore:
             n, ids = 0, _hip.c_vp(0)
         timed = self.timing_events is not None and env_ids is None and rows is None and (what & _hip.POST_REWARD_DONE)
         if timed:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
+            # bench.py: the launch with a pair of events bound to its dispatch (parc_track_post_step_timed) - the kernel's own duration
+            pair = _hip.HipEventPair()
+            _hip.check(_hip.lib().parc_track_post_step_timed(_hip.stream(), self.km.c_struct(), mlib.c_struct(), terrain_struct, self.cfg.struct,
+                                                             self.buffers(reset_rand, rows), ids, n, what, _hip.ptr(self.ray_xy_points),
+                                                             pair.start, pair.stop), "parc_track_post_step_timed")
+            self.timing_events.append(pair)
+            return
         _hip.check(_hip.lib().parc_track_post_step(_hip.stream(), self.km.c_struct(), mlib.c_struct(), terrain_struct,
                                                    self.cfg.struct, self.buffers(reset_rand, rows), ids, n, what, _hip.ptr(self.ray_xy_points)),
                    "parc_track_post_step")
-        if timed:
-            ev1.record()
-            self.timing_events.append((ev0, ev1))
-            if self.timing_overhead is not None:      # an EMPTY pair right behind it: what two event records cost by themselves
-                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ea.record()
-                eb.record()
-                self.timing_overhead.append((ea, eb))
 
     def assemble_obs(self, col_map, out, scalar=None, env_ids=None):
         """rows of a non-default observation layout (TrackerConfig.obs_layout) gathered from the fused rows, obs_aux and one scalar"""

@@ -273,5 +273,8 @@ def load_executing(path):
     reached only through the explicit ``unsafe_pickle`` opt-ins of MotionLib / DeepMimicEnv / motion_edit_lib.load_motion_file, for files
     the user wrote themselves.  Never used on the files that ship with the reference."""
     import pickle
-    with open(path, "rb") as f:
+    from . import terrain_util
+    # the files name their classes by the reference's module paths (util.terrain_util.SubTerrain ...): resolve those to this package for
+    # the duration of the load, whether or not install_reference_aliases() was called - importing the package registers nothing
+    with terrain_util.reference_pickle_path(), open(path, "rb") as f:
         return pickle.load(f)

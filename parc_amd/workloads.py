@@ -115,6 +115,7 @@ def eager_rollout_like_the_graph(agent, num_steps):
             eb.inc()
     finally:
         eb.set_device_head(None)
+        agent._head_dev = -1                 # the device's write row was moved behind the agent's back: re-written before the next replay
         agent._in_graph_step = False
         if snapshots is not None:
             env._info_snapshots = snapshots

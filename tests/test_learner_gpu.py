@@ -309,3 +309,140 @@ def test_flat_sgd_notices_a_rebound_parameter():
     m2.zero_grad(set_to_none=True)
     with pytest.raises(RuntimeError, match="no longer aliases the flat gradient buffer"):
         opt2._check_aliasing()
+
+
+@pytest.mark.parametrize("explicit", [True, False])
+def test_nan_trap_stops_at_the_epoch_and_dumps_the_offending_minibatch(explicit, tmp_path, monkeypatch):
+    """ppo_agent.py:242-252: a NaN critic / actor loss ends the run and the minibatch that produced it is dumped.  Here the trap reads
+    the losses once per update epoch: a batch without any random action (the reference's own NaN case: the mean of an empty selection)
+    is planted in the rollout data, the update raises in the FIRST epoch and output/debug_batch.pkl holds exactly a minibatch that
+    contains planted rows."""
+    import pickle
+    from parc_amd import workloads
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    env, _, _ = workloads.build_env("flat_1clip", 64, DEV, seed=0)
+    agent = workloads.build_agent(env, DEV, steps_per_iter=4, update_epochs=3, batch_size=2, explicit_backward=explicit)
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    agent._train_iter()                                    # a healthy iteration first
+    orig = agent._build_train_data
+
+    def poisoned():
+        info = orig()
+        eb = agent._exp_buffer
+        eb.get_data("rand_action_mask").zero_()              # no random action anywhere: every minibatch's actor loss is 0 / 0
+        if eb.has_buffer("loss_rec"):
+            eb.get_data("loss_rec")[..., 30] = 0.0           # the packed copy the update reads: [norm action 28 | a_logp | adv | MASK | tar_val]
+        return info
+    agent._build_train_data = poisoned
+    with pytest.raises(FloatingPointError, match="minibatch 0 of update epoch 0"):
+        agent._train_iter()
+    d = pickle.load(open(tmp_path / "output" / "debug_batch.pkl", "rb"))
+    key = "loss_rec" if "loss_rec" in d else "rand_action_mask"
+    assert d[key].shape[0] == 2 * 64 and all(not v.is_cuda for v in d.values())
+
+
+def _philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11) in numpy uint64 arithmetic:
+    ctr [n, 4] uint32, key (2,) uint32 -> [n, 4] uint32.  An independent restatement for the test (pinned below by the paper's
+    known-answer vectors)."""
+    c = [ctr[:, i].astype(np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & mask, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & mask]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return np.stack(c, axis=1).astype(np.uint32)
+
+
+def test_rng_step_is_philox_and_its_outputs_are_what_they_claim():
+    """parc_rng_step: one launch per rollout step for the policy's action noise and the env's uniform pool.  (1) the numpy restatement
+    reproduces the Random123 known-answer vectors of Philox4x32-10; (2) the device's uniforms are bit for bit (r >> 8) * 2^-24 of that
+    generator at counter (index / 4, 0, step, 0) and key = seed; (3) the step counter advances by one per launch, the ticket cell
+    returns to zero, and the same (seed, step) gives the same numbers; (4) the normals are Box-Muller pairs of the same stream with the
+    moments of N(0, 1)."""
+    from parc_amd import _hip
+    kat = _philox4x32_10(np.array([[0, 0, 0, 0], [0xFFFFFFFF] * 4, [0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], dtype=np.uint32)[:1],
+                         np.array([0, 0], np.uint32))
+    assert [hex(v) for v in kat[0]] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    kat = _philox4x32_10(np.array([[0xFFFFFFFF] * 4], dtype=np.uint32), np.array([0xFFFFFFFF, 0xFFFFFFFF], np.uint32))
+    assert [hex(v) for v in kat[0]] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    kat = _philox4x32_10(np.array([[0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], dtype=np.uint32), np.array([0xA4093822, 0x299F31D0], np.uint32))
+    assert [hex(v) for v in kat[0]] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+    L = _hip.lib()
+    seed = 0x0123456789ABCDEF
+    nu, nn = 45056 + 3, 4096 * 28
+    state = torch.zeros(2, dtype=torch.int64, device=DEV)
+    uni, nor = torch.empty(nu, device=DEV), torch.empty(nn, device=DEV)
+    outs = []
+    for step in range(3):
+        _hip.check(L.parc_rng_step(_hip.stream(), seed, _hip.ptr(state), _hip.ptr(uni), nu, _hip.ptr(nor), nn), "parc_rng_step")
+        torch.cuda.synchronize()
+        assert state.tolist() == [step + 1, 0]
+        outs.append((uni.cpu().numpy().copy(), nor.cpu().numpy().copy()))
+    qu = (nu + 3) // 4
+    for step in range(3):
+        ctr = np.zeros((qu, 4), np.uint32)
+        ctr[:, 0], ctr[:, 2] = np.arange(qu), step
+        r = _philox4x32_10(ctr, np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32))
+        want = ((r >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).reshape(-1)[:nu]
+        np.testing.assert_array_equal(outs[step][0], want)
+        assert 0.0 <= outs[step][0].min() and outs[step][0].max() < 1.0
+        z = outs[step][1].astype(np.float64)
+        assert abs(z.mean()) < 0.01 and abs(z.var() - 1.0) < 0.02 and abs((z ** 3).mean()) < 0.03 and abs((z ** 4).mean() - 3.0) < 0.1
+        assert np.isfinite(z).all() and np.abs(z).max() < 6.5
+        # Box-Muller of the same stream: quads qu .. qu + nn / 4
+        ctr = np.zeros((nn // 4, 4), np.uint32)
+        ctr[:, 0], ctr[:, 2] = qu + np.arange(nn // 4), step
+        r = _philox4x32_10(ctr, np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32)).astype(np.float64)
+        u1 = (np.floor(r[:, 0::2] / 256.0) + 1.0) / 16777216.0
+        u2 = np.floor(r[:, 1::2] / 256.0) / 16777216.0
+        rad = np.sqrt(-2.0 * np.log(u1))
+        wz = np.stack([rad * np.cos(2 * np.pi * u2), rad * np.sin(2 * np.pi * u2)], axis=-1).reshape(-1)
+        np.testing.assert_allclose(outs[step][1], wz, atol=2e-3, rtol=2e-3)       # __logf / __sincosf on the device
+    assert not np.array_equal(outs[0][0], outs[1][0])
+    state.zero_()                                                  # same (seed, step) -> same numbers
+    _hip.check(L.parc_rng_step(_hip.stream(), seed, _hip.ptr(state), _hip.ptr(uni), nu, _hip.ptr(nor), nn), "parc_rng_step")
+    np.testing.assert_array_equal(uni.cpu().numpy(), outs[0][0])
+    np.testing.assert_array_equal(nor.cpu().numpy(), outs[0][1])
+
+
+def test_record_group_moves_the_device_write_row_and_moments_run_in_one_launch():
+    """ExperienceBuffer.record_group(advance=True): the launch's last workgroup does inc() on the device (row (h + 1) % T), rows land
+    where the host-indexed record() puts them; Normalizer.record in ONE launch (second stage behind per-column-block tickets) equals the
+    column sums for row counts that move the partial rows around in the shared workspace."""
+    from parc_amd.learning.experience_buffer import ExperienceBuffer
+    from parc_amd.learning.normalizer import Normalizer
+    T_, N = 5, 300
+    eb = ExperienceBuffer(T_, N, DEV)
+    ref = ExperienceBuffer(T_, N, DEV)
+    for b in (eb, ref):
+        b.add_buffer("obs", torch.zeros((T_, N, 1312), device=DEV))
+        b.add_buffer("reward", torch.zeros((T_, N), device=DEV))
+        b.add_buffer("ep_num", torch.zeros((T_, N), dtype=torch.int32, device=DEV))
+    head = torch.zeros(1, dtype=torch.int64, device=DEV)
+    eb.set_device_head(head)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for step in range(12):
+        obs, r = torch.randn((N, 1312), generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+        ep = torch.randint(0, 1000, (N,), generator=g).to(DEV)
+        eb.record_group([("obs", obs)])                                    # pre-step group: the row stays
+        assert int(head.item()) == step % T_
+        eb.record_group([("reward", r), ("ep_num", ep)], advance=True)      # post-step group: the row moves on
+        assert int(head.item()) == (step + 1) % T_ and int(eb._ticket.item()) == 0
+        ref.record("obs", obs); ref.record("reward", r); ref.record("ep_num", ep); ref.inc()
+        eb.inc()
+    for k in ("obs", "reward", "ep_num"):
+        assert torch.equal(eb.get_data(k), ref.get_data(k)), k
+    nrm = Normalizer((1312,), device=DEV)
+    tot, tot2, cnt = torch.zeros(1312, dtype=torch.float64), torch.zeros(1312, dtype=torch.float64), 0
+    for rows in (4096, 64, 1000, 4096, 37):
+        x = torch.randn((rows, 1312), generator=g) * 2.0 + 0.5
+        nrm.record(x.to(DEV))
+        tot += x.double().sum(0); tot2 += (x.double() ** 2).sum(0); cnt += rows
+        np.testing.assert_allclose(nrm._acc[0].cpu().numpy(), tot.numpy(), rtol=2e-5, atol=2e-3)
+        np.testing.assert_allclose(nrm._acc[1].cpu().numpy(), tot2.numpy(), rtol=2e-5, atol=2e-3)
+        assert int(nrm._scratch[:64].abs().sum().item()) == 0               # tickets back to zero
+    assert nrm._new_count == cnt

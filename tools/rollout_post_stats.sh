@@ -12,7 +12,6 @@ STEPS=${1:-96}; shift
 O=gpurun_out/rollpost_$TAG
 rm -rf $O && mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/r -- python3 tools/rollout_only.py $STEPS $MODE "$@" > $O/log.txt 2>&1 &&
-find $O/r -name "*kernel_stats.csv" -exec cp {} $O/rollout_kernel_stats.csv \; &&
 find $O/r -name "*kernel_trace.csv" -exec cp {} $O/trace.csv \;
 rm -rf $O/r
 python3 - $O <<'PY'
@@ -33,6 +32,26 @@ for r in rows:
     else:
         prev_sim = False
 half = len(full) // 2
+# per-kernel stats in rocprofv3's own column layout, with the two launch shapes of track_post_kernel kept apart (rocprofv3's stats file
+# has one row per kernel NAME: the full launch behind the simulator and the masked restart launch would be averaged together)
+by = {}
+prev_sim = False
+for r in rows:
+    n = r['Kernel_Name']; d = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    if n.startswith('sim_step_bpl'):
+        prev_sim = True
+    elif n.startswith('track_post_kernel'):
+        n = 'track_post_kernel [full launch of the step, behind the simulator]' if prev_sim else 'track_post_kernel [masked restart launch]'
+        prev_sim = False
+    elif not n.startswith('void at::native::(anonymous namespace)::distribution'):
+        prev_sim = False
+    by.setdefault(n, []).append(d)
+tot = sum(sum(v) for v in by.values())
+with open(O + '/rollout_kernel_stats.csv', 'w', newline='') as f:
+    w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+    for n, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+        w.writerow([n, len(v), sum(v), round(st.mean(v), 3), round(100.0 * sum(v) / tot, 2), min(v), max(v), round(st.pstdev(v), 3)])
 out = {"full_launches": len(full), "full_us_mean": round(st.mean(full), 2), "full_us_mean_second_half": round(st.mean(full[half:]), 2),
        "full_us_median": round(st.median(full[half:]), 2), "full_us_min": round(min(full), 2),
        "masked_restart_launch_us_mean": round(st.mean(masked[len(masked) // 2:]), 2) if masked else None,
