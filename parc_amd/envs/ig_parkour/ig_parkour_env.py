@@ -216,17 +216,16 @@ class IGParkourEnv(base_env.BaseEnv):
         t = self._mgdm_env.get_mgdm_time_buf() if self._enable_replan_timer_obs else None
         self._core.assemble_obs(self._obs_cols, self._obs_buf, scalar=t, env_ids=env_ids)
 
-    _rng_instances = 0
-
     def step_randoms(self, action_dim):
         """Every random number of one rollout step in ONE launch (parc_rng_step, counter-based Philox keyed by torch's seed at the first
         call): returns the N(0, 1) action noise [N, action_dim] of the policy and refills the env's uniform pool (xy-target resample,
-        restart sampling) that the step() which follows consumes - instead of two launches of torch's generator, which inside a replayed
+        restart sampling) that the step() which follows consumes (the key is drawn from torch's host generator at the first call) - instead of two launches of torch's generator, which inside a replayed
         hipGraph also cost two fills of its seed / offset cells per replay."""
         c = self._core
         if getattr(self, "_rng_state", None) is None:
-            IGParkourEnv._rng_instances += 1
-            self._rng_seed = (int(torch.initial_seed()) + 0x9E3779B97F4A7C15 * IGParkourEnv._rng_instances) & 0xFFFFFFFFFFFFFFFF
+            # the key comes out of torch's (host) generator at the first call: torch.manual_seed() fixes it like it fixes torch's own
+            # draws, and two envs of one process get different keys
+            self._rng_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
             self._rng_state = torch.zeros(2, dtype=torch.int64, device=self._device)
             self._action_noise = None
         if self._action_noise is None or self._action_noise.shape[1] != action_dim:

@@ -20,5 +20,5 @@ with open('gpurun_out/rolltrace/one_step.txt','w') as f:
         f.write("%8.1f %6.1f  %s\n"%((s-t0)/1e3,(e-s)/1e3,r['Kernel_Name'][:110]))
     f.write("step span us %.1f, kernels %d\n"%((int(rows[b]['Start_Timestamp'])-t0)/1e3,b-a))
 PY
-rm -f $O/trace.csv
+cat $O/one_step.txt; rm -f $O/trace.csv
 exit $rc
