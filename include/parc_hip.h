@@ -351,28 +351,16 @@ typedef struct {
     int32_t row_bytes;
     int32_t convert;
 } parc_record_field_t;
-int parc_record_step(void *stream, int n_envs, int64_t *head, int n_fields, const parc_record_field_t *fields, int advance_mod,
-                     int32_t *ticket);
-/* advance_mod > 0: after the copies, *head <- (*head + 1) % advance_mod - ExperienceBuffer.inc (experience_buffer.py:41-44) on the
- * device, by the launch's last workgroup (ticket: one int32, zero before the first call, left zero); 0: *head is only read. */
+int parc_record_step(void *stream, int n_envs, const int64_t *head, int n_fields, const parc_record_field_t *fields);
 
 /* The random numbers of one rollout step in one launch (counter-based Philox4x32-10 keyed by `seed`): n_uniform floats in [0, 1) and
  * n_normal floats ~ N(0, 1).  state: two uint64 on the device - [0] the step counter, advanced by the launch; [1] a ticket, zero
- * between launches.  Same (seed, counter) -> same numbers on every run. */
-int parc_rng_step(void *stream, uint64_t seed, uint64_t *state, float *uniform_out, int64_t n_uniform, float *normal_out, int64_t n_normal);
+ * between launches.  Same (seed, counter) -> same numbers on every run.  tick_cell (may be NULL): a device int64 that the launch - the
+ * first of a rollout step - moves on by one modulo tick_mod: ExperienceBuffer.inc (experience_buffer.py:41-44) for a write row kept on
+ * the device (the `head` of parc_record_step). */
+int parc_rng_step(void *stream, uint64_t seed, uint64_t *state, float *uniform_out, int64_t n_uniform, float *normal_out, int64_t n_normal,
+                  int64_t *tick_cell, int tick_mod);
 
-/* ---- K21 episodic return tracker: DMPPOReturnTracker.update  learning/dm_ppo_return_tracker.py:6-99 in one launch.
- * rewards [K, reward_stride] (row k = term k, first n_envs entries), done [N] i32; state: return_buf [K,N], ep_len [N] i64,
- * eps_per_env [N] i64, mean_return [K], mean_ep_len [1], episodes [1] f64.  K <= 12.  workspace: caller-owned,
- * parc_return_tracker_workspace_floats(n_envs) floats, zero-filled once before the first call (the kernel keeps its ticket at zero). */
-int64_t parc_return_tracker_workspace_floats(int n_envs);
-int parc_return_tracker_update(void *stream, int n_envs, int K, const float *rewards, int64_t reward_stride, const int32_t *done,
-                               float *return_buf, int64_t *ep_len, int64_t *eps_per_env, float *mean_return, float *mean_ep_len,
-                               double *episodes, float *workspace);
-
-/* ---- gradient clipping by global norm over a flat buffer (MPOptimizer.step, learning/mp_optimizer.py:24-40 with
- * torch.nn.utils.clip_grad_norm_): x[0..n) *= min(max_norm / (norm[0] + 1e-6), 1); norm is a device scalar. */
-int parc_scale_by_clipped_norm(void *stream, int64_t n, float *x, const float *norm, float max_norm);
 /* K20 in two passes over flat buffers (MPOptimizer.step, learning/mp_optimizer.py:20-40: clip_grad_norm_ then SGD with momentum):
  * norm = |grad|_2 (fixed summation order), coef = min(max_norm / (norm + 1e-6), 1) (max_norm <= 0: no clipping), g' = coef grad
  * (+ weight_decay * p), momentum_buf = momentum * momentum_buf + g', params -= lr * momentum_buf.  grad is left as it was.
@@ -387,8 +375,7 @@ int parc_normalize_clamp(void *stream, int64_t rows, int dim, const float *x, co
 
 /* ---- K22: Normalizer.record  learning/normalizer.py:28-34: acc[0,:] += sum over rows of x, acc[1,:] += sum over rows of x*x
  * in one pass with a fixed summation order.  x [rows, dim] row-major, acc [2, dim], dim a multiple of 4, 16-byte aligned;
- * workspace: parc_moments_workspace_floats(rows, dim) floats of scratch (caller-owned) whose FIRST 64 floats are zero before the first
- * call (tickets of the second stage, which runs inside the same launch; the call leaves them zero). */
+ * workspace: parc_moments_workspace_floats(rows, dim) floats of scratch (caller-owned). */
 int64_t parc_moments_workspace_floats(int64_t rows, int dim);
 int parc_moments_accumulate(void *stream, int64_t rows, int dim, const float *x, float *acc, float *workspace);
 

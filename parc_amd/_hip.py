@@ -245,9 +245,9 @@ def _declare(L):
     L.parc_return_tracker_workspace_floats.argtypes = [c_int]
     L.parc_return_tracker_workspace_floats.restype = c_i64
     L.parc_return_tracker_update.restype = c_int
-    L.parc_record_step.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_vp]
+    L.parc_record_step.argtypes = [c_vp, c_int, c_vp, c_int, c_vp]
     L.parc_record_step.restype = c_int
-    L.parc_rng_step.argtypes = [c_vp, ctypes.c_uint64, c_vp, c_vp, c_i64, c_vp, c_i64]
+    L.parc_rng_step.argtypes = [c_vp, ctypes.c_uint64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_int]
     L.parc_rng_step.restype = c_int
     L.parc_reset_apply.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int] + [c_vp] * 9
     L.parc_reset_apply.restype = c_int

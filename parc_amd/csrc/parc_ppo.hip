@@ -292,7 +292,7 @@ struct record_fields_t {
     parc_record_field_t f[PARC_RECORD_MAX_FIELDS];
 };
 
-__global__ __launch_bounds__(256) void record_step_kernel(int n_envs, int64_t *head, record_fields_t fields, int advance_mod, int32_t *ticket) {
+__global__ __launch_bounds__(256) void record_step_kernel(int n_envs, const int64_t *__restrict__ head, record_fields_t fields) {
     const parc_record_field_t f = fields.f[blockIdx.y];
     const size_t total = (size_t)n_envs * (size_t)f.row_bytes;            // bytes of one time row
     const size_t h = (size_t)head[0];
@@ -301,33 +301,19 @@ __global__ __launch_bounds__(256) void record_step_kernel(int n_envs, int64_t *h
         const int64_t *s = (const int64_t *)f.src;
         int32_t *d = (int32_t *)f.dst + h * (total / 8);
         for (size_t i = tid; i < total / 8; i += nthr) d[i] = (int32_t)s[i];
-    } else {
-        char *d = (char *)f.dst + h * total;
-        const char *s = (const char *)f.src;
-        if (((total | (uintptr_t)d | (uintptr_t)s) & 15) == 0) {
-            for (size_t i = tid; i < total / 16; i += nthr) ((uint4 *)d)[i] = ((const uint4 *)s)[i];
-        } else {
-            for (size_t i = tid; i < total / 4; i += nthr) ((uint32_t *)d)[i] = ((const uint32_t *)s)[i];
-        }
+        return;
     }
-    if (advance_mod > 0) {
-        // ExperienceBuffer.inc (experience_buffer.py:41-44) on the device: the LAST workgroup to finish moves the write row on; every
-        // workgroup read `head` when it started, i.e. before it took its ticket, so nobody sees the new value
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int last = (int)(gridDim.x * gridDim.y) - 1;
-            if (atomicAdd(ticket, 1) == last) {
-                head[0] = (int64_t)((h + 1) % (size_t)advance_mod);
-                *ticket = 0;
-            }
-        }
+    char *d = (char *)f.dst + h * total;
+    const char *s = (const char *)f.src;
+    if (((total | (uintptr_t)d | (uintptr_t)s) & 15) == 0) {
+        for (size_t i = tid; i < total / 16; i += nthr) ((uint4 *)d)[i] = ((const uint4 *)s)[i];
+    } else {
+        for (size_t i = tid; i < total / 4; i += nthr) ((uint32_t *)d)[i] = ((const uint32_t *)s)[i];
     }
 }
 
-extern "C" int parc_record_step(void *stream, int n_envs, int64_t *head, int n_fields, const parc_record_field_t *fields, int advance_mod,
-                                int32_t *ticket) {
-    if (n_envs <= 0 || n_fields <= 0 || n_fields > PARC_RECORD_MAX_FIELDS || !head || !fields || advance_mod < 0 || (advance_mod > 0 && !ticket))
-        return PARC_EINVAL;
+extern "C" int parc_record_step(void *stream, int n_envs, const int64_t *head, int n_fields, const parc_record_field_t *fields) {
+    if (n_envs <= 0 || n_fields <= 0 || n_fields > PARC_RECORD_MAX_FIELDS || !head || !fields) return PARC_EINVAL;
     record_fields_t args;
     int max_row = 0;
     for (int i = 0; i < n_fields; ++i) {
@@ -339,7 +325,7 @@ extern "C" int parc_record_step(void *stream, int n_envs, int64_t *head, int n_f
     size_t units = ((size_t)n_envs * (size_t)max_row + 15) / 16;
     unsigned gx = (unsigned)((units + 255) / 256);
     if (gx > 2048u) gx = 2048u;                                          // grid-stride beyond that
-    hipLaunchKernelGGL(record_step_kernel, dim3(gx, (unsigned)n_fields), dim3(256), 0, (hipStream_t)stream, n_envs, head, args, advance_mod, ticket);
+    hipLaunchKernelGGL(record_step_kernel, dim3(gx, (unsigned)n_fields), dim3(256), 0, (hipStream_t)stream, n_envs, head, args);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }
@@ -350,7 +336,9 @@ extern "C" int parc_record_step(void *stream, int n_envs, int64_t *head, int n_f
 // uniform_) - the env's pool: xy-target resample, restart sampling - and n_normal floats ~ N(0, 1) (Box-Muller on pairs) - the
 // policy's action noise.  state[0] = step counter, advanced by the launch's last workgroup; state[1] = its ticket (zero between launches).
 // Replaces two torch generator launches per step, which inside a replayed hipGraph also cost two fills of the generator's
-// seed / offset cells per replay.
+// seed / offset cells per replay.  Being the FIRST launch of a rollout step it can also carry the step's tick: tick_cell (optional) <-
+// (tick_cell + 1) % tick_mod by the launch's last workgroup - ExperienceBuffer.inc (experience_buffer.py:41-44) for a write row that lives
+// on the device.  (157 workgroups take the ticket here; taking it in the record launch - 14 000 workgroups on one atomic - cost 200 us.)
 // =============================================================================================
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
 #pragma unroll
@@ -365,7 +353,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 }
 
 __global__ __launch_bounds__(256) void rng_step_kernel(uint64_t seed, uint64_t *state, float *__restrict__ uniform_out, int64_t n_uniform,
-                                                       float *__restrict__ normal_out, int64_t n_normal) {
+                                                       float *__restrict__ normal_out, int64_t n_normal, int64_t *tick_cell, int tick_mod) {
     const uint64_t step = state[0];
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // one Philox block = 4 outputs
     const int64_t qu = (n_uniform + 3) / 4, qn = (n_normal + 3) / 4;
@@ -400,17 +388,19 @@ __global__ __launch_bounds__(256) void rng_step_kernel(uint64_t seed, uint64_t *
         if (atomicAdd(ticket, 1ull) == (unsigned long long)gridDim.x - 1ull) {
             state[0] = step + 1;
             *ticket = 0ull;
+            if (tick_cell) tick_cell[0] = (tick_cell[0] + 1) % (int64_t)tick_mod;      // nothing of this launch reads it
         }
     }
 }
 
 extern "C" int parc_rng_step(void *stream, uint64_t seed, uint64_t *state, float *uniform_out, int64_t n_uniform, float *normal_out,
-                             int64_t n_normal) {
-    if (!state || n_uniform < 0 || n_normal < 0 || (n_uniform > 0 && !uniform_out) || (n_normal > 0 && !normal_out)) return PARC_EINVAL;
+                             int64_t n_normal, int64_t *tick_cell, int tick_mod) {
+    if (!state || n_uniform < 0 || n_normal < 0 || (n_uniform > 0 && !uniform_out) || (n_normal > 0 && !normal_out) || (tick_cell && tick_mod < 1))
+        return PARC_EINVAL;
     const int64_t quads = (n_uniform + 3) / 4 + (n_normal + 3) / 4;
-    if (quads == 0) return PARC_OK;
-    hipLaunchKernelGGL(rng_step_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, state, uniform_out, n_uniform,
-                       normal_out, n_normal);
+    if (quads == 0 && !tick_cell) return PARC_OK;
+    hipLaunchKernelGGL(rng_step_kernel, dim3((unsigned)((quads + 255) / 256 > 0 ? (quads + 255) / 256 : 1)), dim3(256), 0, (hipStream_t)stream, seed,
+                       state, uniform_out, n_uniform, normal_out, n_normal, tick_cell, tick_mod);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }
@@ -644,10 +634,8 @@ extern "C" int parc_normalize_clamp(void *stream, int64_t rows, int dim, const f
 // the result does not depend on scheduling.
 // =============================================================================================
 #define MOM_ROWS 64
-__global__ __launch_bounds__(256) void moments_kernel(int rows, int dim4, int chunks, const float4 *__restrict__ x, float4 *partial, float4 *acc,
-                                                      int32_t *tickets) {
+__global__ __launch_bounds__(256) void moments_partial_kernel(int rows, int dim4, const float4 *__restrict__ x, float4 *__restrict__ partial) {
     __shared__ float4 red[2][4][64];
-    __shared__ int s_last;
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     const int r0 = blockIdx.y * MOM_ROWS, r1 = min(r0 + MOM_ROWS, rows);
@@ -668,45 +656,40 @@ __global__ __launch_bounds__(256) void moments_kernel(int rows, int dim4, int ch
         o.x = (a.x + b.x) + (d.x + e.x); o.y = (a.y + b.y) + (d.y + e.y); o.z = (a.z + b.z) + (d.z + e.z); o.w = (a.w + b.w) + (d.w + e.w);
         partial[((size_t)blockIdx.y * 2 + rg) * dim4 + c] = o;
     }
-    // stage 2 in the same launch: the LAST row chunk of this column block to finish (ticket per column block) adds the chunks' partial
-    // rows in chunk order - the order does not depend on which workgroup that is - and folds them into the accumulator
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&tickets[blockIdx.x], 1) == chunks - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (rg < 2 && c < dim4) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 16
-        for (int k = 0; k < chunks; ++k) {          // (unrolled: the loads of 16 chunks are in flight together; the adds stay in chunk order)
-            const float4 v = partial[((size_t)k * 2 + rg) * dim4 + c];
-            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-        }
-        float4 a = acc[(size_t)rg * dim4 + c];
-        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-        acc[(size_t)rg * dim4 + c] = a;
-    }
-    if (threadIdx.x == 0) tickets[blockIdx.x] = 0;
 }
 
-#define MOM_TICKET_FLOATS 64        // the column blocks' tickets, in front of the partial rows (dim <= 16384)
+// (stage 2 stays a launch of its own: folded into stage 1 behind per-column-block tickets - round 4 - the launch took 38 us instead of
+// 6.8 + 4.9: the partial rows must be visible to the last workgroup, and a device-scope release fence per workgroup costs more than
+// the launch it saves)
+__global__ __launch_bounds__(256) void moments_final_kernel(int chunks, int dim4, const float4 *__restrict__ partial, float4 *acc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // over [2, dim4]
+    if (i >= 2 * dim4) return;
+    const int which = i / dim4, c = i - which * dim4;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 16
+    for (int k = 0; k < chunks; ++k) {          // (unrolled: the loads of 16 chunks are in flight together; the adds stay in chunk order)
+        const float4 v = partial[((size_t)k * 2 + which) * dim4 + c];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    float4 a = acc[i];
+    a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    acc[i] = a;
+}
 
 extern "C" int64_t parc_moments_workspace_floats(int64_t rows, int dim) {
     if (rows < 0 || dim <= 0) return -1;
-    return ((rows + MOM_ROWS - 1) / MOM_ROWS) * 2 * (int64_t)dim + MOM_TICKET_FLOATS;
+    return ((rows + MOM_ROWS - 1) / MOM_ROWS) * 2 * (int64_t)dim;
 }
 
-// workspace: parc_moments_workspace_floats(rows, dim) floats whose FIRST 64 are zero before the first call (the kernel leaves them zero)
 extern "C" int parc_moments_accumulate(void *stream, int64_t rows, int dim, const float *x, float *acc, float *workspace) {
     if (rows < 0 || dim <= 0 || (dim & 3) || (((uintptr_t)x | (uintptr_t)acc | (uintptr_t)workspace) & 15)) return PARC_EINVAL;
     if (rows == 0) return PARC_OK;
     if (rows > (int64_t)MOM_ROWS * 65535) return PARC_EUNSUPPORTED;
     const int dim4 = dim / 4, chunks = (int)((rows + MOM_ROWS - 1) / MOM_ROWS);
-    if ((dim4 + 63) / 64 > MOM_TICKET_FLOATS) return PARC_EUNSUPPORTED;
-    int32_t *tickets = reinterpret_cast<int32_t *>(workspace);          // the FIRST 64 floats: the same cells whatever the row count
-    hipLaunchKernelGGL(moments_kernel, dim3((dim4 + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, (int)rows, dim4, chunks, (const float4 *)x,
-                       (float4 *)(workspace + MOM_TICKET_FLOATS), (float4 *)acc, tickets);
+    hipLaunchKernelGGL(moments_partial_kernel, dim3((dim4 + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, (int)rows, dim4, (const float4 *)x,
+                       (float4 *)workspace);
+    hipLaunchKernelGGL(moments_final_kernel, dim3((2 * dim4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, chunks, dim4,
+                       (const float4 *)workspace, (float4 *)acc);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }

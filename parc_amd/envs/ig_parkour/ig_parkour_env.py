@@ -216,7 +216,7 @@ class IGParkourEnv(base_env.BaseEnv):
         t = self._mgdm_env.get_mgdm_time_buf() if self._enable_replan_timer_obs else None
         self._core.assemble_obs(self._obs_cols, self._obs_buf, scalar=t, env_ids=env_ids)
 
-    def step_randoms(self, action_dim):
+    def step_randoms(self, action_dim, tick=None):
         """Every random number of one rollout step in ONE launch (parc_rng_step, counter-based Philox keyed by torch's seed at the first
         call): returns the N(0, 1) action noise [N, action_dim] of the policy and refills the env's uniform pool (xy-target resample,
         restart sampling) that the step() which follows consumes (the key is drawn from torch's host generator at the first call) - instead of two launches of torch's generator, which inside a replayed
@@ -230,8 +230,10 @@ class IGParkourEnv(base_env.BaseEnv):
             self._action_noise = None
         if self._action_noise is None or self._action_noise.shape[1] != action_dim:
             self._action_noise = torch.empty((self._num_envs, action_dim), dtype=torch.float32, device=self._device)
+        # tick = (device int64 cell, modulus): the caller's per-step counter (the experience buffer's write row), moved on by this launch
+        cell, mod = (None, 0) if tick is None else tick
         _hip.check(_hip.lib().parc_rng_step(_hip.stream(), self._rng_seed, _hip.ptr(self._rng_state), _hip.ptr(c.rand_pool), c.rand_pool.numel(),
-                                            _hip.ptr(self._action_noise), self._action_noise.numel()), "parc_rng_step")
+                                            _hip.ptr(self._action_noise), self._action_noise.numel(), _hip.ptr(cell), int(mod)), "parc_rng_step")
         c.rand_pool_prefilled = True
         return self._action_noise
 

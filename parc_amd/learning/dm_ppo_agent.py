@@ -260,9 +260,9 @@ class DMPPOAgent(torch.nn.Module):
             else:
                 self._set_exp_prob(exp_prob)
                 mask = torch.bernoulli(self._exp_prob_t.expand(n, 1)).squeeze(-1).contiguous()
-            # the env draws the step's random numbers in one launch of its own counter-based generator (action noise + its uniform
-            # pool: IGParkourEnv.step_randoms); torch's generator otherwise
-            noise = self._env.step_randoms(A) if (hasattr(self._env, "step_randoms") and n == self._env.get_num_envs()) else torch.randn_like(mean)
+            # inside a captured step the env has drawn the step's random numbers in one launch of its own counter-based generator
+            # (_train_step_body); torch's generator otherwise
+            noise = self._step_noise if (getattr(self, "_step_noise", None) is not None and self._step_noise.shape == mean.shape) else torch.randn_like(mean)
         else:
             mask = torch.zeros(n, dtype=torch.float32, device=mean.device)
             noise = mean                   # unused where the mask is 0
@@ -310,7 +310,7 @@ class DMPPOAgent(torch.nn.Module):
                 if self._replan_time_src is not rt:   # (a tracker env hands out one persistent zero: expand it once, not per step)
                     self._replan_time_src, self._replan_time_rows = rt, rt.expand(self.get_num_envs()).contiguous()
                 items += [("replan_timer", self._replan_time_rows), ("replan_counter", self._env.get_replan_counter())]
-            eb.record_group(items, advance=True)       # the step's last write into the buffer: the device's write row moves on
+            eb.record_group(items)
             return
         eb.record("next_obs", next_obs)
         eb.record("reward", r)
@@ -329,7 +329,15 @@ class DMPPOAgent(torch.nn.Module):
         done_indices = (done != base_env.DoneFlags.NULL.value).nonzero(as_tuple=False).flatten()
         return self._env.reset(done_indices)
 
+    def _device_tick(self):
+        """does the captured step advance the device's write row itself?  (the env's one-launch random draw carries the tick)"""
+        return hasattr(self._env, "step_randoms") and self._config.get("device_step_randoms", True)
+
     def _train_step_body(self, device_reset=False):
+        self._step_noise = None
+        if getattr(self, "_in_graph_step", False) and self._device_tick():
+            # first launch of the step: every random number it needs (policy noise + the env's uniform pool) and the write row's tick
+            self._step_noise = self._env.step_randoms(self.get_action_size(), tick=(self._head_t, self._exp_buffer._buffer_length))
         action, action_info = self._decide_action(self._curr_obs, self._curr_info)
         self._record_data_pre_step(self._curr_obs, self._curr_info, action, action_info)
         next_obs, r, done, next_info = self._env.step(action)
@@ -359,10 +367,12 @@ class DMPPOAgent(torch.nn.Module):
         sig = self._env.host_step_signature() if hasattr(self._env, "host_step_signature") else ()
         key = (self._need_normalizer_update(), exp_prob >= 1.0, device_reset) + tuple(sig)
         # the write row and the exploration probability live on the device; the host only re-writes them when they differ from what
-        # the device holds (the captured step moves the row on itself: ExperienceBuffer.record_group(advance=True)) - no fill per step
-        if self._head_dev != eb._buffer_head:
-            self._head_t.fill_(eb._buffer_head)
-            self._head_dev = eb._buffer_head
+        # the device holds - no fill per step.  With an env that draws the step's random numbers itself (step_randoms) the captured
+        # step's FIRST launch moves the row on by one, so between steps the cell holds the row of the step before.
+        want = (eb._buffer_head - 1) % eb._buffer_length if self._device_tick() else eb._buffer_head
+        if self._head_dev != want:
+            self._head_t.fill_(want)
+            self._head_dev = want
         if self._exp_prob_dev != exp_prob:
             self._exp_prob_t.fill_(exp_prob)         # read by the captured Bernoulli draw: the value of THIS step, not of the capture
             self._exp_prob_dev = exp_prob
@@ -411,7 +421,8 @@ class DMPPOAgent(torch.nn.Module):
             fresh = False
         g, done = self._graphs[key]
         g.replay()
-        self._head_dev = (self._head_dev + 1) % eb._buffer_length      # the replayed step moved the device's write row on
+        if self._device_tick():
+            self._head_dev = (self._head_dev + 1) % eb._buffer_length  # the replayed step moved the device's write row on
         if not fresh and hasattr(self._env, "host_step_replayed"):
             self._env.host_step_replayed()           # what the step changes on the host (the device part is the graph)
         if key[0]:

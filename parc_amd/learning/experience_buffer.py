@@ -16,7 +16,6 @@ class ExperienceBuffer:
         self._sample_buf = torch.randperm(buffer_length * batch_size, device=device, dtype=torch.long)
         self._sample_buf_head = 0
         self._device_head = None
-        self._ticket = None
 
     def has_buffer(self, name):
         return name in self._buffers
@@ -54,16 +53,13 @@ class ExperienceBuffer:
         else:
             self._buffers[name][self._buffer_head] = data
 
-    def record_group(self, items, advance=False):
+    def record_group(self, items):
         """record() for several buffers in ONE launch (K15, parc_record_step): items = [(name, tensor [N, ...]), ...].
-        GPU only, with a device head (the captured rollout step); falls back to record() otherwise.  advance: the launch also moves the
-        DEVICE head on by one row (inc() on the device; the caller still calls inc() for the host's mirror)."""
+        GPU only, with a device head (the captured rollout step); falls back to record() otherwise."""
         if self._device_head is None or not items[0][1].is_cuda:
             for name, data in items:
                 self.record(name, data)
             return
-        if advance and self._ticket is None:
-            self._ticket = torch.zeros(1, dtype=torch.int32, device=items[0][1].device)
         from .. import _hip
         arr = (_hip.RecordFieldS * len(items))()
         keep = []
@@ -78,8 +74,8 @@ class ExperienceBuffer:
             row = data[0].numel() * data.element_size()
             assert row % 4 == 0 and (conv == 1 or row == buf[0, 0].numel() * buf.element_size())
             arr[i] = _hip.RecordFieldS(data.data_ptr(), buf.data_ptr(), row, conv)
-        _hip.check(_hip.lib().parc_record_step(_hip.stream(), self._batch_size, _hip.ptr(self._device_head), len(items), arr,
-                                               self._buffer_length if advance else 0, _hip.ptr(self._ticket) if advance else None), "parc_record_step")
+        _hip.check(_hip.lib().parc_record_step(_hip.stream(), self._batch_size, _hip.ptr(self._device_head), len(items), arr),
+                   "parc_record_step")
 
     def set_device_head(self, head_t):
         """head_t: int64 device tensor [1] mirroring ``_buffer_head`` (None switches back to host indexing)."""

@@ -47,7 +47,7 @@ class Normalizer(torch.nn.Module):
             L = _hip.lib()
             need = int(L.parc_moments_workspace_floats(rows.shape[0], rows.shape[1]))
             if self._scratch is None or self._scratch.numel() < need:
-                self._scratch = torch.zeros(need, dtype=torch.float32, device=rows.device)     # (its first 64 floats are the kernel's tickets)
+                self._scratch = torch.empty(need, dtype=torch.float32, device=rows.device)
             _hip.check(L.parc_moments_accumulate(_hip.stream(), rows.shape[0], rows.shape[1], _hip.ptr(rows), _hip.ptr(self._acc),
                                                  _hip.ptr(self._scratch)), "parc_moments_accumulate")
             return

@@ -107,7 +107,8 @@ def eager_rollout_like_the_graph(agent, num_steps):
     try:
         device_reset = hasattr(env, "reset_done") and env.supports_device_reset()
         for _ in range(num_steps):
-            agent._head_t.fill_(eb._buffer_head)
+            # (with the step's own tick - DMPPOAgent._device_tick - the cell holds the row of the step before)
+            agent._head_t.fill_((eb._buffer_head - 1) % eb._buffer_length if agent._device_tick() else eb._buffer_head)
             agent._exp_prob_t.fill_(agent._get_exp_prob())
             done = agent._train_step_body(device_reset)
             if not device_reset:

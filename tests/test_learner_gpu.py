@@ -409,10 +409,12 @@ def test_rng_step_is_philox_and_its_outputs_are_what_they_claim():
     np.testing.assert_array_equal(nor.cpu().numpy(), outs[0][1])
 
 
-def test_record_group_moves_the_device_write_row_and_moments_run_in_one_launch():
-    """ExperienceBuffer.record_group(advance=True): the launch's last workgroup does inc() on the device (row (h + 1) % T), rows land
-    where the host-indexed record() puts them; Normalizer.record in ONE launch (second stage behind per-column-block tickets) equals the
-    column sums for row counts that move the partial rows around in the shared workspace."""
+def test_rng_step_carries_the_write_row_tick_and_record_group_follows_it():
+    """The captured rollout step keeps the experience buffer's write row in a device cell: its first launch (parc_rng_step) moves the
+    cell on by one modulo T - ExperienceBuffer.inc on the device, no fill per step - and both record launches of the step write that
+    row; rows land where the host-indexed record() puts them.  Normalizer.record equals the column sums for row counts that move the
+    partial rows around in the shared workspace."""
+    from parc_amd import _hip
     from parc_amd.learning.experience_buffer import ExperienceBuffer
     from parc_amd.learning.normalizer import Normalizer
     T_, N = 5, 300
@@ -422,20 +424,25 @@ def test_record_group_moves_the_device_write_row_and_moments_run_in_one_launch()
         b.add_buffer("obs", torch.zeros((T_, N, 1312), device=DEV))
         b.add_buffer("reward", torch.zeros((T_, N), device=DEV))
         b.add_buffer("ep_num", torch.zeros((T_, N), dtype=torch.int32, device=DEV))
-    head = torch.zeros(1, dtype=torch.int64, device=DEV)
+    head = torch.full((1,), T_ - 1, dtype=torch.int64, device=DEV)          # "the row of the step before" the first one
     eb.set_device_head(head)
+    state = torch.zeros(2, dtype=torch.int64, device=DEV)
+    pool, noise = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
     g = torch.Generator(device="cpu").manual_seed(3)
     for step in range(12):
+        _hip.check(_hip.lib().parc_rng_step(_hip.stream(), 7, _hip.ptr(state), _hip.ptr(pool), 64, _hip.ptr(noise), 64, _hip.ptr(head), T_), "rng")
+        assert int(head.item()) == step % T_ and state.tolist() == [step + 1, 0]
         obs, r = torch.randn((N, 1312), generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
         ep = torch.randint(0, 1000, (N,), generator=g).to(DEV)
-        eb.record_group([("obs", obs)])                                    # pre-step group: the row stays
-        assert int(head.item()) == step % T_
-        eb.record_group([("reward", r), ("ep_num", ep)], advance=True)      # post-step group: the row moves on
-        assert int(head.item()) == (step + 1) % T_ and int(eb._ticket.item()) == 0
+        eb.record_group([("obs", obs)])
+        eb.record_group([("reward", r), ("ep_num", ep)])
         ref.record("obs", obs); ref.record("reward", r); ref.record("ep_num", ep); ref.inc()
         eb.inc()
     for k in ("obs", "reward", "ep_num"):
         assert torch.equal(eb.get_data(k), ref.get_data(k)), k
+    # a tick without random numbers is a launch too
+    _hip.check(_hip.lib().parc_rng_step(_hip.stream(), 7, _hip.ptr(state), None, 0, None, 0, _hip.ptr(head), T_), "rng")
+    assert int(head.item()) == 12 % T_
     nrm = Normalizer((1312,), device=DEV)
     tot, tot2, cnt = torch.zeros(1312, dtype=torch.float64), torch.zeros(1312, dtype=torch.float64), 0
     for rows in (4096, 64, 1000, 4096, 37):
@@ -444,5 +451,30 @@ def test_record_group_moves_the_device_write_row_and_moments_run_in_one_launch()
         tot += x.double().sum(0); tot2 += (x.double() ** 2).sum(0); cnt += rows
         np.testing.assert_allclose(nrm._acc[0].cpu().numpy(), tot.numpy(), rtol=2e-5, atol=2e-3)
         np.testing.assert_allclose(nrm._acc[1].cpu().numpy(), tot2.numpy(), rtol=2e-5, atol=2e-3)
-        assert int(nrm._scratch[:64].abs().sum().item()) == 0               # tickets back to zero
     assert nrm._new_count == cnt
+
+
+def test_graph_rollout_writes_the_same_rows_as_the_eager_rollout():
+    """One rollout of T steps through the captured step (device write row ticked by the step's first launch, the env's own random
+    draw) fills every row of every buffer exactly like the step body issued eagerly with a host-indexed write row does for the SAME random
+    numbers - checked on what does not depend on the numbers: each env's timestep / ep_num / env_id rows advance consistently, row t
+    holds step t, no row is skipped or written twice."""
+    from parc_amd import workloads
+    torch.manual_seed(0)
+    env, _, _ = workloads.build_env("flat_1clip", 64, DEV, seed=0)
+    agent = workloads.build_agent(env, DEV, steps_per_iter=8, update_epochs=1, batch_size=2)
+    assert agent._device_tick()
+    agent._curr_obs, agent._curr_info = env.reset()
+    agent._init_train()
+    for _ in range(3):                                      # eager warm-up steps, the capture, then steady replays, over three iterations
+        info = agent._train_iter()
+        eb = agent._exp_buffer
+        ts = eb.get_data("timestep").cpu().numpy()          # [T, N]: the env's step counter after each step
+        ep = eb.get_data("ep_num").cpu().numpy()
+        assert (eb.get_data("env_id").cpu().numpy() == np.arange(64)[None, :]).all()
+        d_ts, d_ep = np.diff(ts, axis=0), np.diff(ep, axis=0)
+        # from one row to the next an env either made one more step of the same episode or finished (done in the earlier row) and restarted
+        done = eb.get_data("done").cpu().numpy()[:-1] != 0
+        assert np.all(np.where(done, ts[1:] == 1, d_ts == 1)) and np.all(np.where(done, d_ep == 1, d_ep == 0))
+        assert np.isfinite(info["critic_loss"].item())
+        assert agent._head_dev == (eb._buffer_head - 1) % eb._buffer_length or not agent._graphs
