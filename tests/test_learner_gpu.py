@@ -378,7 +378,7 @@ def test_rng_step_is_philox_and_its_outputs_are_what_they_claim():
     uni, nor = torch.empty(nu, device=DEV), torch.empty(nn, device=DEV)
     outs = []
     for step in range(3):
-        _hip.check(L.parc_rng_step(_hip.stream(), seed, _hip.ptr(state), _hip.ptr(uni), nu, _hip.ptr(nor), nn), "parc_rng_step")
+        _hip.check(L.parc_rng_step(_hip.stream(), seed, _hip.ptr(state), _hip.ptr(uni), nu, _hip.ptr(nor), nn, None, 0), "parc_rng_step")
         torch.cuda.synchronize()
         assert state.tolist() == [step + 1, 0]
         outs.append((uni.cpu().numpy().copy(), nor.cpu().numpy().copy()))
@@ -404,7 +404,7 @@ def test_rng_step_is_philox_and_its_outputs_are_what_they_claim():
         np.testing.assert_allclose(outs[step][1], wz, atol=2e-3, rtol=2e-3)       # __logf / __sincosf on the device
     assert not np.array_equal(outs[0][0], outs[1][0])
     state.zero_()                                                  # same (seed, step) -> same numbers
-    _hip.check(L.parc_rng_step(_hip.stream(), seed, _hip.ptr(state), _hip.ptr(uni), nu, _hip.ptr(nor), nn), "parc_rng_step")
+    _hip.check(L.parc_rng_step(_hip.stream(), seed, _hip.ptr(state), _hip.ptr(uni), nu, _hip.ptr(nor), nn, None, 0), "parc_rng_step")
     np.testing.assert_array_equal(uni.cpu().numpy(), outs[0][0])
     np.testing.assert_array_equal(nor.cpu().numpy(), outs[0][1])
 

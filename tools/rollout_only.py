@@ -26,9 +26,16 @@ agent._curr_obs, agent._curr_info = env.reset()
 agent._init_train()
 rollout(8)          # warm-up + graph capture
 torch.cuda.synchronize()
+timed = "--timed" in sys.argv       # (with --eager) every full post-step launch through parc_track_post_step_timed, like bench.py does
+if timed:
+    sys.argv.remove("--timed")
+    env._core.timing_events = []
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 t0 = time.time()
 rollout(n)
 torch.cuda.synchronize()
 dt = time.time() - t0
+if timed:
+    us = [p.elapsed_us() for p in env._core.timing_events]
+    print("post-step launches timed by events bound to the dispatch: n %d mean %.2f us min %.2f max %.2f" % (len(us), sum(us) / len(us), min(us), max(us)))
 print("rollout steps/s %.1f  ms/step %.3f  env-steps/s %.0f" % (n / dt, dt / n * 1e3, n * 4096 / dt))
