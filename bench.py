@@ -78,6 +78,40 @@ def cpu_baseline(env, clips, tiled, budget_s=12.0):
                       "no physics, no policy: the reference's physics is the GPU-only Isaac Gym binary".format(k, n)}
 
 
+def post_step_in_rollout_by_the_profiler(workload, envs, steps=64, timeout_s=300):
+    """The duration of the fused post-step launch where the rollout step issues it, by the DISPATCH's own time stamps: a child process runs
+    the rollout's launch sequence eagerly (tools/rollout_only.py --eager: same kernels, same order, same device-side restarts as the
+    captured step) under `rocprofv3 --kernel-trace`, and the trace is reduced by tools/rollout_trace_stats.py - the very numbers
+    profiles/rNN_rollout_kernel_stats.csv holds.  HIP events cannot deliver this figure from inside the process: a pair recorded around
+    the launch reads ~5 us more, a pair bound to the dispatch (hipExtLaunchKernel) ~1 us more (4.7 us more under the profiler) than the
+    dispatch's begin -> end.  None when rocprofv3 is not installed or the child fails (the event figure is used then)."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import rollout_trace_stats
+    out = tempfile.mkdtemp(prefix="parc_bench_prof_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        res = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable,
+                              os.path.join(ROOT, "tools", "rollout_only.py"), str(steps), "--eager", "--workload=" + workload, "--envs=%d" % envs],
+                             cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        if res.returncode != 0:
+            return None
+        for dirpath, _dirs, files in os.walk(out):
+            for f in files:
+                if f.endswith("kernel_trace.csv"):
+                    return rollout_trace_stats.stats(os.path.join(dirpath, f))
+        return None
+    except Exception:                     # noqa: BLE001  (a context measurement: never let it take the metric down)
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as a child torch.distributed.run job and
     relay rank 0's JSON line.  The parent makes no GPU call at all - the device count comes from the visibility variables or the KFD
@@ -158,6 +192,9 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--workload", default="boxes_64clips")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profiler-child", action="store_true",
+                    help="do not start the rocprofv3 child that times the post-step launch inside the rollout (roofline.us_per_launch then "
+                         "comes from HIP events bound to the dispatch)")
     ap.add_argument("--grad-allreduce", default="minibatch", choices=["minibatch", "epoch"],
                     help="minibatch = the reference's cadence (default); epoch = one parameter exchange per PPO epoch (north-star)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "reference"],
@@ -249,8 +286,12 @@ def main():
     # destination lines evicted by the policy GEMMs in between -, by a pair of events bound to the dispatch itself (hipExtLaunchKernel:
     # the kernel's own begin / end time stamps, the ones rocprofv3 reports; an event pair recorded AROUND a launch reads ~5 us more)
     in_rollout = [pr.elapsed_us() for pr in pairs]
-    kern_us = float(np.mean(in_rollout)) if in_rollout else float("nan")
+    kern_events_us = float(np.mean(in_rollout)) if in_rollout else float("nan")
     evs = pairs
+    prof = None
+    if rank == 0 and world == 1 and not args.no_profiler_child:
+        prof = post_step_in_rollout_by_the_profiler(args.workload, N)
+    kern_us = prof["full_us_mean"] if prof else kern_events_us
     # the product step's flags (the reference STATE is published by the step's tail launch, parc_step_tail, since round 3)
     full = _hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS
     for _ in range(10):
@@ -429,12 +470,18 @@ def main():
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "achieved_is": "ALGORITHMIC bytes per launch (SURVEY.md 8d: 13 592 B/env) / us_per_launch = the launch IN THE ROLLOUT "
                                         "STEP, where the product issues it (behind the simulator launch; its clip rows and destination lines "
-                                        "were evicted by the policy GEMMs since the previous step): mean over the {} launches of one rollout, the "
-                                        "step's launch sequence issued eagerly, each timed by a HIP event pair bound to its own dispatch "
-                                        "(hipExtLaunchKernel through parc_track_post_step_timed = the dispatch's begin / end time stamps; "
-                                        "profiles/r04_rollout_kernel_stats.csv is rocprofv3's figure for the same launches)".format(len(evs)),
-                         "us_per_launch": kern_us, "us_per_launch_min": float(np.min(in_rollout)) if in_rollout else None,
-                         "us_per_launch_max": float(np.max(in_rollout)) if in_rollout else None,
+                                        "were evicted by the policy GEMMs since the previous step)",
+                         "us_per_launch": kern_us,
+                         "us_per_launch_source": ("dispatch begin -> end time stamps of {} launches: a child process ran the step's launch "
+                                                  "sequence eagerly under rocprofv3 --kernel-trace during this run (tools/rollout_only.py "
+                                                  "--eager, tools/rollout_trace_stats.py; the method of profiles/r04_rollout_kernel_stats.csv)"
+                                                  .format(prof["full_launches"])) if prof else
+                                                 "HIP events bound to the dispatch (hipExtLaunchKernel), this process; reads ~1 us more than the "
+                                                 "dispatch's own begin -> end (rocprofv3 not available or --no-profiler-child)",
+                         "profiler_child": prof,
+                         "us_per_launch_by_events_bound_to_the_dispatch": kern_events_us,
+                         "us_per_launch_by_events_min": float(np.min(in_rollout)) if in_rollout else None,
+                         "us_per_launch_by_events_max": float(np.max(in_rollout)) if in_rollout else None,
                          "launches_event_timed": len(evs), "algorithmic_bytes_per_launch": alg_bytes,
                          "frac_standalone": achieved_standalone / HBM_PEAK_GBPS, "us_per_launch_standalone": kern_graph_us,
                          "standalone_is": "200 identical launches replayed in one hipGraph: warm caches, nothing else on the chip "

@@ -342,7 +342,8 @@ int parc_ppo_loss_packed(void *stream, int B, int A, const float *mean, const fl
 
 /* ---- K15 experience record: ExperienceBuffer.record  learning/experience_buffer.py:55-59 for a group of buffers at once.
  * Field f copies src [N, row_bytes] into row *head of dst [T, N, row_bytes] (row_bytes a multiple of 4; 16-byte vector copies
- * when sizes and pointers allow).  convert = 1: src is int64 [N], dst int32 [T, N] (the reference's ep_num buffer), row_bytes = 8.
+ * when sizes and pointers allow).  convert = 1: src is int64 [N], dst int32 [T, N] (the reference's ep_num buffer), row_bytes = 8;
+ * convert = 2: src is ONE 4-byte value written to every env of the row (row_bytes = 4; base_agent records the plan clock this way).
  * head: device int64 scalar (so the launch can sit inside a captured graph); fields: HOST array of n_fields <= 12 descriptors,
  * read during the call (they travel as kernel arguments). */
 typedef struct {

@@ -303,6 +303,12 @@ __global__ __launch_bounds__(256) void record_step_kernel(int n_envs, const int6
         for (size_t i = tid; i < total / 8; i += nthr) d[i] = (int32_t)s[i];
         return;
     }
+    if (f.convert == 2) {                                                 // one 4-byte value for every env (the plan clock: replan_timer)
+        const uint32_t v = *(const uint32_t *)f.src;
+        uint32_t *d = (uint32_t *)f.dst + h * (total / 4);
+        for (size_t i = tid; i < total / 4; i += nthr) d[i] = v;
+        return;
+    }
     char *d = (char *)f.dst + h * total;
     const char *s = (const char *)f.src;
     if (((total | (uintptr_t)d | (uintptr_t)s) & 15) == 0) {

@@ -306,10 +306,8 @@ class DMPPOAgent(torch.nn.Module):
                      ("ep_num", next_info["ep_num"]), ("next_char_contact_forces", next_info["char_contact_forces"]),
                      ("env_id", self._env_ids)]
             if self._is_terrain_runner:
-                rt = self._env.get_replan_time_buf()
-                if self._replan_time_src is not rt:   # (a tracker env hands out one persistent zero: expand it once, not per step)
-                    self._replan_time_src, self._replan_time_rows = rt, rt.expand(self.get_num_envs()).contiguous()
-                items += [("replan_timer", self._replan_time_rows), ("replan_counter", self._env.get_replan_counter())]
+                # (the plan clock is ONE device value: the record launch writes it to every env of the row)
+                items += [("replan_timer", self._env.get_replan_time_buf()), ("replan_counter", self._env.get_replan_counter())]
             eb.record_group(items)
             return
         eb.record("next_obs", next_obs)

@@ -65,6 +65,10 @@ class ExperienceBuffer:
         keep = []
         for i, (name, data) in enumerate(items):
             buf = self._buffers[name]
+            if data.numel() == 1 and self._batch_size > 1 and buf[0, 0].numel() == 1 and data.dtype == buf.dtype and data.element_size() == 4:
+                keep.append(data)              # one value for every env of the row: broadcast inside the launch
+                arr[i] = _hip.RecordFieldS(data.data_ptr(), buf.data_ptr(), 4, 2)
+                continue
             assert data.shape[0] == self._batch_size
             conv = 1 if (data.dtype == torch.int64 and buf.dtype == torch.int32) else 0
             if not conv and data.dtype != buf.dtype:

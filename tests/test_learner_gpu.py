@@ -424,6 +424,8 @@ def test_rng_step_carries_the_write_row_tick_and_record_group_follows_it():
         b.add_buffer("obs", torch.zeros((T_, N, 1312), device=DEV))
         b.add_buffer("reward", torch.zeros((T_, N), device=DEV))
         b.add_buffer("ep_num", torch.zeros((T_, N), dtype=torch.int32, device=DEV))
+        b.add_buffer("replan_timer", torch.zeros((T_, N), device=DEV))
+    clock = torch.zeros(1, device=DEV)                                    # one device value recorded for every env of the row
     head = torch.full((1,), T_ - 1, dtype=torch.int64, device=DEV)          # "the row of the step before" the first one
     eb.set_device_head(head)
     state = torch.zeros(2, dtype=torch.int64, device=DEV)
@@ -435,10 +437,11 @@ def test_rng_step_carries_the_write_row_tick_and_record_group_follows_it():
         obs, r = torch.randn((N, 1312), generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
         ep = torch.randint(0, 1000, (N,), generator=g).to(DEV)
         eb.record_group([("obs", obs)])
-        eb.record_group([("reward", r), ("ep_num", ep)])
-        ref.record("obs", obs); ref.record("reward", r); ref.record("ep_num", ep); ref.inc()
+        clock.fill_(0.125 * step)
+        eb.record_group([("reward", r), ("ep_num", ep), ("replan_timer", clock)])
+        ref.record("obs", obs); ref.record("reward", r); ref.record("ep_num", ep); ref.record("replan_timer", clock.expand(N)); ref.inc()
         eb.inc()
-    for k in ("obs", "reward", "ep_num"):
+    for k in ("obs", "reward", "ep_num", "replan_timer"):
         assert torch.equal(eb.get_data(k), ref.get_data(k)), k
     # a tick without random numbers is a launch too
     _hip.check(_hip.lib().parc_rng_step(_hip.stream(), 7, _hip.ptr(state), None, 0, None, 0, _hip.ptr(head), T_), "rng")

@@ -1,0 +1,11 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/c7; rm -rf $O; mkdir -p $O
+timeout -k 10 300 python3 tools/probe/find_step_copies.py > $O/step_copies.txt 2>&1; grep "|" $O/step_copies.txt | head -40
+timeout -k 10 500 python3 bench.py > $O/bench.json 2> $O/bench.err; tail -n 3 $O/bench.err; python3 - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/c7/bench.json') if l.startswith('{')][-1])
+r=d["roofline"]
+print({k: d[k] for k in ("value","ms_per_step","rollout_env_steps_per_s","rollout_fraction_of_time","mean_episode_return")})
+print({k: r[k] for k in ("frac","us_per_launch","us_per_launch_source","profiler_child","us_per_launch_by_events_bound_to_the_dispatch","frac_standalone","us_per_launch_standalone")})
+PY

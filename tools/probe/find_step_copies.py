@@ -1,10 +1,10 @@
-"""Which python lines of the rollout step issue aten::copy_ / aten::fill_ (small launches that could be folded away)?  One eager step body
-under torch.profiler with stacks.  python tools/probe/find_step_copies.py"""
+"""Which python lines of the rollout step issue small torch launches (copies, fills, casts) that could be folded away?  One eager step body
+with the relevant Tensor methods wrapped to print their caller.  python tools/probe/find_step_copies.py"""
 import os
 import sys
+import traceback
 
 import torch
-from torch.profiler import ProfilerActivity, profile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from parc_amd import workloads  # noqa: E402
@@ -19,11 +19,23 @@ agent._curr_obs, agent._curr_info = env.reset()
 agent._init_train()
 workloads.eager_rollout_like_the_graph(agent, 4)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
-    workloads.eager_rollout_like_the_graph(agent, 1)
+active = [False]
+
+
+def wrap(name):
+    orig = getattr(torch.Tensor, name)
+
+    def f(self, *a, **k):
+        if active[0] and self.is_cuda:
+            fr = [x for x in traceback.extract_stack()[:-1] if "/parc_amd/" in x.filename][-2:]
+            print(name, tuple(self.shape), self.dtype, "|", " <- ".join("%s:%d %s" % (x.filename.split("/parc_amd/")[-1], x.lineno, x.name) for x in reversed(fr)), flush=True)
+        return orig(self, *a, **k)
+    setattr(torch.Tensor, name, f)
+
+
+for n in ("to", "contiguous", "copy_", "clone", "fill_", "zero_", "float", "int", "long", "__setitem__", "expand"):
+    wrap(n)
+active[0] = True
+workloads.eager_rollout_like_the_graph(agent, 1)
+active[0] = False
 torch.cuda.synchronize()
-for ev in prof.events():
-    if ev.name in ("aten::copy_", "aten::fill_", "aten::zero_", "aten::clone", "aten::contiguous", "aten::to", "aten::_to_copy", "aten::zeros",
-                   "aten::empty_like", "aten::empty", "aten::index_put_", "aten::uniform_", "aten::normal_", "aten::randn_like"):
-        stack = [s for s in (ev.stack or []) if "/parc_amd/" in s or "/tools/" in s]
-        print(ev.name, "|", " <- ".join(s.split("/parc_amd/")[-1] for s in stack[:3]))

@@ -16,7 +16,10 @@ sys.argv = [a for a in sys.argv if not a.startswith("--diag=")]
 dev = "cuda:0"
 mp_util.init(0, 1, dev)
 torch.manual_seed(0)
-env, _, _ = workloads.build_env("boxes_64clips", 4096, dev, seed=0)
+_wl = ([a.split("=")[1] for a in sys.argv if a.startswith("--workload=")] or ["boxes_64clips"])[0]
+_ne = int(([a.split("=")[1] for a in sys.argv if a.startswith("--envs=")] or ["4096"])[0])
+sys.argv = [a for a in sys.argv if not a.startswith(("--workload=", "--envs="))]
+env, _, _ = workloads.build_env(_wl, _ne, dev, seed=0)
 agent = workloads.build_agent(env, dev, mp_scale_rollout=False)
 rollout = agent._rollout_train
 if "--eager" in sys.argv:            # the same launches without the hipGraph (rocprofv3's per-kernel durations are only trustworthy for
@@ -38,4 +41,4 @@ dt = time.time() - t0
 if timed:
     us = [p.elapsed_us() for p in env._core.timing_events]
     print("post-step launches timed by events bound to the dispatch: n %d mean %.2f us min %.2f max %.2f" % (len(us), sum(us) / len(us), min(us), max(us)))
-print("rollout steps/s %.1f  ms/step %.3f  env-steps/s %.0f" % (n / dt, dt / n * 1e3, n * 4096 / dt))
+print("rollout steps/s %.1f  ms/step %.3f  env-steps/s %.0f" % (n / dt, dt / n * 1e3, n * _ne / dt))
