@@ -379,6 +379,12 @@ int parc_normalize_clamp(void *stream, int64_t rows, int dim, const float *x, co
  * workspace: parc_moments_workspace_floats(rows, dim) floats of scratch (caller-owned). */
 int64_t parc_moments_workspace_floats(int64_t rows, int dim);
 int parc_moments_accumulate(void *stream, int64_t rows, int dim, const float *x, float *acc, float *workspace);
+/* The three passes a rollout step makes over its observation rows in one: norm_out = parc_normalize_clamp(x) (bit-identical);
+ * copy_dst (may be NULL): x is also written into time row *copy_row (device int64) of a [T, rows, dim] buffer - ExperienceBuffer.record
+ * experience_buffer.py:55-59; acc (may be NULL): parc_moments_accumulate(x) with the same partial rows and summation order
+ * (workspace as there).  All pointers 16-byte aligned, dim a multiple of 4. */
+int parc_obs_ingest(void *stream, int64_t rows, int dim, const float *x, const float *mean, const float *stdv, float clip, float *norm_out,
+                    float *copy_dst, const int64_t *copy_row, float *acc, float *workspace);
 
 /* ---- K14: the part of PPOAgent._decide_action (learning/ppo_agent.py:87-119) after the actor MLP: sample / mode by the
  * exploration mask, log-probability, un-normalised action.  mean, noise, action [n, A]; logstd, a_mean, a_std [A]; explore,

@@ -247,6 +247,8 @@ def _declare(L):
     L.parc_return_tracker_update.restype = c_int
     L.parc_record_step.argtypes = [c_vp, c_int, c_vp, c_int, c_vp]
     L.parc_record_step.restype = c_int
+    L.parc_obs_ingest.argtypes = [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_f, c_vp, c_vp, c_vp, c_vp, c_vp]
+    L.parc_obs_ingest.restype = c_int
     L.parc_rng_step.argtypes = [c_vp, ctypes.c_uint64, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_int]
     L.parc_rng_step.restype = c_int
     L.parc_reset_apply.argtypes = [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int] + [c_vp] * 9
@@ -269,7 +271,7 @@ EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hf
             "parc_relu_bwd_bias_grad", "parc_ppo_loss_packed", "parc_weighted_colsum", "parc_sgd_workspace_floats", "parc_sgd_momentum_step",
             "parc_pose_chain_forward", "parc_pose_chain_backward", "parc_points_hf_sdf_grad", "parc_body_points_world", "parc_body_points_world_grad",
             "parc_quat_diff_angle", "parc_quat_diff_angle_grad", "parc_temporal_terms", "parc_temporal_terms_grad", "parc_step_tail",
-            "parc_assemble_obs", "parc_track_post_step_timed", "parc_rng_step"]
+            "parc_assemble_obs", "parc_track_post_step_timed", "parc_rng_step", "parc_obs_ingest"]
 
 
 def check(rc, what):

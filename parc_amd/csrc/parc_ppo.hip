@@ -422,28 +422,27 @@ extern "C" int parc_rng_step(void *stream, uint64_t seed, uint64_t *state, float
 
 __device__ __forceinline__ float lerp_torch(float a, float b, float w) { return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.0f - w); }
 
-// One env per thread, ceil(N / 256) workgroups.  Each workgroup folds its envs' finished-episode sums in a fixed order and parks
-// them in the workspace; the LAST workgroup to arrive (atomic ticket) adds the partial rows in workgroup order and updates the
-// running means, so the result does not depend on scheduling.  workspace: gridDim.x * TRK_SLOTS floats + one int32 ticket (zero
-// before the first launch; the kernel leaves it zero).
+// ONE workgroup of 1024 threads, envs strided over the threads: every sum is folded inside the workgroup in a fixed order (thread's envs
+// in env order -> wave shuffle -> 16 wave rows in wave order), so the result does not depend on scheduling and nothing has to cross
+// workgroups.  (Until round 3: one env per thread, 16 workgroups, partial rows parked in global memory and folded by the last workgroup
+// to take a ticket - the device-scope fence that hand-over needs made a 180 KB pass take 13.6 us.)
+#undef TRK_THREADS
+#define TRK_THREADS 1024
 __global__ __launch_bounds__(TRK_THREADS) void return_tracker_kernel(int n_envs, int K, const float *__restrict__ rewards, int64_t reward_stride,
                                                                      const int32_t *__restrict__ done, float *return_buf, int64_t *ep_len,
-                                                                     int64_t *eps_per_env, float *mean_return, float *mean_ep_len, double *episodes,
-                                                                     float *workspace) {
+                                                                     int64_t *eps_per_env, float *mean_return, float *mean_ep_len, double *episodes) {
     __shared__ float s_part[TRK_THREADS / 64][TRK_SLOTS];
     __shared__ float s_tot[TRK_SLOTS];
-    __shared__ int s_last;
     const int tid = threadIdx.x;
-    const int e = blockIdx.x * TRK_THREADS + tid;
     float acc[TRK_SLOTS];
 #pragma unroll
     for (int k = 0; k < TRK_SLOTS; ++k) acc[k] = 0.f;
-    if (e < n_envs) {
+    for (int e = tid; e < n_envs; e += TRK_THREADS) {
         const bool fin = done[e] != 0;
         const int64_t len = ep_len[e] + 1;
         if (fin) {
-            acc[TRK_MAX_K] = (float)len;
-            acc[TRK_MAX_K + 1] = 1.0f;
+            acc[TRK_MAX_K] += (float)len;
+            acc[TRK_MAX_K + 1] += 1.0f;
             eps_per_env[e] += 1;
         }
         ep_len[e] = fin ? 0 : len;
@@ -451,7 +450,7 @@ __global__ __launch_bounds__(TRK_THREADS) void return_tracker_kernel(int n_envs,
         for (int k = 0; k < TRK_MAX_K; ++k) {
             if (k < K) {
                 const float v = return_buf[(size_t)k * n_envs + e] + rewards[(size_t)k * reward_stride + e];
-                if (fin) acc[k] = v;
+                if (fin) acc[k] += v;
                 return_buf[(size_t)k * n_envs + e] = fin ? 0.f : v;
             }
         }
@@ -463,26 +462,13 @@ __global__ __launch_bounds__(TRK_THREADS) void return_tracker_kernel(int n_envs,
         if (ln == 0) s_part[wv][k] = v;
     }
     __syncthreads();
-    float *part = workspace;
-    int *ticket = reinterpret_cast<int *>(workspace + (size_t)gridDim.x * TRK_SLOTS);
     if (tid < TRK_SLOTS) {
         float v = 0.f;
         for (int w = 0; w < TRK_THREADS / 64; ++w) v += s_part[w][tid];
-        part[(size_t)blockIdx.x * TRK_SLOTS + tid] = v;
-    }
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (tid < TRK_SLOTS) {
-        float v = 0.f;
-        for (unsigned g = 0; g < gridDim.x; ++g) v += part[(size_t)g * TRK_SLOTS + tid];
         s_tot[tid] = v;
     }
-    if (tid == 0) *ticket = 0;
     __syncthreads();
+    // DMPPOReturnTracker.update's running means (dm_ppo_return_tracker.py:60-99): weights by episode count
     const float n_new = s_tot[TRK_MAX_K + 1];
     if (n_new > 0.f) {
         const double new_count = episodes[0] + (double)n_new;
@@ -496,15 +482,16 @@ __global__ __launch_bounds__(TRK_THREADS) void return_tracker_kernel(int n_envs,
 
 extern "C" int64_t parc_return_tracker_workspace_floats(int n_envs) {
     if (n_envs <= 0) return -1;
-    return (int64_t)((n_envs + TRK_THREADS - 1) / TRK_THREADS) * TRK_SLOTS + 4;
+    return 4;          // (nothing is parked in it any more)
 }
 
 extern "C" int parc_return_tracker_update(void *stream, int n_envs, int K, const float *rewards, int64_t reward_stride, const int32_t *done,
                                           float *return_buf, int64_t *ep_len, int64_t *eps_per_env, float *mean_return, float *mean_ep_len,
                                           double *episodes, float *workspace) {
-    if (n_envs <= 0 || K <= 0 || K > TRK_MAX_K || reward_stride < n_envs || !workspace) return PARC_EINVAL;
-    hipLaunchKernelGGL(return_tracker_kernel, dim3((n_envs + TRK_THREADS - 1) / TRK_THREADS), dim3(TRK_THREADS), 0, (hipStream_t)stream, n_envs, K,
-                       rewards, reward_stride, done, return_buf, ep_len, eps_per_env, mean_return, mean_ep_len, episodes, workspace);
+    if (n_envs <= 0 || K <= 0 || K > TRK_MAX_K || reward_stride < n_envs) return PARC_EINVAL;
+    (void)workspace;          // (unused since round 4: nothing crosses workgroups any more; kept in the signature)
+    hipLaunchKernelGGL(return_tracker_kernel, dim3(1), dim3(TRK_THREADS), 0, (hipStream_t)stream, n_envs, K, rewards, reward_stride, done, return_buf,
+                       ep_len, eps_per_env, mean_return, mean_ep_len, episodes);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }
@@ -664,6 +651,47 @@ __global__ __launch_bounds__(256) void moments_partial_kernel(int rows, int dim4
     }
 }
 
+// The rollout step's three passes over the observation rows in ONE (parc_obs_ingest): Normalizer.normalize for the policy forward
+// (normalizer.py:60-63; same fp32 operations as normalize_clamp_kernel: bit-identical), ExperienceBuffer.record of the raw rows
+// (experience_buffer.py:55-59) into time row *copy_row, and stage 1 of Normalizer.record (the kernel above: same mapping, same
+// summation order, hence the same partial rows).  The rows are read once instead of three times.
+__global__ __launch_bounds__(256) void obs_ingest_kernel(int rows, int dim4, const float4 *__restrict__ x, const float4 *__restrict__ mean,
+                                                         const float4 *__restrict__ stdv, float clip, float4 *__restrict__ norm_out,
+                                                         float4 *copy_dst, const int64_t *__restrict__ copy_row, float4 *partial) {
+    __shared__ float4 red[2][4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int r0 = blockIdx.y * MOM_ROWS, r1 = min(r0 + MOM_ROWS, rows);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (c < dim4) {
+        const float4 m = mean[c], sd = stdv[c];
+        float4 *dst = copy_dst ? copy_dst + (size_t)copy_row[0] * (size_t)rows * dim4 : nullptr;
+        for (int r = r0 + rg; r < r1; r += 4) {
+            const size_t i = (size_t)r * dim4 + c;
+            const float4 v = x[i];
+            float4 o;
+            o.x = fminf(fmaxf((v.x - m.x) / sd.x, -clip), clip);
+            o.y = fminf(fmaxf((v.y - m.y) / sd.y, -clip), clip);
+            o.z = fminf(fmaxf((v.z - m.z) / sd.z, -clip), clip);
+            o.w = fminf(fmaxf((v.w - m.w) / sd.w, -clip), clip);
+            norm_out[i] = o;
+            if (dst) dst[i] = v;
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+        }
+    }
+    if (!partial) return;               // (uniform: a launch argument)
+    red[0][rg][lane] = s;
+    red[1][rg][lane] = q;
+    __syncthreads();
+    if (rg < 2 && c < dim4) {
+        const float4 a = red[rg][0][lane], b = red[rg][1][lane], d = red[rg][2][lane], e = red[rg][3][lane];
+        float4 o;
+        o.x = (a.x + b.x) + (d.x + e.x); o.y = (a.y + b.y) + (d.y + e.y); o.z = (a.z + b.z) + (d.z + e.z); o.w = (a.w + b.w) + (d.w + e.w);
+        partial[((size_t)blockIdx.y * 2 + rg) * dim4 + c] = o;
+    }
+}
+
 // (stage 2 stays a launch of its own: folded into stage 1 behind per-column-block tickets - round 4 - the launch took 38 us instead of
 // 6.8 + 4.9: the partial rows must be visible to the last workgroup, and a device-scope release fence per workgroup costs more than
 // the launch it saves)
@@ -685,6 +713,24 @@ __global__ __launch_bounds__(256) void moments_final_kernel(int chunks, int dim4
 extern "C" int64_t parc_moments_workspace_floats(int64_t rows, int dim) {
     if (rows < 0 || dim <= 0) return -1;
     return ((rows + MOM_ROWS - 1) / MOM_ROWS) * 2 * (int64_t)dim;
+}
+
+extern "C" int parc_obs_ingest(void *stream, int64_t rows, int dim, const float *x, const float *mean, const float *stdv, float clip, float *norm_out,
+                               float *copy_dst, const int64_t *copy_row, float *acc, float *workspace) {
+    if (rows < 0 || dim <= 0 || (dim & 3) || !x || !mean || !stdv || !norm_out || (copy_dst && !copy_row) || (acc && !workspace) ||
+        (((uintptr_t)x | (uintptr_t)mean | (uintptr_t)stdv | (uintptr_t)norm_out | (uintptr_t)copy_dst | (uintptr_t)acc | (uintptr_t)workspace) & 15))
+        return PARC_EINVAL;
+    if (rows == 0) return PARC_OK;
+    if (rows > (int64_t)MOM_ROWS * 65535) return PARC_EUNSUPPORTED;
+    const int dim4 = dim / 4, chunks = (int)((rows + MOM_ROWS - 1) / MOM_ROWS);
+    hipLaunchKernelGGL(obs_ingest_kernel, dim3((dim4 + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, (int)rows, dim4, (const float4 *)x,
+                       (const float4 *)mean, (const float4 *)stdv, clip, (float4 *)norm_out, (float4 *)copy_dst, copy_row,
+                       acc ? (float4 *)workspace : (float4 *)nullptr);
+    if (acc)
+        hipLaunchKernelGGL(moments_final_kernel, dim3((2 * dim4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, chunks, dim4,
+                           (const float4 *)workspace, (float4 *)acc);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
 }
 
 extern "C" int parc_moments_accumulate(void *stream, int64_t rows, int dim, const float *x, float *acc, float *workspace) {

@@ -224,7 +224,16 @@ class DMPPOAgent(torch.nn.Module):
     # ------------------------------------------------------------------ acting (ppo_agent.py:87-119)
     @torch.no_grad()
     def _decide_action(self, obs, info):
-        norm_obs = self._obs_norm.normalize(obs)
+        self._obs_ingested = False
+        if getattr(self, "_in_graph_step", False) and self._mode == AgentMode.TRAIN and self._obs_norm.can_ingest(obs) \
+                and obs.shape[0] == self.get_num_envs() and self._exp_buffer._device_head is not None:
+            # captured step: normalisation for the forward pass, the raw copy into the experience buffer's row and the normaliser's
+            # moment sums in ONE pass over the observation rows (_record_data_pre_step then skips those two)
+            norm_obs = self._obs_norm.ingest(obs, record=self._need_normalizer_update(),
+                                             copy_into=(self._exp_buffer.get_data("obs"), self._exp_buffer._device_head))
+            self._obs_ingested = True
+        else:
+            norm_obs = self._obs_norm.normalize(obs)
         dist = self._model.eval_actor(norm_obs)
         if obs.is_cuda and dist.logstd.dim() == 2 and dist.logstd.stride(0) == 0 and self._config.get("fused_action_head", True):
             return self._decide_action_fused(dist, obs.shape[0])
@@ -281,11 +290,13 @@ class DMPPOAgent(torch.nn.Module):
     def _record_data_pre_step(self, obs, info, action, action_info):
         eb = self._exp_buffer
         if getattr(self, "_in_graph_step", False):
-            # captured step: the five pre-step buffers in one launch (K15), sources at stable addresses
-            if self._need_normalizer_update():
+            # captured step: the pre-step buffers in one launch (K15), sources at stable addresses; the observation rows and their
+            # moment sums were already taken care of by the pass that normalised them (_decide_action)
+            ingested = getattr(self, "_obs_ingested", False)
+            if self._need_normalizer_update() and not ingested:
                 self._obs_norm.record(obs)
-            eb.record_group([("obs", obs), ("action", action), ("a_logp", action_info["a_logp"]),
-                             ("rand_action_mask", action_info["rand_action_mask"]),
+            eb.record_group(([] if ingested else [("obs", obs)]) +
+                            [("action", action), ("a_logp", action_info["a_logp"]), ("rand_action_mask", action_info["rand_action_mask"]),
                              ("prev_char_contact_forces", self._env._char_contact_forces)])
             return
         eb.record("obs", obs)

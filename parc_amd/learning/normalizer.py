@@ -109,5 +109,33 @@ class Normalizer(torch.nn.Module):
             return out
         return res
 
+    def can_ingest(self, x):
+        return (x.is_cuda and x.dtype == torch.float32 and self.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2 and self._mean.dim() == 1
+                and self._mean.shape[0] % 4 == 0 and x.shape[-1] == self._mean.shape[0] and x.data_ptr() % 16 == 0 and np.isfinite(self._clip))
+
+    def ingest(self, x, record=False, copy_into=None, out=None):
+        """normalize(x) - and, in the SAME pass over the rows (parc_obs_ingest), record(x) when `record` and a raw copy of the rows into
+        time row `head` of a [T, N, D] buffer when copy_into = (buffer, head device int64): what a rollout step does with its
+        observations in three launches otherwise.  Results equal the three separate calls bit for bit."""
+        from .. import _hip
+        assert self.can_ingest(x)
+        L = _hip.lib()
+        if out is None:
+            out = torch.empty_like(x)
+        ws = None
+        if record:
+            self._new_count += x.shape[0]
+            need = int(L.parc_moments_workspace_floats(x.shape[0], x.shape[1]))
+            if self._scratch is None or self._scratch.numel() < need:
+                self._scratch = torch.empty(need, dtype=torch.float32, device=x.device)
+            ws = self._scratch
+        dst, row = (None, None) if copy_into is None else copy_into
+        if dst is not None:
+            assert dst.is_contiguous() and dst.dtype == torch.float32 and tuple(dst.shape[1:]) == tuple(x.shape) and dst.data_ptr() % 16 == 0
+        _hip.check(L.parc_obs_ingest(_hip.stream(), x.shape[0], x.shape[1], _hip.ptr(x), _hip.ptr(self._mean), _hip.ptr(self._std), float(self._clip),
+                                     _hip.ptr(out), _hip.ptr(dst), _hip.ptr(row), _hip.ptr(self._acc) if record else None, _hip.ptr(ws)),
+                   "parc_obs_ingest")
+        return out
+
     def unnormalize(self, norm_x):
         return (norm_x * self._std + self._mean).type(self.dtype)

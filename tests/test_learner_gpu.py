@@ -481,3 +481,30 @@ def test_graph_rollout_writes_the_same_rows_as_the_eager_rollout():
         assert np.all(np.where(done, ts[1:] == 1, d_ts == 1)) and np.all(np.where(done, d_ep == 1, d_ep == 0))
         assert np.isfinite(info["critic_loss"].item())
         assert agent._head_dev == (eb._buffer_head - 1) % eb._buffer_length or not agent._graphs
+
+
+def test_obs_ingest_equals_its_three_separate_passes():
+    """parc_obs_ingest = Normalizer.normalize + the raw copy into row *head of the experience buffer + Normalizer.record in one pass over
+    the observation rows: every output bit-identical to the three launches it replaces (same fp32 operations, same partial rows, same
+    summation order), with and without the optional parts, for a row count that leaves a ragged last chunk."""
+    from parc_amd.learning.normalizer import Normalizer
+    g = torch.Generator(device="cpu").manual_seed(5)
+    N, D, T_ = 1000, 1312, 3
+    a, b = Normalizer((D,), device=DEV, clip=10.0), Normalizer((D,), device=DEV, clip=10.0)
+    for n in (a, b):
+        n._mean[:] = torch.randn(D, generator=torch.Generator().manual_seed(1)).to(DEV)
+        n._std[:] = (torch.rand(D, generator=torch.Generator().manual_seed(2)) + 0.5).to(DEV)
+    buf = torch.full((T_, N, D), -1.0, device=DEV)
+    head = torch.tensor([2], dtype=torch.int64, device=DEV)
+    for it in range(3):
+        x = (torch.randn((N, D), generator=g) * 3.0).to(DEV)
+        want_norm = a.normalize(x)
+        a.record(x)
+        got = b.ingest(x, record=True, copy_into=(buf, head))
+        assert torch.equal(got, want_norm) and torch.equal(buf[2], x) and (buf[:2] == -1.0).all()
+        assert torch.equal(a._acc, b._acc) and a._new_count == b._new_count == (it + 1) * N
+    x = (torch.randn((N, D), generator=g) * 3.0).to(DEV)
+    acc0 = b._acc.clone()
+    assert torch.equal(b.ingest(x), a.normalize(x)) and torch.equal(b._acc, acc0) and torch.equal(buf[2], buf[2])   # nothing optional: normalise only
+    a.update(); b.update()
+    assert torch.equal(a._mean, b._mean) and torch.equal(a._std, b._std)
