@@ -391,6 +391,12 @@ int parc_obs_ingest(void *stream, int64_t rows, int dim, const float *x, const f
  * logp [n]. */
 int parc_action_head(void *stream, int n, int A, const float *mean, const float *logstd, const float *noise, const float *explore,
                      const float *a_mean, const float *a_std, float *action, float *logp);
+/* The same, and in the same launch what ExperienceBuffer.record stores of this moment (base_agent's _record_data_pre_step,
+ * dm_ppo_agent.py:289-299): action / a_logp / rand_action_mask (= explore) and the env's contact forces forces_src [n, n_forces] into
+ * time row *head (device int64) of rec_action [T, n, A], rec_logp [T, n], rec_mask [T, n], rec_forces [T, n, n_forces].  A <= 32. */
+int parc_action_head_record(void *stream, int n, int A, const float *mean, const float *logstd, const float *noise, const float *explore,
+                            const float *a_mean, const float *a_std, float *action, float *logp, float *rec_action, float *rec_logp,
+                            float *rec_mask, const float *forces_src, float *rec_forces, int n_forces, const int64_t *head);
 
 /* ---- next rows: terrain geometry either side of the tracker -----------------------------------------------
  * terrain_util.points_hf_sdf  util/terrain_util.py:1835-1893 (+ points_boxes_sdf :1774-1804, geom_util.sdBox/sdRoundBox

@@ -221,6 +221,8 @@ def _declare(L):
     L.parc_normalize_clamp.restype = c_int
     L.parc_action_head.argtypes = [c_vp, c_int, c_int] + [c_vp] * 8
     L.parc_action_head.restype = c_int
+    L.parc_action_head_record.argtypes = [c_vp, c_int, c_int] + [c_vp] * 8 + [c_vp] * 5 + [c_int, c_vp]
+    L.parc_action_head_record.restype = c_int
     L.parc_points_hf_sdf.argtypes = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 5 + [c_f, c_f, c_f, c_int, c_f, c_vp, c_vp]
     L.parc_points_hf_sdf.restype = c_int
     L.parc_points_hf_sdf_grad.argtypes = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 5 + [c_f, c_f, c_f, c_int, c_vp, c_vp, c_vp]
@@ -271,7 +273,7 @@ EXPORTED = ["parc_abi_version", "parc_refresh_ray_obs_hfs", "parc_refresh_obs_hf
             "parc_relu_bwd_bias_grad", "parc_ppo_loss_packed", "parc_weighted_colsum", "parc_sgd_workspace_floats", "parc_sgd_momentum_step",
             "parc_pose_chain_forward", "parc_pose_chain_backward", "parc_points_hf_sdf_grad", "parc_body_points_world", "parc_body_points_world_grad",
             "parc_quat_diff_angle", "parc_quat_diff_angle_grad", "parc_temporal_terms", "parc_temporal_terms_grad", "parc_step_tail",
-            "parc_assemble_obs", "parc_track_post_step_timed", "parc_rng_step", "parc_obs_ingest"]
+            "parc_assemble_obs", "parc_track_post_step_timed", "parc_rng_step", "parc_obs_ingest", "parc_action_head_record"]
 
 
 def check(rc, what):

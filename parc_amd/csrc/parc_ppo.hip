@@ -875,10 +875,20 @@ __global__ __launch_bounds__(256) void action_head_kernel(int n, int A, const fl
 
 // A <= 32 (the humanoid has 28 actuated dofs): 32 lanes per env, lane j = action dimension j - coalesced reads of the [n, A] rows and
 // 512 workgroups at 4096 envs instead of 16; the two sums over j are 5-step xor-shuffle reductions inside the 32-lane group.
+// (rec.head != NULL: the same launch also writes what ExperienceBuffer.record stores of this moment - action, a_logp,
+// rand_action_mask and the contact forces the env holds before the step - into time row *head of their [T, n, ...] buffers:
+// base_agent's _record_data_pre_step (ppo_agent.py:121-125, dm_ppo_agent.py:289-299) without a launch of its own)
+struct action_record_t {
+    float *action, *logp, *mask, *forces;      // [T, n, A] [T, n] [T, n] [T, n, n_forces]
+    const float *forces_src;                    // [n, n_forces]
+    int n_forces;
+    const int64_t *head;
+};
+
 __global__ __launch_bounds__(256) void action_head32_kernel(int n, int A, const float *__restrict__ mean, const float *__restrict__ logstd,
                                                             const float *__restrict__ noise, const float *__restrict__ explore,
                                                             const float *__restrict__ a_mean, const float *__restrict__ a_std, float *action,
-                                                            float *logp) {
+                                                            float *logp, action_record_t rec) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = min(gid >> 5, n - 1), j = gid & 31;           // (tail groups redo the last env; they skip the stores)
     const bool live = (gid >> 5) < n, valid = j < A;
@@ -890,14 +900,28 @@ __global__ __launch_bounds__(256) void action_head32_kernel(int n, int A, const 
         const float na = explore[i] == 1.0f ? mu + sd * noise[(size_t)i * A + j] : mu;
         const float z = (na - mu) / sd;
         zz = z * z;
-        if (live) action[(size_t)i * A + j] = na * a_std[j] + a_mean[j];
+        if (live) {
+            const float a = na * a_std[j] + a_mean[j];
+            action[(size_t)i * A + j] = a;
+            if (rec.head) rec.action[((size_t)rec.head[0] * n + i) * A + j] = a;
+        }
     }
 #pragma unroll
     for (int o = 16; o >= 1; o >>= 1) {
         zz += __shfl_xor(zz, o, 32);
         ls += __shfl_xor(ls, o, 32);
     }
-    if (live && j == 0) logp[i] = -0.5f * zz + (-0.5f * (float)A * 1.8378770664093453f - ls);
+    if (live && j == 0) {
+        const float lp = -0.5f * zz + (-0.5f * (float)A * 1.8378770664093453f - ls);
+        logp[i] = lp;
+        if (rec.head) {
+            const size_t row = (size_t)rec.head[0] * n + i;
+            rec.logp[row] = lp;
+            rec.mask[row] = explore[i];
+        }
+    }
+    if (live && rec.head)
+        for (int k = j; k < rec.n_forces; k += 32) rec.forces[((size_t)rec.head[0] * n + i) * rec.n_forces + k] = rec.forces_src[(size_t)i * rec.n_forces + k];
 }
 
 extern "C" int parc_action_head(void *stream, int n, int A, const float *mean, const float *logstd, const float *noise, const float *explore,
@@ -905,13 +929,27 @@ extern "C" int parc_action_head(void *stream, int n, int A, const float *mean, c
     if (n <= 0 || A <= 0) return PARC_EINVAL;
     if (A <= 32) {
         const long long threads = (long long)n * 32;
+        action_record_t none = {};
         hipLaunchKernelGGL(action_head32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, A, mean, logstd, noise,
-                           explore, a_mean, a_std, action, logp);
+                           explore, a_mean, a_std, action, logp, none);
         hipError_t e32 = hipGetLastError();
         return e32 == hipSuccess ? PARC_OK : (int)e32;
     }
     hipLaunchKernelGGL(action_head_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, A, mean, logstd, noise, explore, a_mean,
                        a_std, action, logp);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PARC_OK : (int)e;
+}
+
+extern "C" int parc_action_head_record(void *stream, int n, int A, const float *mean, const float *logstd, const float *noise, const float *explore,
+                                       const float *a_mean, const float *a_std, float *action, float *logp, float *rec_action, float *rec_logp,
+                                       float *rec_mask, const float *forces_src, float *rec_forces, int n_forces, const int64_t *head) {
+    if (n <= 0 || A <= 0 || !rec_action || !rec_logp || !rec_mask || !forces_src || !rec_forces || n_forces < 0 || !head) return PARC_EINVAL;
+    if (A > 32) return PARC_EUNSUPPORTED;
+    action_record_t rec = {rec_action, rec_logp, rec_mask, rec_forces, forces_src, n_forces, head};
+    const long long threads = (long long)n * 32;
+    hipLaunchKernelGGL(action_head32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, A, mean, logstd, noise, explore,
+                       a_mean, a_std, action, logp, rec);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }

@@ -224,7 +224,7 @@ class DMPPOAgent(torch.nn.Module):
     # ------------------------------------------------------------------ acting (ppo_agent.py:87-119)
     @torch.no_grad()
     def _decide_action(self, obs, info):
-        self._obs_ingested = False
+        self._obs_ingested = self._action_recorded = False
         if getattr(self, "_in_graph_step", False) and self._mode == AgentMode.TRAIN and self._obs_norm.can_ingest(obs) \
                 and obs.shape[0] == self.get_num_envs() and self._exp_buffer._device_head is not None:
             # captured step: normalisation for the forward pass, the raw copy into the experience buffer's row and the normaliser's
@@ -278,6 +278,21 @@ class DMPPOAgent(torch.nn.Module):
         a = torch.empty_like(mean)
         logp = torch.empty(n, dtype=torch.float32, device=mean.device)
         p = _hip.ptr
+        eb = self._exp_buffer
+        self._action_recorded = False
+        if (getattr(self, "_in_graph_step", False) and self._mode == AgentMode.TRAIN and A <= 32 and eb._device_head is not None and n == self.get_num_envs()
+                and hasattr(self._env, "_char_contact_forces")):
+            # captured step: the head also writes action / a_logp / rand_action_mask / the contact forces of this moment into the
+            # experience buffer's row (_record_data_pre_step without a launch of its own)
+            f = self._env._char_contact_forces
+            nf = f[0].numel()
+            _hip.check(_hip.lib().parc_action_head_record(_hip.stream(), n, A, p(mean), p(dist.logstd[0].contiguous()), p(noise), p(mask),
+                                                          p(self._a_norm.get_mean()), p(self._a_norm.get_std()), p(a), p(logp),
+                                                          p(eb.get_data("action")), p(eb.get_data("a_logp")), p(eb.get_data("rand_action_mask")),
+                                                          p(f.contiguous()), p(eb.get_data("prev_char_contact_forces")), nf, p(eb._device_head)),
+                       "parc_action_head_record")
+            self._action_recorded = True
+            return a, {"a_logp": logp, "rand_action_mask": mask}
         _hip.check(_hip.lib().parc_action_head(_hip.stream(), n, A, p(mean), p(dist.logstd[0].contiguous()), p(noise), p(mask),
                                                p(self._a_norm.get_mean()), p(self._a_norm.get_std()), p(a), p(logp)), "parc_action_head")
         return a, {"a_logp": logp, "rand_action_mask": mask}
@@ -295,9 +310,12 @@ class DMPPOAgent(torch.nn.Module):
             ingested = getattr(self, "_obs_ingested", False)
             if self._need_normalizer_update() and not ingested:
                 self._obs_norm.record(obs)
-            eb.record_group(([] if ingested else [("obs", obs)]) +
-                            [("action", action), ("a_logp", action_info["a_logp"]), ("rand_action_mask", action_info["rand_action_mask"]),
-                             ("prev_char_contact_forces", self._env._char_contact_forces)])
+            items = [] if ingested else [("obs", obs)]
+            if not getattr(self, "_action_recorded", False):     # (else the action head wrote them itself: _decide_action_fused)
+                items += [("action", action), ("a_logp", action_info["a_logp"]), ("rand_action_mask", action_info["rand_action_mask"]),
+                          ("prev_char_contact_forces", self._env._char_contact_forces)]
+            if items:
+                eb.record_group(items)
             return
         eb.record("obs", obs)
         eb.record("action", action)

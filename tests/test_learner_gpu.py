@@ -481,6 +481,19 @@ def test_graph_rollout_writes_the_same_rows_as_the_eager_rollout():
         assert np.all(np.where(done, ts[1:] == 1, d_ts == 1)) and np.all(np.where(done, d_ep == 1, d_ep == 0))
         assert np.isfinite(info["critic_loss"].item())
         assert agent._head_dev == (eb._buffer_head - 1) % eb._buffer_length or not agent._graphs
+        # rows written by the fused passes of the captured step (observation ingest, action head) hold what the separate record
+        # launches put there: obs[t + 1] is next_obs[t] and the forces carry over wherever the env did not restart; the stored
+        # log-probability is the policy's for the stored action on the stored observation
+        obs, nxt = eb.get_data("obs"), eb.get_data("next_obs")
+        keep = ~torch.tensor(done, device=DEV)
+        assert torch.equal(obs[1:][keep], nxt[:-1][keep])
+        assert torch.equal(eb.get_data("prev_char_contact_forces")[1:][keep], eb.get_data("next_char_contact_forces")[:-1][keep])
+        assert (eb.get_data("rand_action_mask") == 1.0).all()
+        with torch.no_grad():
+            t_ = 5
+            dist = agent._model.eval_actor(agent._obs_norm.normalize(obs[t_].contiguous()))
+            lp = dist.log_prob(agent._a_norm.normalize(eb.get_data("action")[t_]))
+        assert (lp - eb.get_data("a_logp")[t_]).abs().max() < 2e-3 and torch.isfinite(eb.get_data("action")).all()
 
 
 def test_obs_ingest_equals_its_three_separate_passes():

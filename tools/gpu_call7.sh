@@ -1,7 +1,8 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/c7; rm -rf $O; mkdir -p $O
-timeout -k 10 300 python3 tools/probe/find_step_copies.py > $O/step_copies.txt 2>&1; grep "|" $O/step_copies.txt | head -40
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -n 12 $O/pytest.log; [ $rc -eq 0 ] || exit $rc
+timeout -k 10 300 bash tools/rollout_trace.sh > $O/rollout_one_step_trace.txt 2>&1; tail -n 28 $O/rollout_one_step_trace.txt | cut -c1-140
 timeout -k 10 500 python3 bench.py > $O/bench.json 2> $O/bench.err; tail -n 3 $O/bench.err; python3 - <<'PY'
 import json
 d=json.loads([l for l in open('gpurun_out/c7/bench.json') if l.startswith('{')][-1])
