@@ -437,21 +437,39 @@ __global__ __launch_bounds__(TRK_THREADS) void return_tracker_kernel(int n_envs,
     float acc[TRK_SLOTS];
 #pragma unroll
     for (int k = 0; k < TRK_SLOTS; ++k) acc[k] = 0.f;
-    for (int e = tid; e < n_envs; e += TRK_THREADS) {
-        const bool fin = done[e] != 0;
-        const int64_t len = ep_len[e] + 1;
-        if (fin) {
-            acc[TRK_MAX_K] += (float)len;
-            acc[TRK_MAX_K + 1] += 1.0f;
-            eps_per_env[e] += 1;
-        }
-        ep_len[e] = fin ? 0 : len;
+    // 4 envs per thread and pass: all their loads are issued before anything is stored (the buffers are read and written through the
+    // same pointers, so a one-env loop serialises load - store - load: 20 us for 180 KB)
+    for (int e0 = tid; e0 < n_envs; e0 += 4 * TRK_THREADS) {
+        bool fin[4];
+        int64_t len[4];
+        float v[4][TRK_MAX_K];
 #pragma unroll
-        for (int k = 0; k < TRK_MAX_K; ++k) {
-            if (k < K) {
-                const float v = return_buf[(size_t)k * n_envs + e] + rewards[(size_t)k * reward_stride + e];
-                if (fin) acc[k] += v;
-                return_buf[(size_t)k * n_envs + e] = fin ? 0.f : v;
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * TRK_THREADS;
+            const bool in = e < n_envs;
+            const int ec = in ? e : e0;
+            fin[u] = in && done[ec] != 0;
+            len[u] = ep_len[ec] + 1;
+#pragma unroll
+            for (int k = 0; k < TRK_MAX_K; ++k)
+                v[u][k] = k < K ? return_buf[(size_t)k * n_envs + ec] + rewards[(size_t)k * reward_stride + ec] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * TRK_THREADS;
+            if (e >= n_envs) continue;
+            if (fin[u]) {
+                acc[TRK_MAX_K] += (float)len[u];
+                acc[TRK_MAX_K + 1] += 1.0f;
+                eps_per_env[e] += 1;
+            }
+            ep_len[e] = fin[u] ? 0 : len[u];
+#pragma unroll
+            for (int k = 0; k < TRK_MAX_K; ++k) {
+                if (k < K) {
+                    if (fin[u]) acc[k] += v[u][k];
+                    return_buf[(size_t)k * n_envs + e] = fin[u] ? 0.f : v[u][k];
+                }
             }
         }
     }
