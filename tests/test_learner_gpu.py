@@ -469,8 +469,17 @@ def test_graph_rollout_writes_the_same_rows_as_the_eager_rollout():
     assert agent._device_tick()
     agent._curr_obs, agent._curr_info = env.reset()
     agent._init_train()
-    for _ in range(3):                                      # eager warm-up steps, the capture, then steady replays, over three iterations
-        info = agent._train_iter()
+    from parc_amd.learning.dm_ppo_agent import AgentMode
+    for it in range(3):                                     # eager warm-up steps, the capture, then steady replays
+        if it < 2:
+            info = agent._train_iter()
+            assert np.isfinite(info["critic_loss"].item())
+        else:                                               # the third rollout alone: its rows are checked BEFORE an update changes the policy
+            agent._exp_buffer.reset()
+            agent.eval()
+            agent.set_mode(AgentMode.TRAIN)
+            agent._rollout_train(agent._steps_per_iter)
+            assert agent._graphs
         eb = agent._exp_buffer
         ts = eb.get_data("timestep").cpu().numpy()          # [T, N]: the env's step counter after each step
         ep = eb.get_data("ep_num").cpu().numpy()
@@ -479,21 +488,20 @@ def test_graph_rollout_writes_the_same_rows_as_the_eager_rollout():
         # from one row to the next an env either made one more step of the same episode or finished (done in the earlier row) and restarted
         done = eb.get_data("done").cpu().numpy()[:-1] != 0
         assert np.all(np.where(done, ts[1:] == 1, d_ts == 1)) and np.all(np.where(done, d_ep == 1, d_ep == 0))
-        assert np.isfinite(info["critic_loss"].item())
         assert agent._head_dev == (eb._buffer_head - 1) % eb._buffer_length or not agent._graphs
         # rows written by the fused passes of the captured step (observation ingest, action head) hold what the separate record
-        # launches put there: obs[t + 1] is next_obs[t] and the forces carry over wherever the env did not restart; the stored
-        # log-probability is the policy's for the stored action on the stored observation
+        # launches put there: obs[t + 1] is next_obs[t] and the forces carry over wherever the env did not restart
         obs, nxt = eb.get_data("obs"), eb.get_data("next_obs")
         keep = ~torch.tensor(done, device=DEV)
         assert torch.equal(obs[1:][keep], nxt[:-1][keep])
         assert torch.equal(eb.get_data("prev_char_contact_forces")[1:][keep], eb.get_data("next_char_contact_forces")[:-1][keep])
-        assert (eb.get_data("rand_action_mask") == 1.0).all()
-        with torch.no_grad():
-            t_ = 5
+        assert (eb.get_data("rand_action_mask") == 1.0).all() and torch.isfinite(eb.get_data("action")).all()
+    # ... and the stored log-probability is the (unchanged) policy's for the stored action on the stored observation
+    with torch.no_grad():
+        for t_ in (0, 5, 7):
             dist = agent._model.eval_actor(agent._obs_norm.normalize(obs[t_].contiguous()))
             lp = dist.log_prob(agent._a_norm.normalize(eb.get_data("action")[t_]))
-        assert (lp - eb.get_data("a_logp")[t_]).abs().max() < 2e-3 and torch.isfinite(eb.get_data("action")).all()
+            assert (lp - eb.get_data("a_logp")[t_]).abs().max() < 2e-3
 
 
 def test_obs_ingest_equals_its_three_separate_passes():
