@@ -107,9 +107,12 @@ typedef struct {
     float task1_w, task2_w, target_radius;       /* task reward terms, logged only while rel_task_w == 0 */
     float target_future_min, target_future_max;  /* dm.target_xy_future_time_min/max (PARC_POST_TARGETS) */
     /* reward variants (ig_parkour_env.py:1284-1285,1323-1339; mgdm_dm_util.py:343-350): track_root_h = 0 drops the height from the
-     * root position error, use_contact_info = 0 drops the contact penalty from the reward.  (track_root = 0 and global_obs are not
-     * built: the host mirror refuses those configurations.) */
+     * root position error, use_contact_info = 0 drops the contact penalty from the reward. */
     int32_t track_root_h, use_contact_info;
+    /* global_obs (ig_char_env.py:585-590, mgdm_dm_util.py:476-500): observation in world axes instead of the heading frame.
+     * track_root = 0 (the field above) also changes the reward: xy of the root error dropped, root rotation / velocities / key bodies
+     * compared in each character's own heading frame (mgdm_dm_util.py:343-360). */
+    int32_t global_obs;
 } parc_track_cfg_t;
 
 /*

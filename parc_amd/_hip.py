@@ -73,7 +73,7 @@ class TrackCfgS(ctypes.Structure):
                 ("episode_length", c_f), ("contact_eps", c_f), ("min_obs_h", c_f), ("max_obs_h", c_f),
                 ("num_ray_points", c_i32), ("obs_dim", c_i32),
                 ("task1_w", c_f), ("task2_w", c_f), ("target_radius", c_f),
-                ("target_future_min", c_f), ("target_future_max", c_f), ("track_root_h", c_i32), ("use_contact_info", c_i32)]
+                ("target_future_min", c_f), ("target_future_max", c_f), ("track_root_h", c_i32), ("use_contact_info", c_i32), ("global_obs", c_i32)]
 
 
 class EnvBuffersS(ctypes.Structure):

@@ -1150,13 +1150,15 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
         if (pq == 0) {
             const float *prs = buf.root_state + (size_t)pe * 13;
             const q4 cr = ld4(prs + 3);
-            const q4 hi = calc_heading_quat_inv_alg(cr);
+            // global_obs (ig_char_env.py:585-590, mgdm_dm_util.py:476-500): the observation stays in world axes - the "heading frame" every
+            // wave rotates into is the identity, and a target's key bodies are not offset by its root (selector in ed[4].z)
+            const q4 hi = cfg.global_obs ? mk4(0.f, 0.f, 0.f, 1.f) : calc_heading_quat_inv_alg(cr);
             float4 *ed = reinterpret_cast<float4 *>(envd[ple]);
             ed[0] = make_float4(prs[0], prs[1], prs[2], cr.x);
             ed[1] = make_float4(cr.y, cr.z, cr.w, hi.x);
             ed[2] = make_float4(hi.y, hi.z, hi.w, __int_as_float(pe));
             ed[3] = make_float4(prs[7], prs[8], prs[9], prs[10]);
-            ed[4] = make_float4(prs[11], prs[12], 0.f, 0.f);
+            ed[4] = make_float4(prs[11], prs[12], cfg.global_obs ? 0.f : 1.f, 0.f);
         }
         // K3 index part: MotionLib.calc_motion_frame at t (ref) or t + dt_s (targets); dm_env.py:570-582, mgdm_dm_util.py:279-302
         const float t = mtime + (pq > 0 ? cfg.tar_dt[pq - 1] : 0.f);
@@ -1356,7 +1358,7 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             for (int k = 0; k < 6; ++k) seg[3 + 6 * b + k] = tn[k].x, seg[Wt + 3 + 6 * b + k] = tn[k].y;
         }
         if (key_slot >= 0) {
-            const v3p kp = quat_rotate(hinv, pos - p_root) + rpo;
+            const v3p kp = quat_rotate(hinv, pos - p_root) + envd[le][18] * rpo;     // (+ rpo unless global_obs)
             float *ka = seg + 9 + 6 * J + 3 * key_slot;
             ka[0] = kp.x.x, ka[1] = kp.y.x, ka[2] = kp.z.x;
             ka[Wt] = kp.x.y, ka[Wt + 1] = kp.y.y, ka[Wt + 2] = kp.z.y;
@@ -1448,7 +1450,8 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
             // ig_char_env.py:618-620: root height) for parc_assemble_obs
             float *aux = kernarg_late<parc_env_buffers_t>(KARG_OFF_BUF)->obs_aux;
             if (aux) {
-                const v3 lt = quat_rotate(hinv, mk3(tgt_xy[le][0] - c_pos.x, tgt_xy[le][1] - c_pos.y, 0.f));
+                const q4 th = kernarg_late<parc_track_cfg_t>(KARG_OFF_CFG)->global_obs ? calc_heading_quat_inv_alg(c_rot) : hinv;   // always the heading
+                const v3 lt = quat_rotate(th, mk3(tgt_xy[le][0] - c_pos.x, tgt_xy[le][1] - c_pos.y, 0.f));
                 reinterpret_cast<float4 *>(aux)[e] = make_float4(c_pos.z, lt.x, lt.y, 0.f);
             }
         }
@@ -1519,7 +1522,12 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                     // second barrier, and with it every wave of the workgroup would wait for the slowest one
                     q4 cj = c_rot;
                     if (b > 0) cj = joint_rot_lds(dofs);
-                    rot_diff = quat_diff_angle(cj, rq);                 // (lane 0: rq = r_rot, the reference root rotation)
+                    q4 rj = rq;                                         // (lane 0: rq = r_rot, the reference root rotation)
+                    if (!rcfg.track_root && b == 0) {                   // convert_to_local (mgdm_dm_util.py:304-325,358-360): heading-relative root rotations
+                        cj = quat_mul(calc_heading_quat_inv_alg(c_rot), c_rot);
+                        rj = quat_mul(calc_heading_quat_inv_alg(r_rot), r_rot);
+                    }
+                    rot_diff = quat_diff_angle(cj, rj);
                     if (b > 0) pose_e = rcfg.joint_err_w[b - 1] * rot_diff * rot_diff;
                 }
                 #pragma unroll 1
@@ -1528,7 +1536,12 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                     vel_e += rcfg.dof_err_w[d] * dv * dv;
                 }
                 if (key_slot >= 0) {
-                    v3 df = (pos - r_pos) - (sim_pos - c_pos);
+                    v3 kr = pos - r_pos, kc = sim_pos - c_pos;
+                    if (!rcfg.track_root) {                             // key bodies in each character's own heading frame
+                        kr = quat_rotate(calc_heading_quat_inv_alg(r_rot), kr);
+                        kc = quat_rotate(calc_heading_quat_inv_alg(c_rot), kc);
+                    }
+                    v3 df = kr - kc;
                     key_e = dot3(df, df);
                 }
                 if (valid) {
@@ -1559,11 +1572,18 @@ __global__ __launch_bounds__(POST_MAX_THREADS, POST_MIN_WAVES) void track_post_k
                 fall_height = any16(fall_height);
                 if (b == 0 && live) {
                     v3 dp = r_pos - c_pos;
+                    if (!rcfg.track_root) dp.x = dp.y = 0.f;     // mgdm_dm_util.py:346-347
                     if (!rcfg.track_root_h) dp.z = 0.f;          // mgdm_dm_util.py:349-350
                     float root_pos_err = dot3(dp, dp);
                     const float rre = rot_diff;
                     float rre2 = rre * rre;
-                    v3 dv = r_vel - ld3(envd[le] + 12), dw = r_avel - ld3(envd[le] + 15);
+                    v3 cv = ld3(envd[le] + 12), cw = ld3(envd[le] + 15), rv = r_vel, rw = r_avel;
+                    if (!rcfg.track_root) {                      // root velocities in each character's own heading frame
+                        const q4 hc = calc_heading_quat_inv_alg(c_rot), hr = calc_heading_quat_inv_alg(r_rot);
+                        cv = quat_rotate(hc, cv); cw = quat_rotate(hc, cw);
+                        rv = quat_rotate(hr, rv); rw = quat_rotate(hr, rw);
+                    }
+                    v3 dv = rv - cv, dw = rw - cw;
                     float pose_r = fexp(-0.25f * pose_e);
                     float vel_r = fexp(-0.01f * vel_e);
                     float root_pose_r = fexp(-5.0f * (root_pos_err + 0.1f * rre2));

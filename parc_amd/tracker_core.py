@@ -22,14 +22,7 @@ class TrackerConfig:
         # Variants of IGParkourEnv._compute_obs / _update_reward (ig_parkour_env.py:1054-1244,1275-1404) beyond the tracker's defaults:
         #   has_target_xy_obs, global_root_height_obs, enable_tar_obs = False, use_contact_info = False  -> column layout (obs_layout)
         #   track_root_h = False, use_contact_info = False, rel_task_w > 0                             -> reward (kernel flags / one multiply)
-        # Not built: global_obs (the whole row in world axes) and track_root = False (reward / termination in heading-local axes).
-        unsupported = []
-        if env_config.get("global_obs", False):
-            unsupported.append("global_obs=True")
-        if not env_config.get("track_root", True):
-            unsupported.append("track_root=False")
-        if unsupported:
-            raise NotImplementedError("tracker kernels do not cover: " + ", ".join(unsupported))
+        #   global_obs, track_root = False                                                               -> kernel flags
         self.has_target_xy_obs = bool(env_config.get("has_target_xy_obs", False))
         self.global_root_height_obs = bool(env_config.get("global_root_height_obs", False))
         self.enable_tar_obs = bool(env_config.get("enable_tar_obs", True))
@@ -74,6 +67,7 @@ class TrackerConfig:
         s.rel_deepmimic_w = float(env_config["rel_deepmimic_w"]) if self.rel_task_w <= 0 else 1.0
         s.track_root_h = int(bool(env_config.get("track_root_h", True)))
         s.use_contact_info = int(self.use_contact_info)
+        s.global_obs = int(bool(env_config.get("global_obs", False)))
         ptd = env_config["pose_termination_dist"]
         for i in range(J):
             s.pose_termination_dist[i] = float(ptd[i])

@@ -1703,7 +1703,9 @@ def gen_obs_variants():
                 "no_tar_obs": {"enable_tar_obs": False}, "no_contact_info": {"use_contact_info": False},
                 "no_root_h_tracking": {"track_root_h": False}, "task_product": {"rel_task_w": 0.5, "rel_deepmimic_w": 0.7},
                 "everything": {"has_target_xy_obs": True, "global_root_height_obs": True, "track_root_h": False, "rel_task_w": 1.0},
-                "mgdm_shipped": {"has_target_xy_obs": True, "enable_replan_timer_obs": True, "_mgdm": True}}
+                "mgdm_shipped": {"has_target_xy_obs": True, "enable_replan_timer_obs": True, "_mgdm": True},
+                "global_obs": {"global_obs": True, "has_target_xy_obs": True}, "no_root_tracking": {"track_root": False},
+                "no_root_tracking_at_all": {"track_root": False, "track_root_h": False, "global_obs": True}}
     arrs = {"target_xy": target_xy, "plan_clock": plan_clock}
     tables = {}
     import contextlib
@@ -1717,6 +1719,15 @@ def gen_obs_variants():
         ipe.IGParkourEnv._update_reward(e)
         arrs[tag + "_obs"] = obs
         arrs[tag + "_reward"] = e._reward_buf.clone()
+        if not cfg["track_root"]:
+            # compute_done without the root checks (mgdm_dm_util.py:392-460: `if (track_root)` guards root position / rotation failure)
+            arrs[tag + "_done"] = dmu.compute_done(
+                done_buf=torch.zeros(n, dtype=torch.int), time=t(z["time_buf"]), ep_len=10.0, root_rot=e._char_root_rot,
+                body_pos=e._char_rigid_body_pos, char_root_pos=e._char_root_pos, tar_root_rot=e._ref_root_rot, tar_body_pos=e._ref_body_pos,
+                contact_force=e._char_contact_forces, contact_body_ids=torch.zeros(0, dtype=torch.int64),
+                termination_heights=t(z["termination_heights"]), pose_termination=True, pose_termination_dist=t(z["pose_termination_dist"]),
+                global_obs=bool(cfg["global_obs"]), enable_early_termination=True, track_root=False, root_pos_termination_dist=0.6,
+                root_rot_termination_angle=1.309)
         for k, v in e._info["rewards"].items():
             arrs[tag + "_r_" + k] = v
         tables[tag] = {"config": {k: v for k, v in over.items()},

@@ -206,18 +206,22 @@ def test_g6_fused_post_step(km, mlib, oracle, ref_char, ref_mlib):
 
 
 @pytest.mark.parametrize("tag", ["target_xy", "root_height", "no_tar_obs", "no_contact_info", "no_root_h_tracking", "task_product",
-                                 "everything", "mgdm_shipped"])
+                                 "everything", "mgdm_shipped", "global_obs", "no_root_tracking", "no_root_tracking_at_all"])
 def test_g26_observation_and_reward_variants(km, mlib, tag):
     """Fixture G26 = the reference's own IGParkourEnv._compute_obs / _update_reward (ig_parkour_env.py:1054-1244,1275-1404) run on the
     G6 state under the non-default switches: has_target_xy_obs (the configuration data/envs/ig_parkour_env.yaml ships),
-    global_root_height_obs, enable_tar_obs / use_contact_info off, track_root_h off, rel_task_w > 0 (multiplicative task reward), and
-    the shipped motion-generator layout with the replan timer behind the target columns.  Device: the fused launch + obs_aux, the row
+    global_root_height_obs, enable_tar_obs / use_contact_info off, track_root_h off, rel_task_w > 0 (multiplicative task reward), the
+    shipped motion-generator layout with the replan timer behind the target columns, global_obs (the row in world axes) and
+    track_root off (root error / velocities / key bodies in each character's own heading frame; termination without the root checks:
+    compute_done, mgdm_dm_util.py:392-460).  Device: the fused launch + obs_aux, the row
     gather parc_assemble_obs, the reward flags of parc_track_cfg_t, the one multiply of rel_task_w."""
     import json
     from parc_amd import _hip
     g = golden("g26_obs_variants")
     table = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g26_obs_variants.json")))["variants"][tag]
     over = {k: v for k, v in table["config"].items() if not k.startswith("_") and k != "enable_replan_timer_obs"}
+    if not over.get("track_root", True):
+        over.update(pose_termination=True, enable_early_termination=True, episode_length=10.0)       # what the fixture's compute_done was given
     core, z = _core_from_golden(km, mlib, **over)
     replan = tag == "mgdm_shipped"
     core.target_xy[:] = T(g["target_xy"])
@@ -255,6 +259,10 @@ def test_g26_observation_and_reward_variants(km, mlib, tag):
         o += w
     assert o == got.shape[1]
     close(core.reward, g[tag + "_reward"], atol=2e-6)
+    if tag + "_done" in g.files:           # RefCharEnv's flags before the motion-end override (dm_env.py:746-783 turns a clip's end into FAIL)
+        end = z["motion_end"].astype(bool)
+        np.testing.assert_array_equal(core.done.cpu().numpy()[~end], g[tag + "_done"][~end])
+        assert int((g[tag + "_done"] != z["done_nocontact"]).sum()) >= 1                              # the root checks did matter in G6
     for i, k in enumerate(("pose_r", "vel_r", "root_pos_r", "root_vel_r", "key_pos_r", "contact_penalty", "task_r1", "task_r2", "total_task_r")):
         if tag + "_r_" + k in g.files:
             close(core.reward_terms[i], g[tag + "_r_" + k], atol=2e-6)

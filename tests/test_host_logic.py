@@ -82,7 +82,7 @@ def test_g26_observation_layouts_and_the_shipped_configs():
         shapes, cols = cfg.obs_layout(tag == "mgdm_shipped")
         assert [[k, v["use_normalizer"], list(v["shape"])] for k, v in shapes.items()] == table["obs_shapes"], tag
         width = sum(int(np.prod(r[2])) for r in table["obs_shapes"])
-        assert width == table["obs_dim"] and (cols is None) == (tag in ("default", "no_root_h_tracking", "task_product"))
+        assert width == table["obs_dim"] and (cols is None) == (tag in ("default", "no_root_h_tracking", "task_product", "no_root_tracking", "no_root_tracking_at_all"))
         if cols is not None:
             assert len(cols) == width and max(cols) < cfg.obs_dim + 5
             virt = np.arange(cfg.obs_dim + 5)              # a numbered virtual row: [fused row | root_h, tx, ty, 0 | clock]
@@ -105,10 +105,9 @@ def test_g26_observation_layouts_and_the_shipped_configs():
             assert len(cols) == 1315 == g["variants"]["mgdm_shipped"]["obs_dim"]
         else:
             assert cols is None and cfg.obs_dim == 1312
-    with pytest.raises(NotImplementedError):
-        TrackerConfig(dict(default_env_config()["env"], global_obs=True), km, 441)
-    with pytest.raises(NotImplementedError):
-        TrackerConfig(dict(default_env_config()["env"], track_root=False), km, 441)
+    # every switch of the env configuration is accepted (global_obs / track_root off are kernel flags since round 4)
+    both = TrackerConfig(dict(default_env_config()["env"], global_obs=True, track_root=False), km, 441)
+    assert both.struct.global_obs == 1 and both.struct.track_root == 0
 
 
 def test_mjcf_parser_matches_reference_parse():
