@@ -188,6 +188,10 @@ class IGParkourEnv(base_env.BaseEnv):
         # a configuration with other segments (has_target_xy_obs, global_root_height_obs, enable_tar_obs / use_contact_info off, the
         # replan timer of a generator sub-env: ig_parkour_env.py:1163-1239) hands out a buffer of its own that one gather launch
         # (parc_assemble_obs) fills from the fused rows, the per-env extras and the plan clock.
+        # state of the env's own random generator (step_randoms): [step counter, ticket] and the policy-noise buffer it fills
+        self._rng_seed = None
+        self._rng_state = torch.zeros(2, dtype=torch.int64, device=self._device)
+        self._action_noise = torch.empty((N, self._cfg.dof_size), dtype=torch.float32, device=self._device)
         self._obs_shapes, cols = self._cfg.obs_layout(self._enable_replan_timer_obs)
         self._obs_cols = None if cols is None else torch.tensor(cols, dtype=torch.int32, device=self._device)
         self._obs_buf = c.obs if cols is None else torch.zeros((N, len(cols)), dtype=torch.float32, device=self._device)
@@ -222,14 +226,12 @@ class IGParkourEnv(base_env.BaseEnv):
         restart sampling) that the step() which follows consumes (the key is drawn from torch's host generator at the first call) - instead of two launches of torch's generator, which inside a replayed
         hipGraph also cost two fills of its seed / offset cells per replay."""
         c = self._core
-        if getattr(self, "_rng_state", None) is None:
+        if self._rng_seed is None:
             # the key comes out of torch's (host) generator at the first call: torch.manual_seed() fixes it like it fixes torch's own
-            # draws, and two envs of one process get different keys
+            # draws, and two envs of one process get different keys.  (A host-side draw: the device cells - step counter, noise buffer -
+            # exist since construction, so a first call inside a hipGraph capture allocates and fills nothing that a replay would repeat.)
             self._rng_seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-            self._rng_state = torch.zeros(2, dtype=torch.int64, device=self._device)
-            self._action_noise = None
-        if self._action_noise is None or self._action_noise.shape[1] != action_dim:
-            self._action_noise = torch.empty((self._num_envs, action_dim), dtype=torch.float32, device=self._device)
+        assert action_dim == self._action_noise.shape[1]
         # tick = (device int64 cell, modulus): the caller's per-step counter (the experience buffer's write row), moved on by this launch
         cell, mod = (None, 0) if tick is None else tick
         _hip.check(_hip.lib().parc_rng_step(_hip.stream(), self._rng_seed, _hip.ptr(self._rng_state), _hip.ptr(c.rand_pool), c.rand_pool.numel(),

@@ -496,6 +496,18 @@ def test_graph_rollout_writes_the_same_rows_as_the_eager_rollout():
         assert torch.equal(obs[1:][keep], nxt[:-1][keep])
         assert torch.equal(eb.get_data("prev_char_contact_forces")[1:][keep], eb.get_data("next_char_contact_forces")[:-1][keep])
         assert (eb.get_data("rand_action_mask") == 1.0).all() and torch.isfinite(eb.get_data("action")).all()
+    # the env's generator moved on by one per step (a cell allocated inside the capture would be re-zeroed by every replay): 24 steps,
+    # and no two steps drew the same policy noise
+    assert env._rng_state.tolist() == [3 * agent._steps_per_iter - 2, 0]          # (the first two steps of all ran eagerly, on torch's generator)
+    with torch.no_grad():
+        z_ = []
+        for t_ in range(agent._steps_per_iter):
+            dist = agent._model.eval_actor(agent._obs_norm.normalize(obs[t_].contiguous()))
+            z_.append((agent._a_norm.normalize(eb.get_data("action")[t_]) - dist.mean) / dist.logstd.exp())
+        z_ = torch.stack(z_)                                   # [T, N, A] ~ N(0, 1), the noise the head was given
+        assert abs(float(z_.mean())) < 0.02 and abs(float(z_.var()) - 1.0) < 0.05
+        for t_ in range(1, agent._steps_per_iter):
+            assert (z_[t_] - z_[t_ - 1]).abs().max() > 0.5
     # ... and the stored log-probability is the (unchanged) policy's for the stored action on the stored observation
     with torch.no_grad():
         for t_ in (0, 5, 7):
