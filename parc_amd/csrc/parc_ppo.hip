@@ -422,54 +422,37 @@ extern "C" int parc_rng_step(void *stream, uint64_t seed, uint64_t *state, float
 
 __device__ __forceinline__ float lerp_torch(float a, float b, float w) { return w < 0.5f ? a + w * (b - a) : b - (b - a) * (1.0f - w); }
 
-// ONE workgroup of 1024 threads, envs strided over the threads: every sum is folded inside the workgroup in a fixed order (thread's envs
-// in env order -> wave shuffle -> 16 wave rows in wave order), so the result does not depend on scheduling and nothing has to cross
-// workgroups.  (Until round 3: one env per thread, 16 workgroups, partial rows parked in global memory and folded by the last workgroup
-// to take a ticket - the device-scope fence that hand-over needs made a 180 KB pass take 13.6 us.)
+// Two launches: (1) one env per thread, ceil(N / 256) workgroups, each parks the sums of its finished envs in the workspace (folded in a
+// fixed order: wave shuffle, then the four wave rows); (2) one small workgroup adds the workgroups' rows in workgroup order and updates
+// the running means.  The result does not depend on scheduling.  (Round 1-3: one launch, the last workgroup to take a ticket did step
+// 2 - the device-scope fences of that hand-over made it 13.6 us; one workgroup of 1024 threads over all envs - round 4, tried - 20-23 us:
+// 180 KB through one CU.)
 #undef TRK_THREADS
-#define TRK_THREADS 1024
+#define TRK_THREADS 256
 __global__ __launch_bounds__(TRK_THREADS) void return_tracker_kernel(int n_envs, int K, const float *__restrict__ rewards, int64_t reward_stride,
                                                                      const int32_t *__restrict__ done, float *return_buf, int64_t *ep_len,
-                                                                     int64_t *eps_per_env, float *mean_return, float *mean_ep_len, double *episodes) {
+                                                                     int64_t *eps_per_env, float *__restrict__ part) {
     __shared__ float s_part[TRK_THREADS / 64][TRK_SLOTS];
-    __shared__ float s_tot[TRK_SLOTS];
     const int tid = threadIdx.x;
+    const int e = blockIdx.x * TRK_THREADS + tid;
     float acc[TRK_SLOTS];
 #pragma unroll
     for (int k = 0; k < TRK_SLOTS; ++k) acc[k] = 0.f;
-    // 4 envs per thread and pass: all their loads are issued before anything is stored (the buffers are read and written through the
-    // same pointers, so a one-env loop serialises load - store - load: 20 us for 180 KB)
-    for (int e0 = tid; e0 < n_envs; e0 += 4 * TRK_THREADS) {
-        bool fin[4];
-        int64_t len[4];
-        float v[4][TRK_MAX_K];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * TRK_THREADS;
-            const bool in = e < n_envs;
-            const int ec = in ? e : e0;
-            fin[u] = in && done[ec] != 0;
-            len[u] = ep_len[ec] + 1;
-#pragma unroll
-            for (int k = 0; k < TRK_MAX_K; ++k)
-                v[u][k] = k < K ? return_buf[(size_t)k * n_envs + ec] + rewards[(size_t)k * reward_stride + ec] : 0.f;
+    if (e < n_envs) {
+        const bool fin = done[e] != 0;
+        const int64_t len = ep_len[e] + 1;
+        if (fin) {
+            acc[TRK_MAX_K] = (float)len;
+            acc[TRK_MAX_K + 1] = 1.0f;
+            eps_per_env[e] += 1;
         }
+        ep_len[e] = fin ? 0 : len;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = e0 + u * TRK_THREADS;
-            if (e >= n_envs) continue;
-            if (fin[u]) {
-                acc[TRK_MAX_K] += (float)len[u];
-                acc[TRK_MAX_K + 1] += 1.0f;
-                eps_per_env[e] += 1;
-            }
-            ep_len[e] = fin[u] ? 0 : len[u];
-#pragma unroll
-            for (int k = 0; k < TRK_MAX_K; ++k) {
-                if (k < K) {
-                    if (fin[u]) acc[k] += v[u][k];
-                    return_buf[(size_t)k * n_envs + e] = fin[u] ? 0.f : v[u][k];
-                }
+        for (int k = 0; k < TRK_MAX_K; ++k) {
+            if (k < K) {
+                const float v = return_buf[(size_t)k * n_envs + e] + rewards[(size_t)k * reward_stride + e];
+                if (fin) acc[k] = v;
+                return_buf[(size_t)k * n_envs + e] = fin ? 0.f : v;
             }
         }
     }
@@ -483,6 +466,17 @@ __global__ __launch_bounds__(TRK_THREADS) void return_tracker_kernel(int n_envs,
     if (tid < TRK_SLOTS) {
         float v = 0.f;
         for (int w = 0; w < TRK_THREADS / 64; ++w) v += s_part[w][tid];
+        part[(size_t)blockIdx.x * TRK_SLOTS + tid] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void return_tracker_fold_kernel(int groups, int K, const float *__restrict__ part, float *mean_return,
+                                                                 float *mean_ep_len, double *episodes) {
+    __shared__ float s_tot[TRK_SLOTS];
+    const int tid = threadIdx.x;
+    if (tid < TRK_SLOTS) {
+        float v = 0.f;
+        for (int g = 0; g < groups; ++g) v += part[(size_t)g * TRK_SLOTS + tid];
         s_tot[tid] = v;
     }
     __syncthreads();
@@ -500,16 +494,17 @@ __global__ __launch_bounds__(TRK_THREADS) void return_tracker_kernel(int n_envs,
 
 extern "C" int64_t parc_return_tracker_workspace_floats(int n_envs) {
     if (n_envs <= 0) return -1;
-    return 4;          // (nothing is parked in it any more)
+    return (int64_t)((n_envs + TRK_THREADS - 1) / TRK_THREADS) * TRK_SLOTS + 4;
 }
 
 extern "C" int parc_return_tracker_update(void *stream, int n_envs, int K, const float *rewards, int64_t reward_stride, const int32_t *done,
                                           float *return_buf, int64_t *ep_len, int64_t *eps_per_env, float *mean_return, float *mean_ep_len,
                                           double *episodes, float *workspace) {
-    if (n_envs <= 0 || K <= 0 || K > TRK_MAX_K || reward_stride < n_envs) return PARC_EINVAL;
-    (void)workspace;          // (unused since round 4: nothing crosses workgroups any more; kept in the signature)
-    hipLaunchKernelGGL(return_tracker_kernel, dim3(1), dim3(TRK_THREADS), 0, (hipStream_t)stream, n_envs, K, rewards, reward_stride, done, return_buf,
-                       ep_len, eps_per_env, mean_return, mean_ep_len, episodes);
+    if (n_envs <= 0 || K <= 0 || K > TRK_MAX_K || reward_stride < n_envs || !workspace) return PARC_EINVAL;
+    const int groups = (n_envs + TRK_THREADS - 1) / TRK_THREADS;
+    hipLaunchKernelGGL(return_tracker_kernel, dim3(groups), dim3(TRK_THREADS), 0, (hipStream_t)stream, n_envs, K, rewards, reward_stride, done,
+                       return_buf, ep_len, eps_per_env, workspace);
+    hipLaunchKernelGGL(return_tracker_fold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, groups, K, workspace, mean_return, mean_ep_len, episodes);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PARC_OK : (int)e;
 }
