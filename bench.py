@@ -427,7 +427,10 @@ def main():
         c.root_state.copy_(state[0])
         c.dof_state.copy_(state[1])
         extra.append({"kernel": "sim_step_bpl_kernel (articulated-body step, {} substeps)".format(env._sim_steps * env._substeps), "envs": N,
-                      "us_per_launch": us, "bound": "instruction latency (serial tree sweeps); state traffic 1624 B/env",
+                      "us_per_launch": us, "us_per_launch_is": "20 launches replayed in one graph from the end-of-bench state with zero actions "
+                                                               "(contact-rich: slower than in the rollout)",
+                      "us_per_launch_in_rollout": prof["sim_step_us_mean"] if prof else None,
+                      "bound": "instruction issue (one 256-VGPR wave per SIMD, VALU active 48 % of cycles); state traffic 1624 B/env",
                       "achieved_GBps": N * 1624 / us / 1e3})
         # the update phase is fp32 GEMMs (81 % of the iteration): the two largest shapes of a PPO minibatch against the dense fp32 MFMA peak
         mb = agent._batch_size * N
