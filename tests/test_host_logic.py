@@ -155,13 +155,10 @@ def test_tracker_config_observation_layout():
     np.testing.assert_allclose(list(cfg.struct.dof_err_w)[:28], z["dof_err_w"], atol=0)
     assert list(cfg.struct.key_body_ids)[:4] == list(z["key_body_ids"])
     np.testing.assert_allclose(list(cfg.struct.tar_dt), z["tar_obs_steps"].astype(np.float32) * np.float32(1 / 30.0), rtol=1e-6)
-    bad = default_env_config()["env"]
-    bad["global_obs"] = True
-    try:
-        TrackerConfig(bad, km, 441)
-        assert False, "unsupported config must raise"
-    except NotImplementedError:
-        pass
+    # (until round 3 global_obs raised NotImplementedError; every switch of the env YAML is a kernel flag or a column layout since round 4)
+    world = default_env_config()["env"]
+    world["global_obs"] = True
+    assert TrackerConfig(world, km, 441).struct.global_obs == 1 and cfg.struct.global_obs == 0
 
 
 def test_safe_motion_reader_roundtrip(tmp_path):
