@@ -120,15 +120,19 @@ struct ContactEval {
 };
 
 // one sample sphere of this lane's body: the same arithmetic as pass1 / report_contacts of the reference core
-__device__ __forceinline__ ContactEval eval_contact(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_off, const Kin &k, int s, float h) {
+// the heightfield cells under sample sphere s of this lane's body (loads only)
+__device__ __forceinline__ ColumnSample sample_sphere(const parc_sim_model_t &m, const parc_terrain_t &ter, V3 env_off, const Kin &k, int s) {
+    return sample_columns(ter, k.P + mul(k.R, ld(m.sph_pos[s])) + env_off);
+}
+
+__device__ __forceinline__ ContactEval eval_contact(const parc_sim_model_t &m, const parc_terrain_t &ter, const ColumnSample &cs, const Kin &k, int s, float h) {
     ContactEval ce;
     ce.hit = false;
     V3 rb = ld(m.sph_pos[s]);
     const float rad = m.sph_radius[s];
-    V3 pw = k.P + mul(k.R, rb);
     float depth;
     V3 n;
-    if (!sphere_vs_columns(ter, pw + env_off, rad, depth, n)) return ce;
+    if (!columns_contact(ter, cs, rad, depth, n)) return ce;
     ce.nb = mulT(k.R, n);
     ce.rc = rb - rad * ce.nb;
     V3 vpb = k.v.l + cross(k.v.a, ce.rc);
@@ -214,9 +218,17 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
         __syncthreads();                     // the exchange buffer is reused by the inward sweep
     }
     // ---- contacts of this body's sample spheres: implicit spring-damper + regularised friction
-    for (unsigned long long mm = valid ? L.sph : 0ull; mm; mm &= mm - 1) {
+    // (software-pipelined by one: the heights under the NEXT sphere are loading while this one is evaluated - a foot lane walks 8 spheres
+    // and each used to wait for its own loads)
+    unsigned long long mm = valid ? L.sph : 0ull;
+    ColumnSample cs_next;
+    if (mm) cs_next = sample_sphere(m, ter, env_off, k, __ffsll((long long)mm) - 1);
+    for (; mm; mm &= mm - 1) {
         const int s = __ffsll((long long)mm) - 1;
-        ContactEval ce = eval_contact(m, ter, env_off, k, s, h);
+        const ColumnSample cs = cs_next;
+        const unsigned long long rest = mm & (mm - 1);
+        if (rest) cs_next = sample_sphere(m, ter, env_off, k, __ffsll((long long)rest) - 1);
+        ContactEval ce = eval_contact(m, ter, cs, k, s, h);
         if (!ce.hit) continue;
         if (n_hit < BPL_CC_SLOTS) {
             float *o = cc + n_hit * BPL_CC_FLOATS;
@@ -396,7 +408,8 @@ __device__ __forceinline__ void substep(const parc_sim_model_t &m, const parc_te
             Fb = Fb + F;
         }
         for (unsigned long long mm = overflow; mm; mm &= mm - 1) {      // more simultaneous contacts than slots: re-evaluate
-            ContactEval ce = eval_contact(m, ter, env_off, k, __ffsll((long long)mm) - 1, h);
+            const int so = __ffsll((long long)mm) - 1;
+            ContactEval ce = eval_contact(m, ter, sample_sphere(m, ter, env_off, k, so), k, so, h);
             V3 dv = h * (a.l + cross(a.a, ce.rc));
             float dvn = dot(dv, ce.nb);
             V3 F = ce.F0 - (ce.cn + h * m.contact_kn) * dvn * ce.nb - ce.ct * (dv - dvn * ce.nb);

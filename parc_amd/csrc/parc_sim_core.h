@@ -265,17 +265,42 @@ PARC_HD float terrain_h(const parc_terrain_t &t, int i, int j) {
     return t.hf[i * t.dim_y + j];
 }
 
-// One sample sphere (centre p in GLOBAL xy / env z, radius rho) against the column field.  Returns the deepest
-// contact: penetration depth (>0), unit normal n.
-PARC_HD bool sphere_vs_columns(const parc_terrain_t &t, V3 p, float rho, float &depth, V3 &n) {
+// One sample sphere (centre p in GLOBAL xy / env z, radius rho) against the column field, in two halves so that a caller can have the
+// loads of the NEXT sphere in flight while it evaluates this one (parc_sim_bpl.h): sample_columns = cell indices + the four heights the
+// evaluation needs (the own column and the three neighbours on the sphere's side, loaded together: four independent loads instead of up
+// to four dependent round trips), columns_contact = the deepest contact from them: penetration depth (> 0), unit normal n.
+struct ColumnSample {
+    V3 p;
+    int ci, cj, si, sj;
+    float fx, fy;          // offset from the cell centre in cell units, [-0.5, 0.5]
+    float h0, hnb[3];
+};
+
+PARC_HD ColumnSample sample_columns(const parc_terrain_t &t, V3 p) {
+    ColumnSample c;
+    c.p = p;
     float u = (p.x - t.min_x) * p_rcp(t.dx), w = (p.y - t.min_y) * p_rcp(t.dy);
-    int ci = (int)floorf(u + 0.5f), cj = (int)floorf(w + 0.5f);
-    float h0 = terrain_h(t, ci, cj);
+    c.ci = (int)floorf(u + 0.5f);
+    c.cj = (int)floorf(w + 0.5f);
+    c.fx = u - (float)c.ci;
+    c.fy = w - (float)c.cj;
+    c.si = c.fx >= 0.f ? 1 : -1;
+    c.sj = c.fy >= 0.f ? 1 : -1;
+    c.h0 = terrain_h(t, c.ci, c.cj);
+    c.hnb[0] = terrain_h(t, c.ci + c.si, c.cj);
+    c.hnb[1] = terrain_h(t, c.ci, c.cj + c.sj);
+    c.hnb[2] = terrain_h(t, c.ci + c.si, c.cj + c.sj);
+    return c;
+}
+
+PARC_HD bool columns_contact(const parc_terrain_t &t, const ColumnSample &c, float rho, float &depth, V3 &n) {
+    const V3 p = c.p;
+    const int ci = c.ci, cj = c.cj, si = c.si, sj = c.sj;
+    const float fx = c.fx, fy = c.fy, h0 = c.h0;
     bool hit = false;
     depth = 0.f;
     n = v3(0.f, 0.f, 1.f);
     // own column
-    float fx = u - (float)ci, fy = w - (float)cj;   // offset from the cell centre in cell units, [-0.5, 0.5]
     if (p.z - rho < h0) {
         float d_up = h0 - p.z + rho;
         float best = d_up;
@@ -294,11 +319,10 @@ PARC_HD bool sphere_vs_columns(const parc_terrain_t &t, V3 p, float rho, float &
     }
     if (rho > 0.f) {
         // higher neighbours within reach: closest point on the neighbour's box (side face or top edge)
-        int si = fx >= 0.f ? 1 : -1, sj = fy >= 0.f ? 1 : -1;
         PARC_LOOP(13)
         for (int k = 0; k < 3; ++k) {
             int di = (k == 1) ? 0 : si, dj = (k == 0) ? 0 : sj;
-            float hn = terrain_h(t, ci + di, cj + dj);
+            float hn = c.hnb[k];
             if (hn <= h0 + 1e-3f) continue;
             // neighbour footprint relative to p (metres)
             float gx = di == 0 ? 0.f : ((0.5f - fabsf(fx)) * t.dx);   // distance to the shared face along x
@@ -321,6 +345,10 @@ PARC_HD bool sphere_vs_columns(const parc_terrain_t &t, V3 p, float rho, float &
         }
     }
     return hit;
+}
+
+PARC_HD bool sphere_vs_columns(const parc_terrain_t &t, V3 p, float rho, float &depth, V3 &n) {
+    return columns_contact(t, sample_columns(t, p), rho, depth, n);
 }
 
 PARC_HD float clampf01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
