@@ -102,6 +102,15 @@ def test_bench_two_ranks_from_a_plain_invocation():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
     assert abs(line["value"] - 2 * 64 * 32 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    assert line["scaling"] == "weak" and line["config"]["rollout_steps"] == 32 and line["config"]["minibatch"] == 4 * 64
+    # the reference's own scaling rule (base_agent.py:179-180, ppo_agent.py:27-29): half the rollout and half the minibatch per rank at P = 2,
+    # the gradient exchanged through the bucketed all-reduce on every one of the 5 x 8 optimizer steps
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--envs", "64", "--steps", "1", "--warmup", "1",
+                          "--scaling", "reference"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["rollout_steps"] == 16 and line["config"]["minibatch"] == 2 * 64
+    assert abs(line["value"] - 2 * 64 * 16 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
     if torch.cuda.device_count() < 8:
         env.pop("PARC_DIST_BACKEND")
         bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--envs", "64", "--steps", "1"],
