@@ -19,7 +19,17 @@ __global__ __launch_bounds__(64) void sim_step_bpl_kernel(const parc_sim_model_t
     __shared__ float ccache[64][BPL_CC_SLOTS * BPL_CC_FLOATS + 1];     // +1: odd row stride against bank conflicts
     const int g = threadIdx.x / BPL_G, b = threadIdx.x % BPL_G;
     const int e = min((int)blockIdx.x * BPL_EPB + g, n_envs - 1);      // tail groups recompute the last env (same values)
-    const parc_sim_model_t &m = *model;
+    // the model (4.9 KB of per-body / per-dof / per-sphere constants, read ~70 times per lane and substep) staged in LDS once per
+    // workgroup: 100.9 -> 97.2 us per 4096-env step (profiles/r04_sim_step_variants.txt)
+    __shared__ parc_sim_model_t s_model;
+    {
+        static_assert(sizeof(parc_sim_model_t) % 4 == 0, "copied as 32-bit words");
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(model);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&s_model);
+        for (unsigned i = threadIdx.x; i < sizeof(parc_sim_model_t) / 4; i += 64) dst[i] = src[i];
+        __syncthreads();
+    }
+    const parc_sim_model_t &m = s_model;
     const int B = m.num_bodies, D = m.dof_size;
     step_lane(m, ter, b, root_state + 13 * (size_t)e, dof_state + 2 * (size_t)D * e, rigid_body_state + 13 * (size_t)B * e,
               contact_forces + 3 * (size_t)B * e, env_offsets + 3 * (size_t)e, action + (size_t)D * e, act_lo, act_hi, n_sub, h, lds[g],
