@@ -312,7 +312,9 @@ __global__ __launch_bounds__(256) void record_step_kernel(int n_envs, const int6
     char *d = (char *)f.dst + h * total;
     const char *s = (const char *)f.src;
     if (((total | (uintptr_t)d | (uintptr_t)s) & 15) == 0) {
-        for (size_t i = tid; i < total / 16; i += nthr) ((uint4 *)d)[i] = ((const uint4 *)s)[i];
+        // (the buffer row is not read again before the update phase: streamed stores)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        for (size_t i = tid; i < total / 16; i += nthr) __builtin_nontemporal_store(((const u32x4 *)s)[i], (u32x4 *)d + i);
     } else {
         for (size_t i = tid; i < total / 4; i += nthr) ((uint32_t *)d)[i] = ((const uint32_t *)s)[i];
     }
