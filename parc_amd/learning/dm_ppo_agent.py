@@ -380,14 +380,13 @@ class DMPPOAgent(torch.nn.Module):
             try:
                 next_obs, r, done, next_info = self._env.step(action)
             finally:
-                tail_forked = getattr(self._env, "_tail_forked", False)     # (a mixed env steps its sub-envs on the main stream)
                 self._env.set_tail_stream(None)
             s_trk.wait_stream(main)
             with torch.cuda.stream(s_trk):
                 self._train_return_tracker.update(next_info, done)
             self._record_data_post_step(next_obs, r, done, next_info)
             main.wait_stream(s_trk)
-            if tail_forked:
+            if getattr(self._env, "_tail_forked", False):          # (a mixed env steps its sub-envs on the main stream)
                 main.wait_stream(s_tail)
         else:
             next_obs, r, done, next_info = self._env.step(action)
