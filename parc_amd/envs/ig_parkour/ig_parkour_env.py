@@ -239,13 +239,6 @@ class IGParkourEnv(base_env.BaseEnv):
         c.rand_pool_prefilled = True
         return self._action_noise
 
-    def set_tail_stream(self, stream):
-        """a side HIP stream for the step's tail launch (fail-rate update + reference state), or None: step() then forks that launch
-        behind the post-step launch and the CALLER joins it (current_stream().wait_stream(stream)) before the next reset / step.
-        Only the pure tracker step (all rows on dataset clips) honours it."""
-        self._tail_stream = stream
-        self._tail_forked = False
-
     def _draw_step_uniforms(self):
         """the uniform pool of this step: already drawn together with the policy's noise (step_randoms), or one torch launch"""
         c = self._core
@@ -566,16 +559,7 @@ class IGParkourEnv(base_env.BaseEnv):
         self._draw_step_uniforms()      # all uniforms of this step and of the restarts that follow it (tracker_core.rand_pool)
         # (the reference STATE - ref_* buffers - rides in the fail-rate launch below: nothing in the fused launch reads it)
         c.post_step(_hip.POST_OBS | _hip.POST_REWARD_DONE | _hip.POST_HF | _hip.POST_TARGETS)
-        tail = getattr(self, "_tail_stream", None)
-        self._tail_forked = tail is not None
-        if tail is None:
-            c.step_tail(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight)
-        else:
-            # the caller forks the tail onto a side stream (set_tail_stream) and joins it before anything reads the fail rates or
-            # the reference state again: nothing else of the step does
-            tail.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(tail):
-                c.step_tail(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight)
+        c.step_tail(self._dm_env._motion_id_fail_rates, self._dm_env._ema_weight)
         self._finish_reward()
         self._publish_obs()
         if self._never_done:

@@ -88,7 +88,6 @@ class DMPPOAgent(torch.nn.Module):
         self._exp_prob_t = torch.ones([1, 1], dtype=torch.float32, device=self._device)
         self._head_t = torch.zeros([1], dtype=torch.int64, device=self._device)
         self._head_dev, self._exp_prob_dev = 0, 1.0      # what those two device cells hold (host mirror)
-        self._side_streams = None                        # two side HIP streams of the captured step (parallel branches behind the post-step launch)
         self._compute_times = []                         # (row, seconds) of the steps of this rollout, written in one go at its end
         self._replan_time_rows, self._replan_time_src = None, None
         self._ones_mask = None
@@ -368,30 +367,9 @@ class DMPPOAgent(torch.nn.Module):
             self._step_noise = self._env.step_randoms(self.get_action_size(), tick=(self._head_t, self._exp_buffer._buffer_length))
         action, action_info = self._decide_action(self._curr_obs, self._curr_info)
         self._record_data_pre_step(self._curr_obs, self._curr_info, action, action_info)
-        if getattr(self, "_in_graph_step", False) and self._config.get("overlap_step_tail", True) and hasattr(self._env, "set_tail_stream"):
-            # captured step: what follows the post-step launch - the env's step tail (fail rates + reference state), the return
-            # tracker and the record of the step's results - are three small, latency-bound, mutually independent pieces: they run as
-            # parallel branches of the graph (side HIP streams forked behind the post-step launch, joined in front of the restart)
-            if self._side_streams is None:
-                self._side_streams = (torch.cuda.Stream(device=self._device), torch.cuda.Stream(device=self._device))
-            s_tail, s_trk = self._side_streams
-            main = torch.cuda.current_stream()
-            self._env.set_tail_stream(s_tail)
-            try:
-                next_obs, r, done, next_info = self._env.step(action)
-            finally:
-                self._env.set_tail_stream(None)
-            s_trk.wait_stream(main)
-            with torch.cuda.stream(s_trk):
-                self._train_return_tracker.update(next_info, done)
-            self._record_data_post_step(next_obs, r, done, next_info)
-            main.wait_stream(s_trk)
-            if getattr(self._env, "_tail_forked", False):          # (a mixed env steps its sub-envs on the main stream)
-                main.wait_stream(s_tail)
-        else:
-            next_obs, r, done, next_info = self._env.step(action)
-            self._train_return_tracker.update(next_info, done)
-            self._record_data_post_step(next_obs, r, done, next_info)
+        next_obs, r, done, next_info = self._env.step(action)
+        self._train_return_tracker.update(next_info, done)
+        self._record_data_post_step(next_obs, r, done, next_info)
         if device_reset:
             # finished envs restart on the device (masked kernels): no nonzero(), the step stays sync-free
             self._curr_obs, self._curr_info = self._env.reset_done(done)
