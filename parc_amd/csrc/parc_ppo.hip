@@ -690,7 +690,11 @@ __global__ __launch_bounds__(256) void obs_ingest_kernel(int rows, int dim4, con
             o.z = fminf(fmaxf((v.z - m.z) / sd.z, -clip), clip);
             o.w = fminf(fmaxf((v.w - m.w) / sd.w, -clip), clip);
             norm_out[i] = o;
-            if (dst) dst[i] = v;
+            if (dst) {                       // (the buffer row is not read again before the update phase: streamed store)
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                f32x4 vv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(dst) + i);
+            }
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
         }
