@@ -381,6 +381,17 @@ def main():
             torch.cuda.synchronize()
         return a.elapsed_time(b) * 1e3 / iters
 
+    # what a plain device copy reaches on this box (the nominal 8 TB/s next to the achievable figure): 1 GiB read + 1 GiB written
+    copy_gbps = None
+    if rank == 0:
+        try:
+            src_ = torch.empty(256 << 20, dtype=torch.float32, device=dev)
+            dst_ = torch.empty_like(src_)
+            us_c = time_launches(lambda: dst_.copy_(src_), 10)
+            copy_gbps = 2.0 * src_.numel() * 4 / us_c / 1e3
+            del src_, dst_
+        except Exception:           # noqa: BLE001
+            copy_gbps = None
     extra = []
     if rank == 0:
         # the other hand-written kernels of the step, same HIP-event timing (context for the roofline object)
@@ -486,6 +497,8 @@ def main():
                          "us_per_launch_by_events_min": float(np.min(in_rollout)) if in_rollout else None,
                          "us_per_launch_by_events_max": float(np.max(in_rollout)) if in_rollout else None,
                          "launches_event_timed": len(evs), "algorithmic_bytes_per_launch": alg_bytes,
+                         "peak_measured_device_copy_GBps": copy_gbps,
+                         "frac_of_measured_device_copy": (achieved / copy_gbps) if copy_gbps else None,
                          "frac_standalone": achieved_standalone / HBM_PEAK_GBPS, "us_per_launch_standalone": kern_graph_us,
                          "standalone_is": "200 identical launches replayed in one hipGraph: warm caches, nothing else on the chip "
                                           "(profiles/r04_post_step_boxes_64clips_kernel_stats.csv)",
