@@ -455,6 +455,14 @@ def main():
                           "bound": "mfma", "achieved_TFLOPs": tf, "peak_TFLOPs": MFMA_FP32_PEAK_TFLOPS, "frac_of_peak": tf / MFMA_FP32_PEAK_TFLOPS})
             del a_, w_, b_
 
+    replay_bound = None
+    try:
+        ml_ = env.get_dm_env()._motion_lib
+        w_ = ml_._motion_weights.double()
+        steps_ = torch.clamp(ml_._motion_lengths.double() * 0.5 / env._timestep, max=float(env._cfg.struct.episode_length) / env._timestep)
+        replay_bound = float((w_ * steps_).sum() / w_.sum())
+    except Exception:           # noqa: BLE001
+        replay_bound = None
     if rank == 0:
         total_env_steps = world * N * T * args.steps
         out = {
@@ -515,6 +523,10 @@ def main():
             "rollout_env_steps_per_s": world * N * T * args.steps / max(rollout_s[0], 1e-9),
             "rollout_fraction_of_time": rollout_s[0] / elapsed,
             "mean_episode_return": info["mean_return"] if info else None,
+            # the return is reported absolute (no Isaac Gym run exists to compare with), next to the kinematic-replay upper
+            # bound: a character that sits on the reference pose earns reward 1 per step (tests/test_env_gpu.py::
+            # test_kinematic_replay_reward_upper_bound) from its uniformly drawn start phase to the end of its clip
+            "mean_episode_return_kinematic_upper_bound": replay_bound,
             "mean_episode_length": info["mean_ep_len"] if info else None,
         }
         if not args.no_cpu_baseline and world == 1:       # (the CPU leg is a single-GPU datum: rank 0 at N=1 only)
