@@ -198,34 +198,58 @@ def refresh_ray_obs_hfs(ray_xy, root_pos, heading, hf, min_point, dxdy, min_h=-3
     return out
 
 
+def obs_width(mlib, S, K, P, global_root_height_obs=False, enable_tar_obs=True, use_contact_info=True, has_target_xy_obs=False,
+              replan_timer=False):
+    """columns of IGParkourEnv._compute_obs's row for one setting of its switches (ig_parkour_env.py:1150-1244)"""
+    J, D, B = mlib.J, mlib.D, mlib.B
+    w = int(global_root_height_obs) + (12 + 6 * J + D + 3 * K) + P
+    if enable_tar_obs:
+        w += S * (9 + 6 * J + 3 * K)
+    if use_contact_info:
+        w += B + (S * B if enable_tar_obs else 0)
+    return w + 2 * int(has_target_xy_obs) + int(replan_timer)
+
+
 def compute_obs(char, mlib, tar_steps_dt, key_body_ids, motion_ids, motion_times, motion_xy_offset, char_root_pos,
                 char_root_rot, char_root_vel, char_root_ang_vel, char_dof_pos, char_dof_vel, contact_forces, ray_hfs,
-                contact_eps=1e-5):
+                contact_eps=1e-5, global_obs=False, global_root_height_obs=False, enable_tar_obs=True, use_contact_info=True,
+                target_xy=None, replan_t=None):
+    """target_xy [N,2] = has_target_xy_obs; replan_t (a float) = enable_replan_timer_obs on an env with motion-generator rows"""
     N = char_root_pos.shape[0]
     S = len(tar_steps_dt); K = len(key_body_ids); P = ray_hfs.shape[1]
-    J, D, B = mlib.J, mlib.D, mlib.B
-    obs_dim = (12 + 6 * J + D + 3 * K) + S * (9 + 6 * J + 3 * K) + S * B + B + P
+    obs_dim = obs_width(mlib, S, K, P, global_root_height_obs, enable_tar_obs, use_contact_info, target_xy is not None, replan_t is not None)
     obs = np.zeros((N, obs_dim), np.float32)
     a = [_f(tar_steps_dt), _l(key_body_ids), _l(motion_ids), _f(motion_times), _f(motion_xy_offset), _f(char_root_pos),
          _f(char_root_rot), _f(char_root_vel), _f(char_root_ang_vel), _f(char_dof_pos), _f(char_dof_vel),
          _f(contact_forces), _f(ray_hfs)]
-    lib().orc_compute_obs(*char.args(), *mlib.args(), c_int(N), c_int(S), _p(a[0]), c_int(K), _p(a[1]), _p(a[2]), _p(a[3]),
-                          _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]), _p(a[8]), _p(a[9]), _p(a[10]), _p(a[11]), _p(a[12]),
-                          c_int(P), c_float(contact_eps), _p(obs), c_int(obs_dim))
+    txy = None if target_xy is None else _f(target_xy)
+    assert txy is None or txy.shape == (N, 2)
+    lib().orc_compute_obs_ex(*char.args(), *mlib.args(), c_int(N), c_int(S), _p(a[0]), c_int(K), _p(a[1]), _p(a[2]), _p(a[3]),
+                             _p(a[4]), _p(a[5]), _p(a[6]), _p(a[7]), _p(a[8]), _p(a[9]), _p(a[10]), _p(a[11]), _p(a[12]),
+                             c_int(P), c_float(contact_eps), c_int(bool(global_obs)), c_int(bool(global_root_height_obs)),
+                             c_int(bool(enable_tar_obs)), c_int(bool(use_contact_info)), None if txy is None else _p(txy),
+                             c_int(replan_t is not None), c_float(0.0 if replan_t is None else float(replan_t)), _p(obs), c_int(obs_dim))
     return obs
 
 
-def compute_reward(char, key_body_ids, st, ref, joint_err_w, dof_err_w, contact_w, w5, rel_dm_w=1.0):
+def compute_reward(char, key_body_ids, st, ref, joint_err_w, dof_err_w, contact_w, w5, rel_dm_w=1.0, track_root=True, track_root_h=True,
+                   use_contact_info=True, target_xy=None, task1_w=0.7, task2_w=0.3, target_radius=1.0, rel_task_w=0.0, all_terms=False):
+    """-> reward [N], terms [N,6] (pose, vel, root_pose, root_vel, key_pos, contact_penalty); all_terms: [N,9] with task_r1, task_r2 and
+    the total task reward behind them"""
     N = st["char_root_pos"].shape[0]
     K = len(key_body_ids)
-    reward = np.zeros(N, np.float32); terms = np.zeros((N, 6), np.float32)
+    reward = np.zeros(N, np.float32); terms = np.zeros((N, 9), np.float32)
     arrs = [_l(key_body_ids)] + [_f(st[k]) for k in ("char_root_pos", "char_root_rot", "char_root_vel", "char_root_ang_vel",
                                                       "char_dof_pos", "char_dof_vel", "char_rigid_body_pos")] + \
            [_f(ref[k]) for k in ("ref_root_pos", "ref_root_rot", "ref_root_vel", "ref_root_ang_vel", "ref_joint_rot",
                                  "ref_dof_vel", "ref_body_pos", "ref_contacts")] + \
            [_f(st["contact_forces"]), _f(joint_err_w), _f(dof_err_w), _f(contact_w), _f(w5)]
-    lib().orc_compute_reward(*char.args(), c_int(N), c_int(K), *[_p(x) for x in arrs], c_float(rel_dm_w), _p(reward), _p(terms))
-    return reward, terms
+    txy = None if target_xy is None else _f(target_xy)
+    assert txy is None or txy.shape == (N, 2)
+    lib().orc_compute_reward_ex(*char.args(), c_int(N), c_int(K), *[_p(x) for x in arrs], c_float(rel_dm_w), c_int(bool(track_root)),
+                                c_int(bool(track_root_h)), c_int(bool(use_contact_info)), None if txy is None else _p(txy),
+                                c_float(task1_w), c_float(task2_w), c_float(target_radius), c_float(rel_task_w), _p(reward), _p(terms))
+    return reward, (terms if all_terms else np.ascontiguousarray(terms[:, :6]))
 
 
 def update_done(time_buf, ep_len, char_root_rot, body_pos, ref_root_rot, ref_body_pos, contact_forces, contact_body_ids,

@@ -409,6 +409,8 @@ static void calc_motion_frame1(const orc_mlib_t *m, int64_t id, float time, floa
     const int *loop_mode, const float *pos_delta, const float *f_root_pos, const float *f_root_rot,                  \
     const float *f_joint_rot, const float *f_root_vel, const float *f_root_ang_vel, const float *f_dof_vel,          \
     const float *f_contacts
+#define MLIB_PASS M, J, D, B, num_frames, start_idx, length, loop_mode, pos_delta, f_root_pos, f_root_rot, f_joint_rot, f_root_vel, \
+    f_root_ang_vel, f_dof_vel, f_contacts
 #define MLIB_MAKE                                                                                                      \
     orc_mlib_t ml = {M, J, D, B, num_frames, start_idx, length, loop_mode, pos_delta, f_root_pos, f_root_rot,          \
                      f_joint_rot, f_root_vel, f_root_ang_vel, f_dof_vel, f_contacts}
@@ -512,27 +514,36 @@ void orc_refresh_ray_obs_hfs(int N, int P, const float *ray_xy, const float *roo
 
 /* ------------------------------------------------------------------ observations (a9) */
 
-/* envs/ig_char_env.py:582-626 with global_obs=False, root_height_obs=False; out[6+3+3+6J+D+3K] */
-static void char_obs1(int J, int D, int K, const float *root_pos, const float *root_rot, const float *root_vel,
+/* envs/ig_char_env.py:582-626 without the root-height column (the caller prepends it, :621-623); out[6+3+3+6J+D+3K].
+ * global_obs (:587-590,:605): root rotation / velocities and the key-body offsets stay in world axes. */
+static void char_obs1(int J, int D, int K, int global_obs, const float *root_pos, const float *root_rot, const float *root_vel,
                       const float *root_ang_vel, const float *joint_rot, const float *dof_vel, const float *key_pos,
                       float *o) {
     float h[4], lr[4];
     calc_heading_quat_inv(root_rot, h);
-    quat_mul(h, root_rot, lr);
-    quat_to_tan_norm(lr, o);
-    quat_rotate(h, root_vel, o + 6);
-    quat_rotate(h, root_ang_vel, o + 9);
+    if (global_obs) {
+        quat_to_tan_norm(root_rot, o);
+        for (int a = 0; a < 3; ++a) { o[6 + a] = root_vel[a]; o[9 + a] = root_ang_vel[a]; }
+    } else {
+        quat_mul(h, root_rot, lr);
+        quat_to_tan_norm(lr, o);
+        quat_rotate(h, root_vel, o + 6);
+        quat_rotate(h, root_ang_vel, o + 9);
+    }
     for (int j = 0; j < J; ++j) quat_to_tan_norm(joint_rot + 4 * j, o + 12 + 6 * j);
     for (int d = 0; d < D; ++d) o[12 + 6 * J + d] = dof_vel[d];
     for (int k = 0; k < K; ++k) {
         float rel[3] = {key_pos[3 * k] - root_pos[0], key_pos[3 * k + 1] - root_pos[1], key_pos[3 * k + 2] - root_pos[2]};
-        quat_rotate(h, rel, o + 12 + 6 * J + D + 3 * k);
+        float *ok = o + 12 + 6 * J + D + 3 * k;
+        if (global_obs) { ok[0] = rel[0]; ok[1] = rel[1]; ok[2] = rel[2]; }
+        else quat_rotate(h, rel, ok);
     }
 }
 
-/* envs/ig_parkour/mgdm_dm_util.py:462-519 with global_obs=False, global_tar_root_h_obs=False.
- * one env, S target steps; out [S, 3+6+6J+3K] */
-static void tar_obs1(int S, int J, int K, const float *ref_root_pos, const float *ref_root_rot, const float *tar_root_pos,
+/* envs/ig_parkour/mgdm_dm_util.py:462-519 with global_tar_root_h_obs=False (the only value its caller passes, :549).
+ * one env, S target steps; out [S, 3+6+6J+3K].  global_obs (:476): nothing is rotated and the key-body offsets stay relative to
+ * the TARGET root (the `+ root_pos_obs` of :497 sits inside the local branch). */
+static void tar_obs1(int S, int J, int K, int global_obs, const float *ref_root_pos, const float *ref_root_rot, const float *tar_root_pos,
                      const float *tar_root_rot, const float *tar_joint_rot, const float *tar_key_pos, float *o) {
     float h[4];
     calc_heading_quat_inv(ref_root_rot, h);
@@ -542,40 +553,54 @@ static void tar_obs1(int S, int J, int K, const float *ref_root_pos, const float
         const float *tp = tar_root_pos + 3 * s;
         float rp[3] = {tp[0] - ref_root_pos[0], tp[1] - ref_root_pos[1], tp[2] - ref_root_pos[2]};
         float rpo[3];
-        quat_rotate(h, rp, rpo);
-        os[0] = rpo[0]; os[1] = rpo[1]; os[2] = rpo[2];
         float tr[4];
-        quat_mul(h, tar_root_rot + 4 * s, tr);
+        if (global_obs) {
+            for (int a = 0; a < 3; ++a) rpo[a] = rp[a];
+            for (int a = 0; a < 4; ++a) tr[a] = tar_root_rot[4 * s + a];
+        } else {
+            quat_rotate(h, rp, rpo);
+            quat_mul(h, tar_root_rot + 4 * s, tr);
+        }
+        os[0] = rpo[0]; os[1] = rpo[1]; os[2] = rpo[2];
         quat_to_tan_norm(tr, os + 3);
         for (int j = 0; j < J; ++j) quat_to_tan_norm(tar_joint_rot + ((size_t)s * J + j) * 4, os + 9 + 6 * j);
         for (int k = 0; k < K; ++k) {
             const float *kp = tar_key_pos + ((size_t)s * K + k) * 3;
             float rel[3] = {kp[0] - tp[0], kp[1] - tp[1], kp[2] - tp[2]};
             float r[3];
-            quat_rotate(h, rel, r);
-            os[9 + 6 * J + 3 * k + 0] = r[0] + rpo[0];
-            os[9 + 6 * J + 3 * k + 1] = r[1] + rpo[1];
-            os[9 + 6 * J + 3 * k + 2] = r[2] + rpo[2];
+            if (global_obs) { r[0] = rel[0]; r[1] = rel[1]; r[2] = rel[2]; }
+            else {
+                quat_rotate(h, rel, r);
+                r[0] += rpo[0]; r[1] += rpo[1]; r[2] += rpo[2];
+            }
+            os[9 + 6 * J + 3 * k + 0] = r[0];
+            os[9 + 6 * J + 3 * k + 1] = r[1];
+            os[9 + 6 * J + 3 * k + 2] = r[2];
         }
     }
 }
 
 /*
- * Full observation row, IGParkourEnv._compute_obs envs/ig_parkour/ig_parkour_env.py:1054-1244 with the
- * default tracker config: [char_obs | tar_obs | tar_contacts | char_contacts | hf].
+ * Full observation row, IGParkourEnv._compute_obs envs/ig_parkour/ig_parkour_env.py:1054-1244, every switch of it:
+ *   [root_h]? char_obs | tar_obs? | tar_contacts? | char_contacts? | hf | target_xy? | replan_t?
+ * root_h: global_root_height_obs (ig_char_env.py:621-623).  tar_obs: enable_tar_obs (mgdm_dm_util.py:540).  tar_contacts:
+ * use_contact_info AND enable_tar_obs, char_contacts: use_contact_info (:1177-1186).  target_xy (NULL = has_target_xy_obs off): the
+ * offset to the target rotated by minus the heading with cos / sin (rotate_2d_vec torch_util.py:620-631), :1212-1223.  replan_t
+ * (has_replan_t: enable_replan_timer_obs on an env with motion-generator rows): one clock for every env (:1068-1069,:1225-1231).
  * Inputs are the simulator state (char_*), the clip database and the per-env motion bookkeeping.
  * motion_xy_offset[N,2] = motion_offsets[motion_id, terrain_id] - env_offset[:,0:2]  (dm_env.py:604-615).
  */
-void orc_compute_obs(CHAR_ARGS, MLIB_ARGS, int N, int S, const float *tar_steps_dt, int K, const int64_t *key_body_ids,
-                     const int64_t *motion_ids, const float *motion_times, const float *motion_xy_offset,
-                     const float *char_root_pos, const float *char_root_rot, const float *char_root_vel,
-                     const float *char_root_ang_vel, const float *char_dof_pos, const float *char_dof_vel,
-                     const float *contact_forces, const float *ray_hfs, int P, float contact_eps, float *obs, int obs_dim) {
+void orc_compute_obs_ex(CHAR_ARGS, MLIB_ARGS, int N, int S, const float *tar_steps_dt, int K, const int64_t *key_body_ids,
+                        const int64_t *motion_ids, const float *motion_times, const float *motion_xy_offset,
+                        const float *char_root_pos, const float *char_root_rot, const float *char_root_vel,
+                        const float *char_root_ang_vel, const float *char_dof_pos, const float *char_dof_vel,
+                        const float *contact_forces, const float *ray_hfs, int P, float contact_eps, int global_obs,
+                        int root_height_obs, int enable_tar_obs, int use_contact_info, const float *target_xy,
+                        int has_replan_t, float replan_t, float *obs, int obs_dim) {
     orc_char_t c = mk_char(CHAR_PASS);
     MLIB_MAKE;
     int Wc = 12 + 6 * J + D + 3 * K;
     int Wt = 3 + 6 + 6 * J + 3 * K;
-    (void)obs_dim;
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < N; ++e) {
         float *o = obs + (size_t)e * obs_dim;
@@ -584,47 +609,98 @@ void orc_compute_obs(CHAR_ARGS, MLIB_ARGS, int N, int S, const float *tar_steps_
         forward_kinematics1(&c, char_root_pos + 3 * e, char_root_rot + 4 * e, jrot, bpos, brot);
         for (int k = 0; k < K; ++k)
             for (int a = 0; a < 3; ++a) key[3 * k + a] = bpos[3 * key_body_ids[k] + a];
-        char_obs1(J, D, K, char_root_pos + 3 * e, char_root_rot + 4 * e, char_root_vel + 3 * e, char_root_ang_vel + 3 * e,
-                  jrot, char_dof_vel + (size_t)e * D, key, o);
+        if (root_height_obs) *o++ = char_root_pos[3 * e + 2];
+        char_obs1(J, D, K, global_obs, char_root_pos + 3 * e, char_root_rot + 4 * e, char_root_vel + 3 * e,
+                  char_root_ang_vel + 3 * e, jrot, char_dof_vel + (size_t)e * D, key, o);
+        o += Wc;
         /* target frames: fetch_tar_obs_data mgdm_dm_util.py:279-302, dm_env.compute_tar_obs dm_env.py:686-718 */
         float trp[8 * 3], trr[8 * 4], tjr[8 * 64 * 4], tkey[8 * 16 * 3], tcon[8 * 65];
-        for (int s = 0; s < S; ++s) {
-            float rv[3], rav[3], dv[128];
-            float t = motion_times[e] + tar_steps_dt[s];
-            calc_motion_frame1(&ml, motion_ids[e], t, trp + 3 * s, trr + 4 * s, rv, rav, tjr + (size_t)s * J * 4, dv, tcon + s * B);
-            trp[3 * s + 0] += motion_xy_offset[2 * e + 0];
-            trp[3 * s + 1] += motion_xy_offset[2 * e + 1];
-            forward_kinematics1(&c, trp + 3 * s, trr + 4 * s, tjr + (size_t)s * J * 4, bpos, brot);
-            for (int k = 0; k < K; ++k)
-                for (int a = 0; a < 3; ++a) tkey[(s * K + k) * 3 + a] = bpos[3 * key_body_ids[k] + a];
+        if (enable_tar_obs) {
+            for (int s = 0; s < S; ++s) {
+                float rv[3], rav[3], dv[128];
+                float t = motion_times[e] + tar_steps_dt[s];
+                calc_motion_frame1(&ml, motion_ids[e], t, trp + 3 * s, trr + 4 * s, rv, rav, tjr + (size_t)s * J * 4, dv, tcon + s * B);
+                trp[3 * s + 0] += motion_xy_offset[2 * e + 0];
+                trp[3 * s + 1] += motion_xy_offset[2 * e + 1];
+                forward_kinematics1(&c, trp + 3 * s, trr + 4 * s, tjr + (size_t)s * J * 4, bpos, brot);
+                for (int k = 0; k < K; ++k)
+                    for (int a = 0; a < 3; ++a) tkey[(s * K + k) * 3 + a] = bpos[3 * key_body_ids[k] + a];
+            }
+            tar_obs1(S, J, K, global_obs, char_root_pos + 3 * e, char_root_rot + 4 * e, trp, trr, tjr, tkey, o);
+            o += S * Wt;
         }
-        tar_obs1(S, J, K, char_root_pos + 3 * e, char_root_rot + 4 * e, trp, trr, tjr, tkey, o + Wc);
-        float *oc = o + Wc + S * Wt;
-        for (int s = 0; s < S; ++s)
-            for (int b = 0; b < B; ++b) oc[s * B + b] = tcon[s * B + b];
-        oc += S * B;
-        for (int b = 0; b < B; ++b) { /* ig_parkour_env.py:841-848 */
-            const float *f = contact_forces + ((size_t)e * B + b) * 3;
-            float nrm = sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
-            oc[b] = nrm > contact_eps ? 1.f : 0.f;
+        if (use_contact_info) {
+            if (enable_tar_obs) {
+                for (int s = 0; s < S; ++s)
+                    for (int b = 0; b < B; ++b) o[s * B + b] = tcon[s * B + b];
+                o += S * B;
+            }
+            for (int b = 0; b < B; ++b) { /* ig_parkour_env.py:841-848 */
+                const float *f = contact_forces + ((size_t)e * B + b) * 3;
+                float nrm = sqrtf(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+                o[b] = nrm > contact_eps ? 1.f : 0.f;
+            }
+            o += B;
         }
-        oc += B;
-        for (int p = 0; p < P; ++p) oc[p] = ray_hfs[(size_t)e * P + p];
+        for (int p = 0; p < P; ++p) o[p] = ray_hfs[(size_t)e * P + p];
+        o += P;
+        if (target_xy) {
+            float ang = -calc_heading(char_root_rot + 4 * e);
+            float x = target_xy[2 * e] - char_root_pos[3 * e], y = target_xy[2 * e + 1] - char_root_pos[3 * e + 1];
+            float ca = cosf(ang), sa = sinf(ang);
+            o[0] = x * ca - y * sa;
+            o[1] = x * sa + y * ca;
+            o += 2;
+        }
+        if (has_replan_t) *o++ = replan_t;
+        if ((int)(o - (obs + (size_t)e * obs_dim)) != obs_dim) abort();          /* the caller's row width is the reference's */
     }
+}
+
+/* the default tracker configuration (every switch at the value the reference ships for stage 3) */
+void orc_compute_obs(CHAR_ARGS, MLIB_ARGS, int N, int S, const float *tar_steps_dt, int K, const int64_t *key_body_ids,
+                     const int64_t *motion_ids, const float *motion_times, const float *motion_xy_offset,
+                     const float *char_root_pos, const float *char_root_rot, const float *char_root_vel,
+                     const float *char_root_ang_vel, const float *char_dof_pos, const float *char_dof_vel,
+                     const float *contact_forces, const float *ray_hfs, int P, float contact_eps, float *obs, int obs_dim) {
+    orc_compute_obs_ex(CHAR_PASS, MLIB_PASS, N, S, tar_steps_dt, K, key_body_ids, motion_ids, motion_times, motion_xy_offset,
+                       char_root_pos, char_root_rot, char_root_vel, char_root_ang_vel, char_dof_pos, char_dof_vel, contact_forces,
+                       ray_hfs, P, contact_eps, 0, 0, 1, 1, NULL, 0, 0.f, obs, obs_dim);
 }
 
 /* ------------------------------------------------------------------ reward (a10) */
 
-/* envs/ig_parkour/mgdm_dm_util.py:327-390 (track_root = track_root_h = True) + :555-576 +
- * ig_parkour_env.py:1307-1339,1399-1404.  terms[N,6] = pose, vel, root_pose, root_vel, key_pos, contact_penalty */
-void orc_compute_reward(CHAR_ARGS, int N, int K, const int64_t *key_body_ids, const float *char_root_pos,
-                        const float *char_root_rot, const float *char_root_vel, const float *char_root_ang_vel,
-                        const float *char_dof_pos, const float *char_dof_vel, const float *char_body_pos,
-                        const float *ref_root_pos, const float *ref_root_rot, const float *ref_root_vel,
-                        const float *ref_root_ang_vel, const float *ref_joint_rot, const float *ref_dof_vel,
-                        const float *ref_body_pos, const float *ref_contacts, const float *contact_forces,
-                        const float *joint_err_w, const float *dof_err_w, const float *contact_w, const float *w5,
-                        float rel_dm_w, float *reward, float *terms) {
+/* the three root quantities and the key-body offsets in the heading frame: convert_to_local mgdm_dm_util.py:305-325 */
+static void to_local1(int K, float *root_rot, float *root_vel, float *root_ang_vel, float *key) {
+    float h[4], q[4], v[3];
+    calc_heading_quat_inv(root_rot, h);
+    quat_mul(h, root_rot, q);
+    for (int a = 0; a < 4; ++a) root_rot[a] = q[a];
+    quat_rotate(h, root_vel, v);
+    for (int a = 0; a < 3; ++a) root_vel[a] = v[a];
+    quat_rotate(h, root_ang_vel, v);
+    for (int a = 0; a < 3; ++a) root_ang_vel[a] = v[a];
+    for (int k = 0; k < K; ++k) {
+        quat_rotate(h, key + 3 * k, v);
+        for (int a = 0; a < 3; ++a) key[3 * k + a] = v[a];
+    }
+}
+
+/* IGParkourEnv._update_reward ig_parkour_env.py:1275-1404, every switch of it: compute_deepmimic_reward mgdm_dm_util.py:327-390
+ * (track_root: the horizontal root error is dropped :352-353 and root rotation / velocities / key-body offsets of both sides are
+ * compared in their own heading frames :364-366; track_root_h: the vertical root error is dropped :355-356), the contact term
+ * mgdm_dm_util.py:555-576 if use_contact_info (:1324-1339), the target-location task reward :1347-1388 (target_xy NULL: the target is
+ * the character's own position, what the reference holds before a target is set) and the product rule for rel_task_w > 0 (:1399-1404).
+ * terms[N,9] = pose, vel, root_pose, root_vel, key_pos, contact_penalty, task_r1, task_r2, total_task_r */
+void orc_compute_reward_ex(CHAR_ARGS, int N, int K, const int64_t *key_body_ids, const float *char_root_pos,
+                           const float *char_root_rot, const float *char_root_vel, const float *char_root_ang_vel,
+                           const float *char_dof_pos, const float *char_dof_vel, const float *char_body_pos,
+                           const float *ref_root_pos, const float *ref_root_rot, const float *ref_root_vel,
+                           const float *ref_root_ang_vel, const float *ref_joint_rot, const float *ref_dof_vel,
+                           const float *ref_body_pos, const float *ref_contacts, const float *contact_forces,
+                           const float *joint_err_w, const float *dof_err_w, const float *contact_w, const float *w5,
+                           float rel_dm_w, int track_root, int track_root_h, int use_contact_info, const float *target_xy,
+                           float task1_w, float task2_w, float target_radius, float rel_task_w, float *reward, float *terms) {
     orc_char_t c = mk_char(CHAR_PASS);
     int D = char_dof_size(&c), J = nb - 1, B = nb;
 #pragma omp parallel for schedule(static)
@@ -643,24 +719,42 @@ void orc_compute_reward(CHAR_ARGS, int N, int K, const int64_t *key_body_ids, co
         }
         const float *rp = char_root_pos + 3 * e, *tp = ref_root_pos + 3 * e;
         float root_pos_err = 0.f;
-        for (int a = 0; a < 3; ++a) { float d = tp[a] - rp[a]; root_pos_err += d * d; }
-        float rre = quat_diff_angle(char_root_rot + 4 * e, ref_root_rot + 4 * e);
+        for (int a = 0; a < 3; ++a) {
+            float d = tp[a] - rp[a];
+            if ((a < 2 && !track_root) || (a == 2 && !track_root_h)) d = 0.f;
+            root_pos_err += d * d;
+        }
+        float rq[4], rv[3], rw[3], tq[4], tv[3], tw[3], ckey[16 * 3], tkey[16 * 3];
+        for (int a = 0; a < 4; ++a) { rq[a] = char_root_rot[4 * e + a]; tq[a] = ref_root_rot[4 * e + a]; }
+        for (int a = 0; a < 3; ++a) {
+            rv[a] = char_root_vel[3 * e + a]; rw[a] = char_root_ang_vel[3 * e + a];
+            tv[a] = ref_root_vel[3 * e + a]; tw[a] = ref_root_ang_vel[3 * e + a];
+        }
+        for (int k = 0; k < K; ++k) {
+            int64_t b = key_body_ids[k];
+            for (int a = 0; a < 3; ++a) {
+                ckey[3 * k + a] = char_body_pos[((size_t)e * B + b) * 3 + a] - rp[a];
+                tkey[3 * k + a] = ref_body_pos[((size_t)e * B + b) * 3 + a] - tp[a];
+            }
+        }
+        if (!track_root) {
+            to_local1(K, rq, rv, rw, ckey);
+            to_local1(K, tq, tv, tw, tkey);
+        }
+        float rre = quat_diff_angle(rq, tq);
         rre *= rre;
         float rve = 0.f, rave = 0.f;
         for (int a = 0; a < 3; ++a) {
-            float d = ref_root_vel[3 * e + a] - char_root_vel[3 * e + a];
+            float d = tv[a] - rv[a];
             rve += d * d;
-            float d2 = ref_root_ang_vel[3 * e + a] - char_root_ang_vel[3 * e + a];
+            float d2 = tw[a] - rw[a];
             rave += d2 * d2;
         }
         float kpe = 0.f;
         for (int k = 0; k < K; ++k) {
-            int64_t b = key_body_ids[k];
             float s = 0.f;
             for (int a = 0; a < 3; ++a) {
-                float kp = char_body_pos[((size_t)e * B + b) * 3 + a] - rp[a];
-                float tk = ref_body_pos[((size_t)e * B + b) * 3 + a] - tp[a];
-                float d = tk - kp;
+                float d = tkey[3 * k + a] - ckey[3 * k + a];
                 s += d * d;
             }
             kpe += s;
@@ -682,11 +776,46 @@ void orc_compute_reward(CHAR_ARGS, int N, int K, const int64_t *key_body_ids, co
         }
         cp /= (float)B;
         float dm = w5[0] * pose_r + w5[1] * vel_r + w5[2] * root_pose_r + w5[3] * root_vel_r + w5[4] * key_r;
-        dm += cp;
-        reward[e] = rel_dm_w * dm;
-        float *t6 = terms + 6 * (size_t)e;
-        t6[0] = pose_r; t6[1] = vel_r; t6[2] = root_pose_r; t6[3] = root_vel_r; t6[4] = key_r; t6[5] = cp;
+        if (use_contact_info) dm += cp;
+        /* task reward: reach the target location at >= 2 m/s facing it (:1347-1388) */
+        float dx = (target_xy ? target_xy[2 * e] : rp[0]) - rp[0], dy = (target_xy ? target_xy[2 * e + 1] : rp[1]) - rp[1];
+        float err = dx * dx + dy * dy;
+        float r1 = expf(-0.075f * err);
+        float len = sqrtf(err);
+        float ux = len > 0.01f ? dx / len : 0.f, uy = len > 0.01f ? dy / len : 0.f;
+        float mv = 2.0f - (ux * char_root_vel[3 * e] + uy * char_root_vel[3 * e + 1]);
+        if (mv < 0.f) mv = 0.f;
+        float min_vel_r = expf(-(mv * mv));
+        float hd = calc_heading(char_root_rot + 4 * e);
+        float he = 1.0f - (ux * cosf(hd) + uy * sinf(hd));
+        if (he < 0.f) he = 0.f;
+        float r2 = min_vel_r * expf(-(he * he));
+        float task = task1_w * r1 + task2_w * r2;
+        if (err < target_radius * target_radius) task = 1.0f;
+        reward[e] = rel_task_w > 0.f ? dm * task : rel_dm_w * dm;
+        float *t9 = terms + 9 * (size_t)e;
+        t9[0] = pose_r; t9[1] = vel_r; t9[2] = root_pose_r; t9[3] = root_vel_r; t9[4] = key_r; t9[5] = cp;
+        t9[6] = r1; t9[7] = r2; t9[8] = task;
     }
+}
+
+/* the default tracker configuration; terms[N,6] = pose, vel, root_pose, root_vel, key_pos, contact_penalty */
+void orc_compute_reward(CHAR_ARGS, int N, int K, const int64_t *key_body_ids, const float *char_root_pos,
+                        const float *char_root_rot, const float *char_root_vel, const float *char_root_ang_vel,
+                        const float *char_dof_pos, const float *char_dof_vel, const float *char_body_pos,
+                        const float *ref_root_pos, const float *ref_root_rot, const float *ref_root_vel,
+                        const float *ref_root_ang_vel, const float *ref_joint_rot, const float *ref_dof_vel,
+                        const float *ref_body_pos, const float *ref_contacts, const float *contact_forces,
+                        const float *joint_err_w, const float *dof_err_w, const float *contact_w, const float *w5,
+                        float rel_dm_w, float *reward, float *terms) {
+    float *t9 = (float *)malloc(sizeof(float) * 9 * (size_t)(N > 0 ? N : 1));
+    orc_compute_reward_ex(CHAR_PASS, N, K, key_body_ids, char_root_pos, char_root_rot, char_root_vel, char_root_ang_vel, char_dof_pos,
+                          char_dof_vel, char_body_pos, ref_root_pos, ref_root_rot, ref_root_vel, ref_root_ang_vel, ref_joint_rot,
+                          ref_dof_vel, ref_body_pos, ref_contacts, contact_forces, joint_err_w, dof_err_w, contact_w, w5, rel_dm_w,
+                          1, 1, 1, NULL, 0.7f, 0.3f, 1.0f, 0.f, reward, t9);
+    for (int e = 0; e < N; ++e)
+        for (int k = 0; k < 6; ++k) terms[6 * (size_t)e + k] = t9[9 * (size_t)e + k];
+    free(t9);
 }
 
 /* ------------------------------------------------------------------ termination (a11) */

@@ -160,31 +160,68 @@ def oracle_compare(env, clips, tiled, obs, r, ids=None, report=False, oracle_fra
     glob = rs[:, 0:3] + z(c.env_offsets)
     hfs = orc.refresh_ray_obs_hfs(full(c.ray_xy_points), glob, orc.calc_heading(rs[:, 3:7]), tiled[0], tiled[1], tiled[2])
     cf = z(c.contact_forces.view(N_all, 15, 3))
+    # the switches of IGParkourEnv._compute_obs / _update_reward this env was built with (tracker defaults unless overridden)
+    tc = env._cfg
+    g_glob, g_rh, g_tar, g_con = bool(s.global_obs), bool(tc.global_root_height_obs), bool(tc.enable_tar_obs), bool(tc.use_contact_info)
+    txy = z(c.target_xy)
+    replan = float(env._mgdm_env.get_mgdm_time_buf()) if getattr(env, "_enable_replan_timer_obs", False) else None
     o_obs = orc.compute_obs(char, mlib, tar_dt, key_ids, mids, times, off, rs[:, 0:3], rs[:, 3:7], rs[:, 7:10], rs[:, 10:13],
-                            np.ascontiguousarray(ds[..., 0]), np.ascontiguousarray(ds[..., 1]), cf, hfs)
+                            np.ascontiguousarray(ds[..., 0]), np.ascontiguousarray(ds[..., 1]), cf, hfs, global_obs=g_glob,
+                            global_root_height_obs=g_rh, enable_tar_obs=g_tar, use_contact_info=g_con,
+                            target_xy=txy if tc.has_target_xy_obs else None, replan_t=replan)
     g_obs = z(obs)
     Wc = 12 + 6 * J + 28 + 3 * len(key_ids)
     Wt = tar_dep.shape[0]
-    assert Wc + S * Wt + S * B + B + hfs.shape[1] == g_obs.shape[1]
+    assert o_obs.shape[1] == g_obs.shape[1], (o_obs.shape, g_obs.shape)
+    stats["obs_columns"] = int(g_obs.shape[1])
     # observation entries are differences of world coordinates expressed in the heading frame: their resolution is that of the
     # coordinates themselves (tiles of a 1024-clip grid sit up to ~300 m from the origin, where one fp32 ulp is 3e-5 m)
     far = np.maximum(np.abs(rs[:, 0:3]).max(-1), np.abs(ref["ref_root_pos"]).max(-1))
     coord_ulp = (2.0 ** (np.floor(np.log2(np.maximum(far, 1.0))) - 23))[:, None]
-    check("obs_char", g_obs[:, :Wc], o_obs[:, :Wc], none, TIGHT + 2 * coord_ulp)
-    tar_exc = (marg[:, 1:, None, :] & tar_dep[None, None]).any(-1).reshape(n, S * Wt)
-    check("obs_tar", g_obs[:, Wc:Wc + S * Wt], o_obs[:, Wc:Wc + S * Wt], tar_exc, TIGHT + 2 * coord_ulp)
-    RL = Wc + S * Wt + S * B + B                                           # pose-derived columns (871 with six target steps)
-    check("obs_contacts", g_obs[:, Wc + S * Wt:RL], o_obs[:, Wc + S * Wt:RL], none, 2e-5)
-    flips = float(np.mean(g_obs[:, RL:] != o_obs[:, RL:]))
+    at = 0
+    if g_rh:
+        check("obs_root_height", g_obs[:, 0:1], o_obs[:, 0:1], none, 0.0)                   # a copy of the root's z
+        at = 1
+    check("obs_char", g_obs[:, at:at + Wc], o_obs[:, at:at + Wc], none, TIGHT + 2 * coord_ulp)
+    at += Wc
+    if g_tar:
+        tar_exc = (marg[:, 1:, None, :] & tar_dep[None, None]).any(-1).reshape(n, S * Wt)
+        check("obs_tar", g_obs[:, at:at + S * Wt], o_obs[:, at:at + S * Wt], tar_exc, TIGHT + 2 * coord_ulp)
+        at += S * Wt
+    if g_con:
+        Wn = (S * B if g_tar else 0) + B
+        check("obs_contacts", g_obs[:, at:at + Wn], o_obs[:, at:at + Wn], none, 2e-5)
+        at += Wn
+    P = hfs.shape[1]
+    flips = float(np.mean(g_obs[:, at:at + P] != o_obs[:, at:at + P]))
     stats["obs_hf_fraction_of_nearest_cell_flips"] = flips
     if not report:
         assert flips < 5e-3                                            # nearest-cell flips only at cell boundaries
+    at += P
+    if tc.has_target_xy_obs:
+        # the offset to the target in the heading frame: a difference of world coordinates, rotated by cos / sin in the reference
+        # (rotate_2d_vec) and by the heading quaternion on the device: relative 1e-6 of the offset on top of the coordinates' ulp
+        reach = np.linalg.norm(txy - rs[:, 0:2], axis=-1, keepdims=True)
+        check("obs_target_xy", g_obs[:, at:at + 2], o_obs[:, at:at + 2], none, TIGHT + 2 * coord_ulp + 2e-6 * reach)
+        at += 2
+    if replan is not None:
+        check("obs_replan_t", g_obs[:, at:at + 1], o_obs[:, at:at + 1], none, 0.0)
+        at += 1
+    assert at == g_obs.shape[1]
     st = dict(char_root_pos=rs[:, 0:3], char_root_rot=rs[:, 3:7], char_root_vel=rs[:, 7:10], char_root_ang_vel=rs[:, 10:13],
               char_dof_pos=np.ascontiguousarray(ds[..., 0]), char_dof_vel=np.ascontiguousarray(ds[..., 1]),
               char_rigid_body_pos=z(c.rigid_body_state.view(N_all, 15, 13))[..., 0:3], contact_forces=cf)
-    o_r, _ = orc.compute_reward(char, key_ids, st, ref, list(s.joint_err_w)[:14], list(s.dof_err_w)[:28], list(s.contact_w)[:15],
-                                list(s.reward_w))
+    # (TrackerConfig folds rel_deepmimic_w into the struct as 1 when the product rule applies; the oracle's rule ignores it then too)
+    o_r, o_terms = orc.compute_reward(char, key_ids, st, ref, list(s.joint_err_w)[:14], list(s.dof_err_w)[:28], list(s.contact_w)[:15],
+                                      list(s.reward_w), rel_dm_w=float(s.rel_deepmimic_w), track_root=bool(s.track_root),
+                                      track_root_h=bool(s.track_root_h), use_contact_info=g_con, target_xy=txy, task1_w=float(s.task1_w),
+                                      task2_w=float(s.task2_w), target_radius=float(s.target_radius), rel_task_w=float(tc.rel_task_w),
+                                      all_terms=True)
     check("reward", z(r), o_r, marg[:, 0].any(-1), 1e-4)
+    # the nine logged terms (info["rewards"]: pose, vel, root_pos, root_vel, key_pos, contact_penalty, task_r1, task_r2, total_task_r)
+    g_terms = full(c.reward_terms)[:, ids].T
+    rows = [i for i in range(9) if g_con or i != 5]
+    check("reward_terms", g_terms[:, rows], o_terms[:, rows], marg[:, 0].any(-1)[:, None], 1e-4)
     # ---- termination flags (compute_done mgdm_dm_util.py:392-460 + the motion-end override dm_env.py:746-783), from the DEVICE's
     # reference pose so that only the rule arithmetic is compared; a flag may differ from the oracle's only where the decision is
     # marginal, i.e. where the oracle itself answers differently with every threshold moved by 1e-4 of its value either way

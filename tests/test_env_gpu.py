@@ -535,6 +535,45 @@ def test_config4_parkour_8192_envs_with_record_rollout(tmp_path):
     assert d["terrain"]["__class__"] == "util.terrain_util.SubTerrain"
 
 
+SWITCH_SETS = {
+    "everything": {"has_target_xy_obs": True, "global_root_height_obs": True, "track_root_h": False, "rel_task_w": 1.0},
+    "global_obs": {"global_obs": True, "has_target_xy_obs": True},
+    "no_root_tracking": {"track_root": False},
+    "no_root_tracking_at_all": {"track_root": False, "track_root_h": False, "global_obs": True},
+    "bare_row": {"enable_tar_obs": False, "use_contact_info": False},
+    "task_product": {"rel_task_w": 0.5, "rel_deepmimic_w": 0.7},
+}
+
+
+@pytest.mark.parametrize("tag", sorted(SWITCH_SETS))
+def test_observation_and_reward_switches_at_full_size(tag):
+    """The non-default settings of IGParkourEnv._compute_obs / _update_reward (ig_parkour_env.py:1054-1244,1275-1404) on the metric's
+    configuration (4096 envs, 64 clips on box heightfields), three simulated steps in: EVERY env's handed-out observation row,
+    reward, nine reward terms and termination flags against the oracle, whose own switches are pinned on the reference's output
+    (G26, tests/test_oracle_golden.py).  The 64-env G26 state itself is checked through the C ABI in tests/test_hip_parity.py."""
+    import smoke_impl
+    from parc_amd import workloads
+    torch.manual_seed(0)
+    n = 4096
+    over = SWITCH_SETS[tag]
+    env, clips, tiled = workloads.build_env("boxes_64clips", n, DEV, seed=0, env_overrides=dict(over))
+    obs, info = env.reset()
+    lo, hi = env._action_bound_low, env._action_bound_high
+    mid, half = 0.5 * (hi + lo), 0.5 * (hi - lo)
+    for _ in range(3):
+        a = mid + 0.2 * half * torch.randn((n, 28), device=DEV)
+        obs, r, done, info = env.step(a)
+    torch.cuda.synchronize()
+    width = 1312 + 2 * bool(over.get("has_target_xy_obs")) + bool(over.get("global_root_height_obs")) \
+        - (6 * 105 + 6 * 15) * (not over.get("enable_tar_obs", True)) - 15 * (not over.get("use_contact_info", True))
+    assert obs.shape == (n, width) and torch.isfinite(obs).all() and torch.isfinite(r).all()
+    c = env._core
+    if over.get("has_target_xy_obs") or over.get("rel_task_w", 0) > 0:
+        # the xy targets were drawn (dm_env.py:617-654) and are not the characters' own positions
+        assert float((c.target_xy - c.root_state[:, 0:2]).norm(dim=-1).mean()) > 0.2
+    assert smoke_impl.oracle_compare(env, clips, tiled, obs, r) == n
+
+
 @pytest.mark.parametrize("workload,num_envs", [("flat_1clip", 1024), ("boxes_64clips", 4096), ("iter0_1024clips", 4096)])
 def test_baseline_config_workloads_at_full_size(workload, num_envs):
     """BASELINE.json configs[1] (1024 envs, flat terrain, one clip), configs[2] (4096 envs on procgen box heightfields, 64 clips: the

@@ -1,9 +1,11 @@
 """The CPU oracle (oracle/parc_oracle.c) against the golden vectors produced by the reference's own
 Python (tests/golden/gen_golden.py).  fp32 throughout; the only differences allowed are libm-vs-torch
 rounding of sin/cos/atan2/acos (a few ulp), hence 1e-5-scale tolerances, stated per test."""
+import os
+
 import numpy as np
 
-from conftest import golden
+from conftest import GOLDEN, golden
 
 ATOL = 2e-6   # |x| <= ~1 quantities: a few fp32 ulp
 RTOL = 1e-5
@@ -138,6 +140,51 @@ def test_g7_reward(oracle, ref_char):
     close(terms[:, 0:5], z["reward_terms"], atol=1e-5)
     close(terms[:, 5], z["contact_penalty"], atol=1e-5)
     close(r, z["reward"], atol=1e-5)
+
+
+def test_g26_observation_and_reward_switches(oracle, ref_char, ref_mlib):
+    """every switch of IGParkourEnv._compute_obs / _update_reward (ig_parkour_env.py:1054-1244,1275-1404) that G26 holds the
+    reference's own output for: the oracle's row, reward, every reward term and - without root tracking - the termination flags"""
+    import json
+    z = golden("g6_step")
+    g = golden("g26_obs_variants")
+    tables = json.load(open(os.path.join(GOLDEN, "g26_obs_variants.json")))["variants"]
+    off, times = _step_inputs(z)
+    tar_dt = (z["tar_obs_steps"].astype(np.float32) * np.float32(1.0 / 30.0)).astype(np.float32)
+    base = dict(global_obs=False, global_root_height_obs=False, enable_tar_obs=True, use_contact_info=True, has_target_xy_obs=False,
+                track_root=True, track_root_h=True, rel_deepmimic_w=1.0, rel_task_w=0.0, enable_replan_timer_obs=False)
+    names = ("pose_r", "vel_r", "root_pos_r", "root_vel_r", "key_pos_r", "contact_penalty", "task_r1", "task_r2", "total_task_r")
+    assert len(tables) >= 12
+    for tag, tab in tables.items():
+        cfg = dict(base, **{k: v for k, v in tab["config"].items() if not k.startswith("_")})
+        obs = oracle.compute_obs(ref_char, ref_mlib, tar_dt, z["key_body_ids"], z["motion_ids"], times, off, z["char_root_pos"],
+                                 z["char_root_rot"], z["char_root_vel"], z["char_root_ang_vel"], z["char_dof_pos"], z["char_dof_vel"],
+                                 z["contact_forces"], z["ray_hfs"], global_obs=cfg["global_obs"],
+                                 global_root_height_obs=cfg["global_root_height_obs"], enable_tar_obs=cfg["enable_tar_obs"],
+                                 use_contact_info=cfg["use_contact_info"], target_xy=g["target_xy"] if cfg["has_target_xy_obs"] else None,
+                                 replan_t=float(g["plan_clock"]) if cfg["enable_replan_timer_obs"] else None)
+        assert obs.shape == g[tag + "_obs"].shape == (64, tab["obs_dim"]), tag
+        close(obs, g[tag + "_obs"], atol=2e-5)
+        r, terms = oracle.compute_reward(ref_char, z["key_body_ids"], z, z, z["joint_err_w"], z["dof_err_w"], np.full(15, 5.0, np.float32),
+                                         z["reward_w"], rel_dm_w=cfg["rel_deepmimic_w"], track_root=cfg["track_root"],
+                                         track_root_h=cfg["track_root_h"], use_contact_info=cfg["use_contact_info"], target_xy=g["target_xy"],
+                                         rel_task_w=cfg["rel_task_w"], all_terms=True)
+        close(r, g[tag + "_reward"], atol=1e-5)
+        for i, name in enumerate(names):
+            if tag + "_r_" + name in g:
+                close(terms[:, i], g[tag + "_r_" + name], atol=1e-5)
+            else:
+                assert name == "contact_penalty" and not cfg["use_contact_info"]
+        if not cfg["track_root"]:
+            pre, _, _ = oracle.update_done(
+                time_buf=z["time_buf"], ep_len=10.0, char_root_rot=z["char_root_rot"], body_pos=z["char_rigid_body_pos"],
+                ref_root_rot=z["ref_root_rot"], ref_body_pos=z["ref_body_pos"], contact_forces=z["contact_forces"], contact_body_ids=[],
+                env_offsets=z["env_offsets"], hf=z["hf"], min_point=z["min_point"], dxdy=z["dxdy"], termination_height=0.15,
+                pose_termination=True, pose_termination_dist=z["pose_termination_dist"], enable_early_termination=True, track_root=False,
+                root_pos_term_dist=0.6, root_rot_term_angle=1.309, motion_ids=z["motion_ids"], motion_times=times, motion_len=ref_mlib.length,
+                motion_loop_mode=ref_mlib.loop_mode, fail_rates=np.ones(4, np.float32))
+            np.testing.assert_array_equal(pre, g[tag + "_done"])
+            assert (pre != z["done_nocontact"]).any()                  # the root checks did decide some of the default flags
 
 
 def test_g8_done_and_fail_rates(oracle, ref_mlib):
