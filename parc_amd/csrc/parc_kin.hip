@@ -1713,6 +1713,19 @@ __global__ __launch_bounds__(REF_STATE_THREADS) void ref_state_kernel(parc_char_
     ref_state_group(m, ml, buf, env_ids, n_total, what, (int)(blockIdx.x * (REF_STATE_THREADS / GRP) + (threadIdx.x >> 4)), threadIdx.x & 15);
 }
 
+#ifdef PARC_DIAG_BUILD
+// occupancy probe: bytes of dynamic LDS added to every workgroup of track_post_kernel (fewer workgroups resident per CU); diagnostics build only
+static int g_post_lds_pad = 0;
+extern "C" int parc_tune_post_lds_pad(int bytes) {
+    if (bytes < 0 || bytes > 120 * 1024) return PARC_EINVAL;
+    g_post_lds_pad = bytes;
+    return PARC_OK;
+}
+#define POST_LDS_PAD g_post_lds_pad
+#else
+#define POST_LDS_PAD 0
+#endif
+
 static int track_post_step_impl(void *stream, const parc_char_model_t &model, const parc_motion_lib_t &mlib, const parc_terrain_t &terrain,
                                 const parc_track_cfg_t &cfg, const parc_env_buffers_t &buf, const int64_t *env_ids, int n_sel, int what,
                                 const float *ray_xy, hipEvent_t start_event, hipEvent_t stop_event) {
@@ -1747,10 +1760,10 @@ static int track_post_step_impl(void *stream, const parc_char_model_t &model, co
         if (start_event || stop_event)
             // the same launch with a pair of events bound to THIS dispatch: they carry the kernel's own begin / end time stamps (what a
             // profiler reads from the dispatch), not the time between two separate event records around it
-            hipExtLaunchKernelGGL(track_post_kernel, grid, block, 0, (hipStream_t)stream, start_event, stop_event, 0, model, mlib, terrain, cfg, buf,
+            hipExtLaunchKernelGGL(track_post_kernel, grid, block, POST_LDS_PAD, (hipStream_t)stream, start_event, stop_event, 0, model, mlib, terrain, cfg, buf,
                                   env_ids, n, what, ray_xy);
         else
-            hipLaunchKernelGGL(track_post_kernel, grid, block, 0, (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, n, what, ray_xy);
+            hipLaunchKernelGGL(track_post_kernel, grid, block, POST_LDS_PAD, (hipStream_t)stream, model, mlib, terrain, cfg, buf, env_ids, n, what, ray_xy);
         PARC_CHECK_LAUNCH();
     }
     return PARC_OK;

@@ -15,7 +15,7 @@ from parc_amd.util import geom_util  # noqa: E402
 # --plain: the PRODUCT library and only launches of the product's own flags (what profiles/ *_kernel_stats / pmc files are taken from).
 # Anything else (knob sweeps, role ablations) runs on the diagnostics library, tools/parc_diag.py.
 PLAIN = "--plain" in sys.argv                    # one launch variant per process, no sweeps
-if not PLAIN or any(a.startswith("--ablate=") for a in sys.argv):
+if not PLAIN or any(a.startswith("--ablate=") or a.startswith("--lds-pad=") for a in sys.argv):
     import parc_diag  # noqa: E402
     parc_diag.install()
 
@@ -153,6 +153,14 @@ def bench_post_step(n, iters, workload="boxes_64clips"):
             torch.cuda.synchronize()
             best = min(best, s_.elapsed_time(e_) * 1e3 / n)
         return best
+    pads = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--lds-pad=")]
+    if pads:
+        # occupancy probe (diagnostics library): the static LDS of the kernel lets 4 workgroups of 6 waves share a CU; padding it
+        # leaves 3 / 2 / 1, i.e. the 1024 workgroups of 4096 envs run in more than one round and their load / store phases overlap
+        for pad in pads:
+            assert parc_diag.lib().parc_tune_post_lds_pad(pad) == 0
+            print(json.dumps({"lds_pad_bytes": pad, "us_graph_replay": round(graph_us(full), 2)}), flush=True)
+        parc_diag.lib().parc_tune_post_lds_pad(0)
     us_fused = time_loop(lambda: core.post_step(full), iters)
     us_graph = graph_us(full)
     # --plain runs are what the profiler passes wrap: ONE launch variant per process, so that a kernel-stats mean or a counter mean

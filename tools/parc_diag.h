@@ -15,6 +15,9 @@ int parc_tune_hf_envs_per_block(int envs_per_block);
 int parc_tune_hf_groups(int groups);
 int parc_tune_hf_ablation(int variant);
 
+/* occupancy probe of track_post_kernel: bytes of dynamic LDS added to every workgroup (process-global; 0 = the product's launch) */
+int parc_tune_post_lds_pad(int bytes);
+
 /* parc_track_post_step of this build also honours these bits of `what` (timing only: the launch's outputs are garbage) */
 #define PARC_DIAG_POST_NO_TARGET_WAVES 0x10000
 #define PARC_DIAG_POST_NO_REFERENCE_WAVE 0x20000

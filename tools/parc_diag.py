@@ -33,7 +33,7 @@ def lib():
         L = ctypes.CDLL(_hip.DIAG_LIB_PATH)
         _hip._declare(L)
         c_vp, c_int, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
-        for name in ("parc_tune_hf_envs_per_block", "parc_tune_hf_groups", "parc_tune_hf_ablation"):
+        for name in ("parc_tune_hf_envs_per_block", "parc_tune_hf_groups", "parc_tune_hf_ablation", "parc_tune_post_lds_pad"):
             getattr(L, name).argtypes = [c_int]
             getattr(L, name).restype = c_int
         L.parc_diag_sim_step_env_per_lane.restype = c_int
