@@ -805,3 +805,153 @@ def test_tumbling_free_body_keeps_its_velocity(model):
     # (0.5 % in one second: the drives hold the pose against the centrifugal load, the configuration moves a little, and a reduced-
     # coordinate semi-implicit step conserves P = J(q) qdot to O(h) only - see test_momentum_is_conserved_through_link_contacts)
     assert np.abs(P1 - P0).max() < 1e-2 * np.linalg.norm(P0), (P0, P1)
+
+
+def make_arm(model, joint, kp=40.0, kd=3.0, armature=0.02, effort=0.0, **over):
+    """A two-body chain in free space without gravity: a 10^6 kg base (the free root) and one link on a hinge about y (joint=1) or on
+    a spherical joint (joint=2) at the base's origin; the link: 2 kg, centre of mass 0.3 m below the joint, inertia about its centre
+    diag(0.05, 0.05, 0.01) -> 0.23 kg m^2 about the joint's x and y axes.  The base is heavy enough that its reaction moves the joint
+    by a millionth of the link's motion."""
+    km, sm = model
+    s = copy.deepcopy(sm.struct)
+    D = 1 if joint == 1 else 3
+    s.num_bodies, s.dof_size, s.num_spheres = 2, D, 1
+    s.parent[0], s.dof_idx[0] = -1, 0
+    s.parent[1], s.joint_type[1], s.dof_idx[1] = 0, joint, 0
+    for k in range(3):
+        s.com[0][k] = 0.0
+        s.sph_pos[0][k] = 0.0
+        s.local_translation[1][k] = 0.0
+        s.joint_axis[1][k] = [0.0, 1.0, 0.0][k]
+        s.com[1][k] = [0.0, 0.0, -0.3][k]
+    for k in range(4):
+        s.local_rotation[1][k] = [0.0, 0.0, 0.0, 1.0][k]
+    s.mass[0], s.mass[1] = 1.0e6, 2.0
+    for k, v in enumerate([1.0e6, 0.0, 0.0, 1.0e6, 0.0, 1.0e6]):
+        s.inertia_o[0][k] = v
+    for k, v in enumerate([0.05 + 2.0 * 0.09, 0.0, 0.0, 0.05 + 2.0 * 0.09, 0.0, 0.01]):       # about the joint (parallel axes)
+        s.inertia_o[1][k] = v
+    for d in range(D):
+        s.kp[d], s.kd[d], s.armature[d], s.effort[d] = kp, kd, armature, effort
+        s.limit_lo[d], s.limit_hi[d] = -10.0, 10.0
+    s.sph_body[0], s.sph_radius[0] = 0, 0.01
+    for b in range(16):
+        s.self_mask[b] = 0
+        s.cap_radius[b] = 0.0
+    s.angular_damping, s.gravity = 0.0, 0.0
+    for k, v in over.items():
+        setattr(s, k, v)
+    hf = np.full((20, 20), -100.0, np.float32)
+    if _FORMULATION[0] == "device":
+        from device_sim import DeviceSim
+        sim = DeviceSim(s, 1, hf, [-4.0, -4.0], [0.4, 0.4], num_bodies=2, dof_size=D)
+    else:
+        from oracle.sim_host import HostSim
+        sim = HostSim(s, 1, hf, [-4.0, -4.0], [0.4, 0.4], num_bodies=2, dof_size=D)
+    sim.root_state[0, 0:3] = [0.0, 0.0, 5.0]
+    return sim
+
+
+@pytest.mark.parametrize("joint", [1, 2])
+def test_joint_drive_is_the_implicit_euler_spring_damper(model, joint):
+    """One driven link (hinge, and a spherical joint turning about one of its axes): I th'' = kp (th* - th) - kd th' with I = the
+    link's inertia about the joint axis + the armature.  The drive is integrated implicitly, so every substep must be the implicit
+    Euler step of that equation,  w+ = (I w + h kp (th* - th)) / (I + h kd + h^2 kp),  th+ = th + h w+  (computed here in float64
+    from the physical constants - nothing of the kernel's articulated-body recursion), and the trajectory must approach the closed-
+    form step response of the damped oscillator as h shrinks."""
+    kp, kd, arm, target = 40.0, 3.0, 0.02, 0.5
+    inertia = 0.23 + arm
+    sim = make_arm(model, joint, kp, kd, arm)
+    D = sim.D
+    act = np.zeros((1, D), np.float32)
+    act[0, 1 if joint == 2 else 0] = target                    # spherical: exp-map target about y
+    col = 1 if joint == 2 else 0
+    h = 1.0 / 120.0
+    th, w = 0.0, 0.0
+    for step in range(60):
+        sim.step(act, n_sub=4, h=h)
+        for _ in range(4):
+            w = (inertia * w + h * kp * (target - th)) / (inertia + h * kd + h * h * kp)
+            th += h * w
+        assert abs(sim.dof_state[0, col, 0] - th) < 5e-5, (step, sim.dof_state[0, col, 0], th)
+        assert abs(sim.dof_state[0, col, 1] - w) < 5e-4, (step, sim.dof_state[0, col, 1], w)
+        if joint == 2:
+            assert np.abs(sim.dof_state[0, [0, 2], :]).max() < 1e-5         # the other two axes stay put
+    assert np.abs(sim.root_state[0, 7:13]).max() < 1e-4                      # the base does not move
+    # closed form of the under-damped oscillator (zeta = 0.47): first-order convergence in h
+    wn = np.sqrt(kp / inertia)
+    zeta = kd / (2.0 * np.sqrt(kp * inertia))
+    wd = wn * np.sqrt(1.0 - zeta * zeta)
+
+    def exact(t):
+        return target * (1.0 - np.exp(-zeta * wn * t) * (np.cos(wd * t) + zeta / np.sqrt(1.0 - zeta * zeta) * np.sin(wd * t)))
+    errs = []
+    for n_sub in (4, 32):
+        sim = make_arm(model, joint, kp, kd, arm)
+        worst = 0.0
+        for step in range(30):
+            sim.step(act, n_sub=n_sub, h=1.0 / (30.0 * n_sub))
+            worst = max(worst, abs(float(sim.dof_state[0, col, 0]) - exact((step + 1) / 30.0)))
+        errs.append(worst)
+    assert errs[0] < 0.06 * target and errs[1] < 0.01 * target and errs[1] < 0.2 * errs[0], errs
+
+
+def test_joint_drive_torque_limit(model):
+    """A drive that asks for more than its effort limit pushes with the limit: far from the target the link accelerates at
+    limit / I (to O(h): the implicit terms are scaled down with the torque), and the torque is the full PD law again once the error is
+    small enough."""
+    kp, kd, arm, lim = 400.0, 3.0, 0.02, 5.0
+    inertia = 0.23 + arm
+    sim = make_arm(model, 1, kp, kd, arm, effort=lim)
+    act = np.full((1, 1), 2.0, np.float32)                      # kp * 2 rad = 800 N m asked for, 5 N m allowed
+    h = 1.0 / 120.0
+    sim.step(act, n_sub=4, h=h)
+    acc = sim.dof_state[0, 0, 1] / (4 * h)
+    assert 0.9 * lim / inertia < acc <= lim / inertia + 1e-4, (acc, lim / inertia)
+    # an unlimited drive of the same gains does not respect it (the limit is what held the first one back)
+    free = make_arm(model, 1, kp, kd, arm)
+    free.step(act, n_sub=4, h=h)
+    assert free.dof_state[0, 0, 1] > 10.0 * sim.dof_state[0, 0, 1]
+    # inside the limit (error 0.01 rad -> 4 N m) the step is the unlimited one
+    small = np.full((1, 1), 0.01, np.float32)
+    a, b = make_arm(model, 1, kp, kd, arm, effort=lim), make_arm(model, 1, kp, kd, arm)
+    a.step(small, n_sub=4, h=h)
+    b.step(small, n_sub=4, h=h)
+    np.testing.assert_array_equal(a.dof_state, b.dof_state)
+
+
+def test_torque_free_asymmetric_body_conserves_angular_momentum_and_energy(model):
+    """A free rigid body with three different principal inertias, spun near its intermediate axis (the unstable one: it flips over
+    within two seconds), no force on it: the angular momentum in WORLD axes and the kinetic energy are constants of Euler's equations
+    - the only thing at work is the gyroscopic term w x I w of the root.  Semi-implicit Euler keeps both to O(h)."""
+    I = np.array([0.10, 0.22, 0.40])
+
+    def run(h, n_sub):
+        sim = make_ball(model, 10.0, 0.2, gravity=0.0, hf=np.full((60, 20), -100.0, np.float32))
+        for k, v in enumerate([I[0], 0.0, 0.0, I[1], 0.0, I[2]]):
+            sim.m.inertia_o[0][k] = v
+        sim.root_state[0, 0:3] = [0.0, 0.0, 3.0]
+        # root angular velocity in world axes; the body starts aligned with them
+        sim.root_state[0, 10:13] = [0.05, 6.0, 0.05]
+        act = np.zeros((1, 0), np.float32)
+        L, T, wy = [], [], []
+        for _ in range(60):
+            R = rotm(sim.root_state[0, 3:7].astype(np.float64))
+            w = sim.root_state[0, 10:13].astype(np.float64)
+            wb = R.T @ w
+            L.append(R @ (I * wb))
+            T.append(0.5 * wb @ (I * wb))
+            wy.append(wb[1])
+            sim.step(act, n_sub=n_sub, h=h)
+        return np.array(L), np.array(T), np.array(wy)
+    L1, T1, wy1 = run(1.0 / 120.0, 4)
+    L4, T4, _ = run(1.0 / 480.0, 16)
+    assert wy1.min() < -3.0                                              # it did flip: the spin about the body's own y axis reversed
+    dL1, dL4 = np.abs(L1 - L1[0]).max(), np.abs(L4 - L4[0]).max()
+    dT1, dT4 = np.abs(T1 - T1[0]).max(), np.abs(T4 - T4[0]).max()
+    # (the gyroscopic term is integrated explicitly: 4 % / 8 % over two seconds of tumbling at 6 rad/s with h = 1/120 s, a quarter of
+    # that with a quarter of the step)
+    print("drift of |L|, T at h = 1/120:", dL1 / np.linalg.norm(L1[0]), dT1 / T1[0], "at h = 1/480:", dL4 / np.linalg.norm(L1[0]), dT4 / T1[0])
+    assert dL1 < 0.06 * np.linalg.norm(L1[0]) and dT1 < 0.12 * T1[0], (dL1, dT1, L1[0], T1[0])
+    assert dL4 < 0.4 * dL1 and dT4 < 0.4 * dT1, (dL1, dL4, dT1, dT4)
+
