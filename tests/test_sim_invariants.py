@@ -955,3 +955,50 @@ def test_torque_free_asymmetric_body_conserves_angular_momentum_and_energy(model
     assert dL1 < 0.06 * np.linalg.norm(L1[0]) and dT1 < 0.12 * T1[0], (dL1, dT1, L1[0], T1[0])
     assert dL4 < 0.4 * dL1 and dT4 < 0.4 * dT1, (dL1, dL4, dT1, dT4)
 
+
+def test_drive_against_a_joint_limit_rests_where_the_two_springs_balance(model):
+    """A drive whose target lies beyond the joint's upper limit: at rest the drive's spring and the limit's spring carry the same
+    torque, kp (th* - th) = limit_kp (th - hi), so th = (kp th* + limit_kp hi) / (kp + limit_kp), with nothing moving."""
+    kp, target, hi = 40.0, 0.8, 0.3
+    sim = make_arm(model, 1, kp, 3.0, 0.02)
+    sim.m.limit_hi[0] = hi
+    lk = float(sim.m.limit_kp)
+    assert lk > 10.0 * kp                                            # the limit is the stiffer spring by far
+    act = np.full((1, 1), target, np.float32)
+    for _ in range(90):
+        sim.step(act, n_sub=4, h=1.0 / 120.0)
+    rest = (kp * target + lk * hi) / (kp + lk)
+    assert hi < rest < hi + 0.05
+    assert abs(sim.dof_state[0, 0, 0] - rest) < 2e-5, (sim.dof_state[0, 0, 0], rest)
+    assert abs(sim.dof_state[0, 0, 1]) < 1e-4
+
+
+def test_two_coaxial_rotors_share_the_drive_torque(model):
+    """A light base and a link whose centres of mass both sit on the hinge axis: two rotors on one shaft.  The drive is an internal
+    torque, so Ia wa + Ib wb stays zero (the base turns the other way by Ib / Ia) and the RELATIVE angle is the spring-damper of the
+    reduced inertia Ia Ib / (Ia + Ib) plus the armature - the implicit-Euler recurrence of test_joint_drive_... with that inertia."""
+    kp, kd, arm, target = 40.0, 3.0, 0.02, 0.5
+    Ia, Ib = 0.30, 0.20
+    sim = make_arm(model, 1, kp, kd, arm)
+    sim.m.mass[0] = 5.0
+    for k, v in enumerate([Ia, 0.0, 0.0, Ia, 0.0, Ia]):
+        sim.m.inertia_o[0][k] = v
+    for k in range(3):
+        sim.m.com[1][k] = 0.0
+    for k, v in enumerate([0.05, 0.0, 0.0, Ib, 0.0, 0.01]):
+        sim.m.inertia_o[1][k] = v
+    inertia = Ia * Ib / (Ia + Ib) + arm
+    act = np.full((1, 1), target, np.float32)
+    h = 1.0 / 120.0
+    th, w = 0.0, 0.0
+    for step in range(45):
+        sim.step(act, n_sub=4, h=h)
+        for _ in range(4):
+            w = (inertia * w + h * kp * (target - th)) / (inertia + h * kd + h * h * kp)
+            th += h * w
+        assert abs(sim.dof_state[0, 0, 0] - th) < 1e-4, (step, sim.dof_state[0, 0, 0], th)
+        wa = float(sim.root_state[0, 11])                            # base spin about y (world = body axes: it only turns about y)
+        wb = wa + float(sim.dof_state[0, 0, 1])
+        assert abs(Ia * wa + Ib * wb) < 2e-4 * max(1.0, abs(Ib * wb)), (step, wa, wb)
+    assert np.abs(sim.root_state[0, 7:10]).max() < 1e-5               # nothing pushes the pair anywhere
+
