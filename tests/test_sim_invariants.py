@@ -1002,3 +1002,24 @@ def test_two_coaxial_rotors_share_the_drive_torque(model):
         assert abs(Ia * wa + Ib * wb) < 2e-4 * max(1.0, abs(Ib * wb)), (step, wa, wb)
     assert np.abs(sim.root_state[0, 7:10]).max() < 1e-5               # nothing pushes the pair anywhere
 
+
+def test_free_fall_does_not_load_an_undriven_joint(model):
+    """Gravity accelerates every body alike: an undriven link hinged to a falling base, its centre of mass 0.3 m to the side of the
+    joint, feels no torque about the joint - the angle stays where it is while both fall at g (a gravity that acted on the base alone,
+    or as a force at the wrong point, would swing it)."""
+    sim = make_arm(model, 1, kp=0.0, kd=0.0, armature=0.0, gravity=9.81)
+    sim.m.mass[0] = 20.0                                               # a base the link could drag around
+    for k, v in enumerate([2.0, 0.0, 0.0, 2.0, 0.0, 2.0]):
+        sim.m.inertia_o[0][k] = v
+    sim.dof_state[0, 0, 0] = 0.5 * np.pi                               # link horizontal: the lever arm of its weight is the full 0.3 m
+    act = np.zeros((1, 1), np.float32)
+    h, steps = 1.0 / 120.0, 20
+    z0 = float(sim.root_state[0, 2])
+    for _ in range(steps):
+        sim.step(act, n_sub=4, h=h)
+    k = 4 * steps
+    assert abs(sim.dof_state[0, 0, 0] - 0.5 * np.pi) < 2e-5 and abs(sim.dof_state[0, 0, 1]) < 1e-4
+    assert abs(sim.root_state[0, 9] + 9.81 * k * h) < 1e-3
+    assert abs(sim.root_state[0, 2] - (z0 - 9.81 * h * h * k * (k + 1) / 2)) < 1e-3
+    assert np.abs(sim.root_state[0, 10:13]).max() < 1e-4               # and the base does not start to turn
+
