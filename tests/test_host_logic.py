@@ -67,6 +67,55 @@ def test_product_library_carries_no_diagnostics():
         assert "PARC_POST_DIAG" not in text and "PARC_ALLOW_STALE_LIB" not in text and "environ.get(\"PARC_POST" not in text
 
 
+def test_entry_points_refuse_bad_arguments_before_any_launch():
+    """Error behaviour of the C ABI (include/parc_hip.h: 0 ok, PARC_EINVAL -1, PARC_EUNSUPPORTED -2): malformed calls of the rollout
+    step's entry points are answered before any HIP call - so this runs without a GPU - instead of reaching a kernel with operands
+    it would index out of bounds."""
+    import ctypes
+    import __graft_entry__ as ge
+    ge.build()
+    from parc_amd import _hip, _hip_sim  # noqa: F401  (_hip_sim declares the simulator's prototypes on the same handle)
+    L = _hip.lib()
+    cell = (ctypes.c_int64 * 2)()
+    buf = (ctypes.c_float * 64)()
+    a16 = ctypes.addressof(buf) + (-ctypes.addressof(buf)) % 16          # a 16-byte aligned host address: never dereferenced
+    P = ctypes.c_void_p
+    EINVAL, EUNSUP = -1, -2
+    # random numbers of a step: no state cell; a count below zero; an output count without its buffer; a tick without a modulus
+    assert L.parc_rng_step(None, 1, None, P(a16), 4, None, 0, None, 0) == EINVAL
+    assert L.parc_rng_step(None, 1, cell, P(a16), -4, None, 0, None, 0) == EINVAL
+    assert L.parc_rng_step(None, 1, cell, None, 4, None, 0, None, 0) == EINVAL
+    assert L.parc_rng_step(None, 1, cell, None, 0, None, 0, cell, 0) == EINVAL
+    assert L.parc_rng_step(None, 1, cell, None, 0, None, 0, None, 0) == 0                   # nothing to draw, nothing to tick: a no-op
+    # observation ingest: a width that is not a multiple of 4, a misaligned row pointer, a copy target without its row cell, sums
+    # without their workspace
+    ok = (None, 8, 8, P(a16), P(a16), P(a16), 5.0, P(a16))
+    assert L.parc_obs_ingest(None, 8, 6, P(a16), P(a16), P(a16), 5.0, P(a16), None, None, None, None) == EINVAL
+    assert L.parc_obs_ingest(None, 8, 8, P(a16 + 4), P(a16), P(a16), 5.0, P(a16), None, None, None, None) == EINVAL
+    assert L.parc_obs_ingest(*ok, P(a16), None, None, None) == EINVAL
+    assert L.parc_obs_ingest(*ok, None, None, P(a16), None) == EINVAL
+    assert L.parc_obs_ingest(None, 0, 8, P(a16), P(a16), P(a16), 5.0, P(a16), None, None, None, None) == 0      # no rows: a no-op
+    # action head + record: more action columns than its 32 lanes per env; a record target missing
+    eight = [P(a16)] * 8
+    assert L.parc_action_head_record(None, 4, 33, *eight, *([P(a16)] * 5), 45, cell) == EUNSUP
+    assert L.parc_action_head_record(None, 4, 28, *eight, None, P(a16), P(a16), P(a16), P(a16), 45, cell) == EINVAL
+    assert L.parc_action_head_record(None, 4, 28, *eight, *([P(a16)] * 5), 45, None) == EINVAL
+    # row assembly: more rows than one grid dimension holds; no column map
+    assert L.parc_assemble_obs(None, 70000, P(a16), 1312, None, None, P(a16), P(a16), 1314, None, 0) == EUNSUP
+    assert L.parc_assemble_obs(None, 8, P(a16), 1312, None, None, None, P(a16), 1314, None, 0) == EINVAL
+    # the simulator step that also advances the clock, without the clock
+    assert L.parc_sim_step_tick(None, P(a16), _hip.TerrainS(), 4, *([P(a16)] * 8), 4, 1.0 / 120.0, None, None, 1.0 / 30.0) == EINVAL
+    # timed post step without its events
+    from parc_amd.anim.kin_char_model import KinCharModel
+    from parc_amd.assets import humanoid_spec
+    km = KinCharModel("cpu")
+    km.load_char_file(humanoid_spec.write_mjcf())
+    ms = _hip.MotionLibS()
+    ms.num_bodies, ms.dof_size = 15, 28
+    assert L.parc_track_post_step_timed(None, km.c_struct(), ms, _hip.TerrainS(), _hip.TrackCfgS(), _hip.EnvBuffersS(), None, 0,
+                                        _hip.POST_OBS, None, None, None) == EINVAL
+
+
 def test_g26_observation_layouts_and_the_shipped_configs():
     """The segment table IGParkourEnv._compute_obs(ret_obs_shapes=True) prints (fixture G26: the reference's own method, one entry per
     configuration variant) against TrackerConfig.obs_layout, with the gather map checked on a numbered row; and the two env
