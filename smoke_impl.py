@@ -95,7 +95,7 @@ def oracle_compare(env, clips, tiled, obs, r, ids=None, report=False, oracle_fra
     """Reference pose, observation rows, reward and termination flags of the envs `ids` (all if None) recomputed by the CPU oracle from
     the state the GPU holds, and compared at TIGHT - no blanket tolerance.  oracle_frames="device" (the tests, smoke): the oracle samples
     the clip rows the device stored, which are first checked against its own (adopt_device_frames); nothing is excused.
-    oracle_frames="own" (tools/slerp_outliers.py, report=True): the oracle samples its own stored frames; elements beyond TIGHT are
+    oracle_frames="own" (tests/tools/slerp_outliers.py, report=True): the oracle samples its own stored frames; elements beyond TIGHT are
     counted and each must depend on a quaternion that sits at one of slerp's two discontinuities (slerp_branch_marginal) - the
     explanation of round 2's red full-size run, kept as a measurement.  report=True returns the statistics instead of asserting."""
     from oracle import oracle as orc

@@ -1,7 +1,7 @@
 """Localise the -O3 divergence of the one-env-per-lane simulator kernel (sim_step_kernel, parc_sim_core.h).
 
-  python tools/bisect_sim_o3.py build            # here (no GPU): variants of parc_sim.hip + parc_sim_ref.hip -> gpurun_out/../_bisect/*.so
-  python tools/bisect_sim_o3.py run              # on the GPU box: every variant against the g++ host build of the same source
+  python tests/tools/bisect_sim_o3.py build            # here (no GPU): variants of parc_sim.hip + parc_sim_ref.hip -> gpurun_out/../_bisect/*.so
+  python tests/tools/bisect_sim_o3.py run              # on the GPU box: every variant against the g++ host build of the same source
 
 A variant = optimisation flags + a set of loop tags kept rolled (-DPARC_BISECT -DPARC_ROLL_<k>, parc_sim_bisect.h).  `run` steps
 the same random scene with every variant (both kernels: variant 0 = one env per lane, 1 = body per lane) and prints the largest
@@ -14,7 +14,7 @@ import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "parc_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "_bisect")

@@ -1,4 +1,4 @@
-// Debug aid of tools/bisect_sim_o3.py (not part of the product build): PARC_LOOP(k) keeps the loops tagged k rolled when
+// Debug aid of tests/tools/bisect_sim_o3.py (not part of the product build): PARC_LOOP(k) keeps the loops tagged k rolled when
 // PARC_ROLL_<k> is defined.  Tags: 0 kinematics sweep, 1 rigid-body inertia, 2 contact impedance, 3 contact report, 4 inward sweep,
 // 5 spherical drive (3 axes), 6 outward acceleration sweep, 7 integration, 8 load_state, 9 store_state, 10 publish_bodies,
 // 11 substep loop, 12 the fixed-trip 3x3 helpers, 13 neighbour columns of sphere_vs_columns.

@@ -1,7 +1,7 @@
 """Compiler-flag variants of the PRODUCT simulator kernel (sim_step_bpl_kernel, parc_sim.hip alone), timed and checked in one GPU call.
 
-  python tools/sim_variants.py build     # here (no GPU): tools/_simvar/libsim_<name>.so
-  python tools/sim_variants.py run       # on the GPU box: us per 4096-env launch (20 launches replayed in one hipGraph, best of 3) and the
+  python tests/tools/sim_variants.py build     # here (no GPU): tests/tools/_simvar/libsim_<name>.so
+  python tests/tools/sim_variants.py run       # on the GPU box: us per 4096-env launch (20 launches replayed in one hipGraph, best of 3) and the
                                          # largest deviation from the g++ host build of the same equations after 3 env steps on 64 envs
 """
 import ctypes
@@ -11,10 +11,10 @@ import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "parc_amd", "csrc")
-OUT = os.path.join(ROOT, "tools", "_simvar")
+OUT = os.path.join(ROOT, "tests", "tools", "_simvar")
 
 VARIANTS = {
     "O3 with SLP vectorisation (the round-3 build)": "-O3",

@@ -9,7 +9,7 @@ compares the device's reference pose / observation with the CPU oracle at the ti
 slerp (util/torch_util.py:443-468) is discontinuous at `cos >= 1 -> q0` (k = 0 | 1 ulps below one) and at `sin < 1e-3 -> average`
 (k = 8 | 9: 1 - c*c = 2k * 2^-24 exactly for small k, 16 * 2^-24 = 9.5e-7 < 1e-6 < 18 * 2^-24).
 
-    python tools/slerp_outliers.py [--workload iter0_1024clips] [--envs 4096] [--out gpurun_out/slerp_outliers.json]
+    python tests/tools/slerp_outliers.py [--workload iter0_1024clips] [--envs 4096] [--out gpurun_out/slerp_outliers.json]
 """
 import argparse
 import json
@@ -19,7 +19,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():
