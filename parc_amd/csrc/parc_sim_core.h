@@ -33,7 +33,7 @@
 #endif
 
 // PARC_LOOP(k): no-op in the product.  tests/tools/bisect_sim_o3.py rebuilds the simulator sources with -DPARC_BISECT -DPARC_ROLL_<k> (and
-// -I tools, where the macro table parc_sim_bisect.h lives) to keep the loops tagged k rolled at -O3, which is how the -O3 divergence of
+// -I tests/tools, where the macro table parc_sim_bisect.h lives) to keep the loops tagged k rolled at -O3, which is how the -O3 divergence of
 // sim_step_kernel was localised.
 #if defined(PARC_BISECT)
 #include "parc_sim_bisect.h"
