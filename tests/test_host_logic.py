@@ -67,6 +67,33 @@ def test_product_library_carries_no_diagnostics():
         assert "PARC_POST_DIAG" not in text and "PARC_ALLOW_STALE_LIB" not in text and "environ.get(\"PARC_POST" not in text
 
 
+def test_only_the_checkers_touch_the_oracle():
+    """oracle/ is test infrastructure: nothing of the package, of tools/ or of the driver entry points imports it - only tests/ (with
+    tests/tools/), smoke_impl.py (smoke()'s check) and the cpu_baseline leg of bench.py do."""
+    import ast
+    import glob
+    offenders = []
+    files = glob.glob(os.path.join(REPO, "parc_amd", "**", "*.py"), recursive=True) + glob.glob(os.path.join(REPO, "tools", "**", "*.py"), recursive=True) \
+        + [os.path.join(REPO, "__graft_entry__.py"), os.path.join(REPO, "bench.py")]
+    assert len(files) > 60
+    for f in files:
+        tree = ast.parse(open(f).read())
+        for fn_name, node in [(None, n) for n in tree.body] + [(fn.name, n) for fn in ast.walk(tree) if isinstance(fn, (ast.FunctionDef, ast.AsyncFunctionDef))
+                                                              for n in ast.walk(fn)]:
+            mods = []
+            if isinstance(node, ast.Import):
+                mods = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom) and node.level == 0:
+                mods = [node.module or ""]
+            if any(m == "oracle" or m.startswith("oracle.") for m in mods):
+                if not (os.path.basename(f) == "bench.py" and fn_name == "cpu_baseline"):
+                    offenders.append((os.path.relpath(f, REPO), fn_name))
+    assert not offenders, offenders
+    for f in glob.glob(os.path.join(REPO, "parc_amd", "**", "*.py"), recursive=True):
+        text = open(f).read()
+        assert "liboracle" not in text and "parc_oracle" not in text and "sim_host" not in text, f
+
+
 def test_entry_points_refuse_bad_arguments_before_any_launch():
     """Error behaviour of the C ABI (include/parc_hip.h: 0 ok, PARC_EINVAL -1, PARC_EUNSUPPORTED -2): malformed calls of the rollout
     step's entry points are answered before any HIP call - so this runs without a GPU - instead of reaching a kernel with operands
